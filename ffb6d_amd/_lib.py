@@ -1,0 +1,71 @@
+"""ctypes binding of libffb6d_amd.so (the C ABI declared in include/ffb6d_knn.h and
+include/ffb6d_ops.h).  There is NO fallback: if the library is missing or a call fails,
+an exception is raised."""
+import ctypes
+import os
+
+from . import build as _build
+
+_c = ctypes
+_vp, _i64, _i32, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/*.h one to one
+SIGNATURES = {
+    "ffb6d_last_error": (_c.c_char_p, []),
+    "ffb6d_abi_version": (_c.c_int, []),
+    "cpp_knn": (None, [_vp, _sz, _sz, _vp, _sz, _sz, _vp]),
+    "cpp_knn_omp": (None, [_vp, _sz, _sz, _vp, _sz, _sz, _vp]),
+    "cpp_knn_batch": (None, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
+    "cpp_knn_batch_omp": (None, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
+    "ffb6d_knn_workspace_bytes": (_sz, [_i64, _i64, _i64, _i32]),
+    "ffb6d_knn_batch_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ffb6d_random_sample_f32": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_random_sample_bwd_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "ffb6d_nearest_interpolation_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "ffb6d_nearest_interpolation_bwd_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "ffb6d_gather_neighbour_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_gather_neighbour_bwd_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_relative_pos_encoding_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp]),
+    "ffb6d_att_pool_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_att_pool_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_check_index_range": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
+}
+
+_LIB = None
+
+
+class FFB6DNativeError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """dlopen the library (once) and attach the prototypes.  Never builds implicitly:
+    run `python -m ffb6d_amd.build` (or __graft_entry__.build()) first."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FFB6DNativeError(
+            f"{path} is missing: build it with `python -m ffb6d_amd.build` "
+            "(the HIP extension is mandatory, there is no CPU fallback)")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def last_error():
+    return load().ffb6d_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise FFB6DNativeError(f"{what} failed (rc={rc}): {last_error()}")

@@ -1,0 +1,131 @@
+"""Seeded synthetic RGB-D frames and synthetic weights (numpy only, no GPU, no dataset).
+
+There is no network or dataset on the build/bench machines, so every test, golden vector
+and benchmark runs on frames generated here (SURVEY.md section 8d / BASELINE.md section 3):
+
+  depth   z(y,x) = 1.0 + 0.3*sin(x/37)*cos(y/29) + 0.002*N(0,1) metres, 5 % of pixels
+          zeroed (invalid depth); the noise keeps point-to-point distances tie-free
+  xyz     back-projection with the LineMOD intrinsics exactly as `dpt_2_pcld`
+          (ffb6d/datasets/linemod/linemod_dataset.py:188-199; float64 maths, cast to f32
+          where the reference casts: knn.pyx:95-96, linemod_dataset.py:325)
+  choose  the first N entries of a seeded permutation of the valid pixels (the reference
+          samples N valid pixels and shuffles them once, linemod_dataset.py:264-282)
+  rgb     uint8 uniform noise; normals: normalised N(0,1)^3
+  cld_rgb_nrm = [xyz, rgb at the chosen pixels, normals at the chosen pixels]  [9,N]
+                (linemod_dataset.py:284-289)
+
+Seeds follow `1000*config + sample`.
+"""
+import zlib
+
+import numpy as np
+
+LINEMOD_K = np.array([[572.4114, 0.0, 325.2611],
+                      [0.0, 573.57043, 242.04899],
+                      [0.0, 0.0, 1.0]])  # ffb6d/common.py:144-146
+
+
+def frame_seed(config, sample):
+    return 1000 * int(config) + int(sample)
+
+
+def make_frame(seed, n_points=12288, height=480, width=640, invalid_frac=0.05, K=LINEMOD_K):
+    """One synthetic RGB-D frame as the dataset would hand it over (numpy, CPU).
+
+    Returns dict: rgb u8 [3,H,W]; dpt_xyz f32 [3,H,W]; cld f32 [N,3];
+    cld_rgb_nrm f32 [9,N]; choose i32 [1,N].
+    """
+    rng = np.random.RandomState(seed)
+    ys, xs = np.mgrid[:height, :width]
+    z = 1.0 + 0.3 * np.sin(xs / 37.0) * np.cos(ys / 29.0) + 0.002 * rng.standard_normal((height, width))
+    dpt = z.astype(np.float32)
+    dpt[rng.random_sample((height, width)) < invalid_frac] = 0.0
+    # dpt_2_pcld: xmap = row index, ymap = column index (linemod_dataset.py:35-36)
+    msk = (dpt > 1e-8).astype(np.float32)
+    row = (xs - K[0][2]) * dpt / K[0][0]
+    col = (ys - K[1][2]) * dpt / K[1][1]
+    dpt_xyz = np.concatenate((row[..., None], col[..., None], dpt[..., None]), axis=2)
+    dpt_xyz = (dpt_xyz * msk[:, :, None]).astype(np.float32)  # [H,W,3]
+
+    valid = (dpt.reshape(-1) > 1e-6).nonzero()[0]
+    if valid.size < n_points:
+        raise ValueError(f"only {valid.size} valid pixels for n_points={n_points}")
+    choose = valid[rng.permutation(valid.size)[:n_points]].astype(np.int32)
+
+    rgb = rng.randint(0, 256, size=(height, width, 3)).astype(np.uint8)
+    nrm = rng.standard_normal((height, width, 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=2, keepdims=True)).astype(np.float32)
+
+    cld = dpt_xyz.reshape(-1, 3)[choose, :]
+    rgb_pt = rgb.reshape(-1, 3)[choose, :].astype(np.float32)
+    nrm_pt = nrm.reshape(-1, 3)[choose, :]
+    cld_rgb_nrm = np.concatenate((cld, rgb_pt, nrm_pt), axis=1).transpose(1, 0)
+    return dict(
+        rgb=np.ascontiguousarray(rgb.transpose(2, 0, 1)),
+        dpt_xyz=np.ascontiguousarray(dpt_xyz.transpose(2, 0, 1)),
+        cld=np.ascontiguousarray(cld, dtype=np.float32),
+        cld_rgb_nrm=np.ascontiguousarray(cld_rgb_nrm, dtype=np.float32),
+        choose=choose[None, :].copy(),
+    )
+
+
+def make_batch(config, batch_size, **kw):
+    """Stack `batch_size` frames with seeds 1000*config + sample."""
+    frames = [make_frame(frame_seed(config, s), **kw) for s in range(batch_size)]
+    return {k: np.stack([f[k] for f in frames], axis=0) for k in frames[0]}
+
+
+def strided_grids(dpt_xyz):
+    """`sr2dptxyz` of linemod_dataset.py:299-311: xyz image sub-sampled at stride 1,2,4,8,
+    pixel (y*s, x*s), flattened to [G_s,3].  dpt_xyz: [3,H,W] or [B,3,H,W]."""
+    out = {}
+    for s in (1, 2, 4, 8):
+        h, w = dpt_xyz.shape[-2] // s, dpt_xyz.shape[-1] // s
+        g = dpt_xyz[..., : h * s : s, : w * s : s]
+        g = g.reshape(*g.shape[:-2], -1)
+        out[s] = np.ascontiguousarray(np.swapaxes(g, -1, -2))
+    return out
+
+
+# ------------------------------------------------------------------------------------
+# synthetic weights: deterministic per parameter NAME, so the reference model (golden
+# generation, build container) and our modules (GPU box) get identical values without
+# shipping a 135 MB checkpoint.
+# ------------------------------------------------------------------------------------
+def _tensor_seed(name, seed):
+    return (zlib.crc32(name.encode("utf-8")) ^ (seed * 2654435761)) & 0x7FFFFFFF
+
+
+def synth_tensor(name, shape, seed=0):
+    """float32/int64 numpy array for state-dict entry `name` (shape from the module)."""
+    rng = np.random.RandomState(_tensor_seed(name, seed))
+    shape = tuple(int(s) for s in shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, dtype=np.int64)
+    if leaf == "running_var":
+        return rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+    if leaf == "running_mean":
+        return (0.1 * rng.standard_normal(shape)).astype(np.float32)
+    if leaf == "bias":
+        return (0.05 * rng.standard_normal(shape)).astype(np.float32)
+    if len(shape) <= 1:  # BatchNorm gamma / PReLU slope
+        if shape == (1,):
+            return np.full(shape, 0.25, dtype=np.float32)
+        return rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    return (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+
+
+def synth_state_dict(module, seed=0):
+    """Deterministic state dict for a torch module with the reference's key names.
+    Entries that alias the same storage (the reference shares `cnn.final` between
+    cnn_up_stages[2] and [3], ffb6d.py:86-87) get the values of the first alias."""
+    import torch
+
+    out, first_name = {}, {}
+    for name, t in module.state_dict().items():
+        key = (t.data_ptr(), tuple(t.shape)) if t.numel() > 0 else (name, ())
+        src = first_name.setdefault(key, name)
+        out[name] = torch.from_numpy(synth_tensor(src, t.shape, seed)).to(t.dtype)
+    return out

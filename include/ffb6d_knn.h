@@ -1,0 +1,90 @@
+/*
+ * include/ffb6d_knn.h -- C ABI of the MI355X-native exact K-nearest-neighbour search.
+ *
+ * Drop-in for the reference's native KNN unit
+ *     ffb6d/models/RandLA/utils/nearest_neighbors/knn_.h:4-27   (declarations)
+ *     ffb6d/models/RandLA/utils/nearest_neighbors/knn_.cxx:22-135 (definitions)
+ * which the reference binds from Cython (knn.pyx:7-30 `cdef extern from "knn_.h"`).
+ * The four host-pointer entry points below keep the reference's names, argument order
+ * and meaning, so knn.pyx can bind this library instead of knn_.cxx unchanged
+ * (see INTEGRATION.md).  The result is the exact K-NN set in ascending distance order;
+ * squared distances are evaluated in float32 as ((dx*dx + dy*dy) + dz*dz) with no FMA
+ * contraction (nanoflann.hpp:323-348); equal distances resolve to the LOWEST support
+ * index (the reference's kd-tree keeps the first-visited member of a tie,
+ * nanoflann.hpp:115-139 -- identical whenever distances are distinct).
+ *
+ * Differences from the reference, all loud instead of silent:
+ *   - dim must be 3 and 1 <= K <= 32, npts >= K (the reference leaves stale output
+ *     for npts < K, knn_.cxx:121-131); violations are reported through
+ *     ffb6d_last_error() and the output is left untouched.
+ *   - `_omp` and non-`_omp` variants are the same GPU launch (there is no host loop).
+ *   - cpp_knn_batch_distance_pick[_omp] (knn_.cxx:138-271) are NOT provided: they are
+ *     unused by FFB6D and seeded from time(0), i.e. not reproducible by construction.
+ *
+ * All pointers are plain host pointers for the cpp_* functions (the library stages them
+ * through device memory itself) and plain device pointers for the ffb6d_*_device
+ * functions.  No torch types cross this boundary.
+ */
+#ifndef FFB6D_KNN_H_
+#define FFB6D_KNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* hipStream_t passed as an opaque pointer (NULL = the default stream). */
+typedef void* ffb6d_stream_t;
+
+/* 0 on success; negative on error (message via ffb6d_last_error()). */
+#define FFB6D_OK 0
+#define FFB6D_ERR_ARG (-1)
+#define FFB6D_ERR_HIP (-2)
+#define FFB6D_ERR_WORKSPACE (-3)
+
+/* Thread-local description of the last error raised by any entry point. */
+const char* ffb6d_last_error(void);
+
+/* Library/ABI version (major*1000 + minor). */
+int ffb6d_abi_version(void);
+
+/* ---- host-pointer entry points: same names/signatures as knn_.h:4-19 ------------- */
+/* points [npts,dim] f32, queries [nqueries,dim] f32, indices [nqueries,K] long (caller allocated) */
+void cpp_knn(const float* points, const size_t npts, const size_t dim,
+             const float* queries, const size_t nqueries,
+             const size_t K, long* indices);
+void cpp_knn_omp(const float* points, const size_t npts, const size_t dim,
+                 const float* queries, const size_t nqueries,
+                 const size_t K, long* indices);
+/* batch_data [B,npts,dim], queries [B,nqueries,dim], batch_indices [B,nqueries,K] */
+void cpp_knn_batch(const float* batch_data, const size_t batch_size, const size_t npts,
+                   const size_t dim, const float* queries, const size_t nqueries,
+                   const size_t K, long* batch_indices);
+void cpp_knn_batch_omp(const float* batch_data, const size_t batch_size, const size_t npts,
+                       const size_t dim, const float* queries, const size_t nqueries,
+                       const size_t K, long* batch_indices);
+
+/* ---- device-pointer entry points ------------------------------------------------ */
+/* Scratch bytes ffb6d_knn_batch_device needs for this shape (0 is possible). */
+size_t ffb6d_knn_workspace_bytes(int64_t batch_size, int64_t npts, int64_t nqueries, int K);
+
+/*
+ * support [B,npts,3] f32, query [B,nqueries,3] f32 (device, contiguous).
+ * Any of the three outputs may be NULL:
+ *   idx64 [B,nqueries,K] int64  -- what knn.pyx:93 allocates
+ *   idx32 [B,nqueries,K] int32  -- what DataProcessing.knn_search returns (helper_tool.py:170)
+ *   dist  [B,nqueries,K] f32    -- squared distances, ascending
+ * workspace: device scratch of at least ffb6d_knn_workspace_bytes(...) bytes (may be NULL
+ * when that is 0).  Stream-ordered on `stream`; does not synchronise.
+ */
+int ffb6d_knn_batch_device(const float* support, const float* query,
+                           int64_t batch_size, int64_t npts, int64_t nqueries, int K,
+                           int64_t* idx64, int32_t* idx32, float* dist,
+                           void* workspace, size_t workspace_bytes, ffb6d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFB6D_KNN_H_ */

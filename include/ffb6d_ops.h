@@ -1,0 +1,90 @@
+/*
+ * include/ffb6d_ops.h -- C ABI of the MI355X-native RandLA-Net neighbour ops and the
+ * pixel<->point fusion gathers of FFB6D.  Every function is the device-side body of one
+ * reference Python operator (the reference has no native code for these; it composes
+ * torch.gather/max/softmax -- SURVEY.md section 2b), with the reference's tensor layouts:
+ *
+ *   ffb6d_random_sample_f32           FFB6D.random_sample           ffb6d/models/ffb6d.py:159-177
+ *   ffb6d_nearest_interpolation_f32   FFB6D.nearest_interpolation   ffb6d/models/ffb6d.py:179-194
+ *                                     (also the `choose` gather,    ffb6d/models/ffb6d.py:309-312)
+ *   ffb6d_gather_neighbour_f32        Building_block.gather_neighbour        RandLANet.py:225-234
+ *   ffb6d_relative_pos_encoding_f32   Building_block.relative_pos_encoding   RandLANet.py:216-223
+ *   ffb6d_att_pool_f32                Att_pooling.forward softmax/mul/sum    RandLANet.py:245-248
+ *   *_bwd_f32                         the autograd of the above (the reference gets it from torch)
+ *
+ * Conventions: all tensors are contiguous row-major device buffers, features float32;
+ * index tensors are int64 (what the model receives, train_lm.py:236-237) or int32 (what
+ * the dataset produces, linemod_dataset.py:319-339) selected by `idx_bits` (64 or 32);
+ * indices must lie in [0, M) -- out-of-range indices are a caller error and are
+ * reported by ffb6d_check_index_range(), the kernels themselves do not bounds-check.
+ * Calls are stream-ordered on `stream` and never synchronise.
+ * Return: FFB6D_OK or a negative FFB6D_ERR_* (message via ffb6d_last_error()).
+ */
+#ifndef FFB6D_OPS_H_
+#define FFB6D_OPS_H_
+
+#include "ffb6d_knn.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[b,c,n] = max_k feat[b,c,idx[b,n,k]]           feat [B,C,M], idx [B,Np,K], out [B,C,Np]
+ * arg (nullable) [B,C,Np] int32: the winning source column (first maximum in k order,
+ * as torch.max returns), used by the backward. */
+int ffb6d_random_sample_f32(const float* feat, const void* idx, int idx_bits,
+                            float* out, int32_t* arg,
+                            int64_t B, int64_t C, int64_t M, int64_t Np, int K,
+                            ffb6d_stream_t stream);
+
+/* grad_feat[b,c,arg[b,c,n]] += grad_out[b,c,n]; grad_feat [B,C,M] is zeroed first. */
+int ffb6d_random_sample_bwd_f32(const float* grad_out, const int32_t* arg, float* grad_feat,
+                                int64_t B, int64_t C, int64_t M, int64_t Np,
+                                ffb6d_stream_t stream);
+
+/* out[b,c,u] = feat[b,c,idx[b,u]]                   feat [B,C,M], idx [B,U], out [B,C,U] */
+int ffb6d_nearest_interpolation_f32(const float* feat, const void* idx, int idx_bits,
+                                    float* out,
+                                    int64_t B, int64_t C, int64_t M, int64_t U,
+                                    ffb6d_stream_t stream);
+
+/* grad_feat[b,c,idx[b,u]] += grad_out[b,c,u]; grad_feat [B,C,M] is zeroed first. */
+int ffb6d_nearest_interpolation_bwd_f32(const float* grad_out, const void* idx, int idx_bits,
+                                        float* grad_feat,
+                                        int64_t B, int64_t C, int64_t M, int64_t U,
+                                        ffb6d_stream_t stream);
+
+/* out[b,n,k,:] = pc[b,idx[b,n,k],:]                 pc [B,M,C], idx [B,N,K], out [B,N,K,C] */
+int ffb6d_gather_neighbour_f32(const float* pc, const void* idx, int idx_bits, float* out,
+                               int64_t B, int64_t M, int64_t C, int64_t N, int K,
+                               ffb6d_stream_t stream);
+
+/* grad_pc[b,idx[b,n,k],:] += grad_out[b,n,k,:]; grad_pc [B,M,C] is zeroed first. */
+int ffb6d_gather_neighbour_bwd_f32(const float* grad_out, const void* idx, int idx_bits,
+                                   float* grad_pc,
+                                   int64_t B, int64_t M, int64_t C, int64_t N, int K,
+                                   ffb6d_stream_t stream);
+
+/* out[b,n,k,0:10] = [ |p-q|, p-q, p, q ],  p = xyz[b,n], q = xyz[b,idx[b,n,k]]
+ * xyz [B,N,3], idx [B,N,K], out [B,N,K,10];  |.| = sqrt((dx*dx+dy*dy)+dz*dz), f32, no FMA */
+int ffb6d_relative_pos_encoding_f32(const float* xyz, const void* idx, int idx_bits, float* out,
+                                    int64_t B, int64_t N, int K, ffb6d_stream_t stream);
+
+/* s = softmax_k(act[b,c,n,:]);  out[b,c,n] = sum_k feat[b,c,n,k] * s[k]
+ * feat, act [B,C,N,K] (K in {1,2,4,8,16,32}), out [B,C,N] */
+int ffb6d_att_pool_f32(const float* feat, const float* act, float* out,
+                       int64_t B, int64_t C, int64_t N, int K, ffb6d_stream_t stream);
+
+/* grad_feat = g*s ; grad_act = g*s*(feat - out)  with g = grad_out[b,c,n] broadcast over k */
+int ffb6d_att_pool_bwd_f32(const float* grad_out, const float* feat, const float* act,
+                           float* grad_feat, float* grad_act,
+                           int64_t B, int64_t C, int64_t N, int K, ffb6d_stream_t stream);
+
+/* Debug helper: number of entries of idx[0:count] outside [0, M) written to *bad (device int32). */
+int ffb6d_check_index_range(const void* idx, int idx_bits, int64_t count, int64_t M,
+                            int32_t* bad, ffb6d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFB6D_OPS_H_ */

@@ -1,0 +1,58 @@
+"""oracle/knn.py -- TEST INFRASTRUCTURE ONLY.  ctypes front-end of oracle/knn_oracle.c (our
+CPU restatement of knn_.cxx:104-135) with the marshalling of knn.pyx:71-109 and of
+DataProcessing.knn_search (helper_tool.py:160-170)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "liboracle_knn.so")
+_lib = None
+
+
+def build():
+    """(Re)build the C restatement and, where /root/reference exists, oracle/_ref."""
+    subprocess.run(["make", "-C", HERE, "all"], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            build()
+        l = ctypes.CDLL(SO)
+        vp, sz = ctypes.c_void_p, ctypes.c_size_t
+        l.oracle_knn_batch.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp]
+        l.oracle_knn_batch.restype = None
+        l.oracle_knn_batch_dist.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp, vp]
+        l.oracle_knn_batch_dist.restype = None
+        _lib = l
+    return _lib
+
+
+def knn_batch(pts, queries, K, omp=False, return_dist=False):
+    """knn.pyx:71-109: float32 contiguous copies in, zero-initialised int64 [B,Q,K] out."""
+    p = np.ascontiguousarray(pts, dtype=np.float32)
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    B, npts, dim = p.shape
+    nq = q.shape[1]
+    idx = np.zeros((B, nq, K), dtype=np.int64)
+    if return_dist:
+        dist = np.zeros((B, nq, K), dtype=np.float32)
+        lib().oracle_knn_batch_dist(p.ctypes.data, B, npts, dim, q.ctypes.data, nq, K,
+                                    idx.ctypes.data, dist.ctypes.data)
+        return idx, dist
+    lib().oracle_knn_batch(p.ctypes.data, B, npts, dim, q.ctypes.data, nq, K, idx.ctypes.data)
+    return idx
+
+
+def knn(pts, queries, K, omp=False):
+    """knn.pyx:32-69 (single cloud)."""
+    return knn_batch(np.asarray(pts)[None], np.asarray(queries)[None], K)[0]
+
+
+def knn_search(support_pts, query_pts, k):
+    """helper_tool.py:160-170."""
+    return knn_batch(support_pts, query_pts, k, omp=True).astype(np.int32)
