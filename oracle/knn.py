@@ -56,3 +56,28 @@ def knn(pts, queries, K, omp=False):
 def knn_search(support_pts, query_pts, k):
     """helper_tool.py:160-170."""
     return knn_batch(support_pts, query_pts, k, omp=True).astype(np.int32)
+
+
+def sqdist_f32(q, p):
+    """((dx*dx + dy*dy) + dz*dz) with every op rounded to f32 (nanoflann.hpp:323-348)."""
+    q = np.asarray(q, np.float32)
+    p = np.asarray(p, np.float32)
+    d = q - p
+    return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+
+
+def canonical_ties(idx, support, query):
+    """Re-order every run of EQUAL distances inside a KNN row by ascending index.
+
+    The reference's kd-tree keeps the first-VISITED candidate of an exact distance tie
+    (nanoflann.hpp:118-135), which depends on the tree traversal; the oracle and the HIP
+    kernel keep the lowest index.  Both orders list the same neighbours at the same
+    distances; this maps either of them to one canonical form so they can be compared
+    bit-exactly.  idx [Q,K] into support [S,3]; query [Q,3].  Returns (canonical idx,
+    number of rows that contained a tie)."""
+    idx = np.asarray(idx)
+    d = sqdist_f32(np.asarray(query)[:, None, :], np.asarray(support)[idx.astype(np.int64)])
+    order = np.lexsort((idx, d), axis=-1)
+    canon = np.take_along_axis(idx, order, axis=-1)
+    ties = int(((np.diff(d, axis=-1) == 0).any(axis=-1)).sum()) if idx.shape[-1] > 1 else 0
+    return canon, ties

@@ -56,3 +56,26 @@ def build_batch(frames, knn_search):
     per = [build_pyramid(frames['cld'][b], frames['dpt_xyz'][b], knn_search)
            for b in range(frames['cld'].shape[0])]
     return {k: np.stack([p[k] for p in per], axis=0) for k in per[0]}
+
+
+def knn_calls(pyr, dpt_xyz_chw):
+    """The (support, query) pair behind every index tensor of one frame's pyramid:
+    {key: (support [S,3], query [Q,3])}, for tie canonicalisation (oracle.knn.canonical_ties)."""
+    grids = strided_grids(dpt_xyz_chw)
+    calls = {}
+    for i in range(N_DS):
+        cld = pyr['cld_xyz%d' % i]
+        n_sub = cld.shape[0] // PCLD_SUB_SR[i]
+        sub = cld[:n_sub]
+        g = np.ascontiguousarray(grids[RGB_DS_SR[i]], dtype=np.float32)
+        calls['cld_nei_idx%d' % i] = (cld, cld)
+        calls['cld_sub_idx%d' % i] = (cld, sub)
+        calls['cld_interp_idx%d' % i] = (sub, cld)
+        calls['r2p_ds_nei_idx%d' % i] = (g, sub)
+        calls['p2r_ds_nei_idx%d' % i] = (sub, g)
+    for i in range(N_UP):
+        g = np.ascontiguousarray(grids[RGB_UP_SR[i]], dtype=np.float32)
+        pts = pyr['cld_xyz%d' % (N_DS - i - 1)]
+        calls['r2p_up_nei_idx%d' % i] = (g, pts)
+        calls['p2r_up_nei_idx%d' % i] = (pts, g)
+    return calls

@@ -1,0 +1,97 @@
+"""CPU suite: the C-ABI library builds, loads and exports every symbol that include/*.h
+declares (no compute calls -- there is no GPU here), and the Python host layer fails
+loudly instead of falling back."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def declared_functions():
+    names = []
+    for hdr in ("ffb6d_knn.h", "ffb6d_ops.h"):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(\w+)\s*\(", src, flags=re.M):
+            name = m.group(1)
+            if name.startswith(("ffb6d_", "cpp_knn")):
+                names.append(name)
+    return sorted(set(names))
+
+
+def test_headers_declare_the_expected_entry_points():
+    names = declared_functions()
+    for must in ("cpp_knn", "cpp_knn_omp", "cpp_knn_batch", "cpp_knn_batch_omp",
+                 "ffb6d_knn_batch_device", "ffb6d_random_sample_f32",
+                 "ffb6d_nearest_interpolation_f32", "ffb6d_gather_neighbour_f32",
+                 "ffb6d_relative_pos_encoding_f32", "ffb6d_att_pool_f32"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(native_lib):
+    from ffb6d_amd import _lib
+    for name in declared_functions():
+        assert hasattr(native_lib, name), f"{name} declared in include/ but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
+    assert native_lib.ffb6d_abi_version() >= 1000
+
+
+def test_workspace_query_is_pure_host_logic(native_lib):
+    # many query blocks -> no split, no scratch; few queries against a big grid -> split-S scratch
+    assert native_lib.ffb6d_knn_workspace_bytes(64, 12288, 12288, 16) == 0
+    assert native_lib.ffb6d_knn_workspace_bytes(8, 76800, 768, 16) > 0
+    assert native_lib.ffb6d_knn_workspace_bytes(0, 10, 10, 16) == 0
+
+
+def test_argument_errors_are_reported_without_a_gpu(native_lib):
+    from ffb6d_amd import _lib
+    rc = native_lib.ffb6d_knn_batch_device(None, None, 1, 100, 10, 64, None, None, None, None, 0, None)
+    assert rc != 0 and "K must be" in _lib.last_error()
+    rc = native_lib.ffb6d_knn_batch_device(None, None, 1, 8, 10, 16, None, None, None, None, 0, None)
+    assert rc != 0 and "npts" in _lib.last_error()
+    rc = native_lib.ffb6d_random_sample_f32(None, None, 16, None, None, 1, 1, 1, 1, 16, None)
+    assert rc != 0 and "idx_bits" in _lib.last_error()
+
+
+def test_ops_refuse_cpu_tensors():
+    from ffb6d_amd import _lib, ops
+    f = torch.zeros(1, 4, 10, 1)
+    i = torch.zeros(1, 3, 16, dtype=torch.int64)
+    with pytest.raises(_lib.FFB6DNativeError):
+        ops.random_sample(f, i)
+    with pytest.raises(_lib.FFB6DNativeError):
+        ops.nearest_interpolation(f, torch.zeros(1, 5, 1, dtype=torch.int64))
+    with pytest.raises(_lib.FFB6DNativeError):
+        ops.gather_neighbour(torch.zeros(1, 10, 4), i)
+    with pytest.raises(_lib.FFB6DNativeError):
+        ops.att_pool(torch.zeros(1, 2, 3, 16), torch.zeros(1, 2, 3, 16))
+
+
+def test_knn_python_boundary_validates_like_the_header_says(native_lib):
+    from ffb6d_amd import nearest_neighbors as nn
+    pts = np.zeros((2, 10, 3), np.float32)
+    with pytest.raises(ValueError):
+        nn.knn_batch(pts, pts, 16)           # npts < K
+    with pytest.raises(ValueError):
+        nn.knn_batch(pts, pts[:1], 4)        # batch mismatch
+    with pytest.raises(ValueError):
+        nn.knn_batch(np.zeros((2, 10, 4), np.float32), np.zeros((2, 10, 4), np.float32), 4)  # dim != 3
+    with pytest.raises(ValueError):
+        nn.knn(np.zeros((10, 3), np.float32), np.zeros((10, 3), np.float32), 33)
+
+
+def test_synthetic_frames_are_deterministic():
+    from ffb6d_amd import synth
+    a = synth.make_frame(2000, n_points=768, height=120, width=160)
+    b = synth.make_frame(2000, n_points=768, height=120, width=160)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    assert a["cld"].shape == (768, 3) and a["cld_rgb_nrm"].shape == (9, 768)
+    assert (a["cld"][:, 2] > 0).all()  # only valid-depth pixels are chosen
+    g = synth.strided_grids(a["dpt_xyz"])
+    assert g[4].shape == (30 * 40, 3) and g[8].shape == (15 * 20, 3)
+    np.testing.assert_array_equal(g[4][41], a["dpt_xyz"][:, 4, 4])  # pixel (y*s, x*s), row-major

@@ -1,0 +1,136 @@
+"""GPU parity of the neighbour operators (through the C ABI) against the reference goldens
+and a plain PyTorch fp32 CPU restatement (oracle/ops_ref.py).  Bar: gathers / max pooling
+bit-exact; softmax pooling and position encoding within 1e-5 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from ffb6d_amd import ops
+from oracle import ops_ref
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def test_ops_match_reference_goldens(device):
+    z = np.load(os.path.join(GOLDEN, "ops_small.npz"))
+    t = lambda k: torch.from_numpy(z[k]).to(device)
+    for idt in (torch.int64, torch.int32):
+        np.testing.assert_array_equal(ops.random_sample(t("feat").unsqueeze(3), t("pool_idx").to(idt)).cpu().numpy(),
+                                      z["random_sample"])
+        np.testing.assert_array_equal(ops.nearest_interpolation(t("feat").unsqueeze(3), t("interp_idx").to(idt)).cpu().numpy(),
+                                      z["nearest_interpolation"])
+        np.testing.assert_array_equal(ops.gather_neighbour(t("pc"), t("nei").to(idt)).cpu().numpy(), z["gather_neighbour"])
+        rpe = ops.relative_pos_encoding(t("xyz"), t("nei").to(idt)).cpu().numpy()
+        np.testing.assert_array_equal(rpe[..., 1:], z["relative_pos_encoding"][..., 1:])
+        # the norm column differs from torch-CPU's by <= 1 ulp in ~0.1 % of entries (numpy's
+        # own (x+y)+z, sqrt differs from torch in as many); the bar for features is 1e-5
+        np.testing.assert_allclose(rpe[..., 0], z["relative_pos_encoding"][..., 0], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ops.att_pool(t("fs"), t("act")).cpu().numpy(), z["att_pool"], **TOL)
+
+
+# (C, M, Np) shapes of FFB6D at N=12288 plus ragged ones
+@pytest.mark.parametrize("B,C,M,Np,K", [(2, 64, 12288, 3072, 16), (1, 1024, 4800, 48, 16), (2, 64, 76800, 768, 16),
+                                        (1, 5, 37, 300, 16), (3, 7, 100, 1, 4), (1, 512, 192, 48, 16)])
+def test_random_sample(device, B, C, M, Np, K):
+    g = torch.Generator().manual_seed(C + M + Np)
+    feat = torch.randn(B, C, M, generator=g)
+    idx = torch.randint(0, M, (B, Np, K), generator=g)
+    want = ops_ref.random_sample(feat, idx)
+    got = ops.random_sample(feat.to(device).unsqueeze(3), idx.to(device))
+    assert got.shape == (B, C, Np, 1)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(ops.random_sample(feat.to(device), idx.to(device).int()).cpu(), want)  # 3-d feature, int32 idx
+
+
+@pytest.mark.parametrize("B,C,M,U", [(2, 64, 3072, 19200), (1, 1024, 48, 4800), (1, 64, 3072, 76800),
+                                     (2, 9, 50, 333), (1, 3, 5, 1), (1, 512, 48, 192)])
+def test_nearest_interpolation(device, B, C, M, U):
+    g = torch.Generator().manual_seed(C + M + U)
+    feat = torch.randn(B, C, M, 1, generator=g)
+    idx = torch.randint(0, M, (B, U, 1), generator=g)
+    want = ops_ref.nearest_interpolation(feat, idx)
+    got = ops.nearest_interpolation(feat.to(device), idx.to(device))
+    assert got.shape == (B, C, U, 1)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_choose_gather(device):
+    g = torch.Generator().manual_seed(1)
+    rgb = torch.randn(2, 64, 30, 40, generator=g)
+    choose = torch.randint(0, 1200, (2, 1, 500), generator=g)
+    want = torch.gather(rgb.view(2, 64, -1), 2, choose.repeat(1, 64, 1))   # ffb6d.py:309-312
+    assert torch.equal(ops.choose_gather(rgb.to(device), choose.to(device)).cpu(), want)
+
+
+@pytest.mark.parametrize("B,N,C,K", [(2, 3072, 32, 16), (1, 500, 3, 16), (1, 192, 128, 16), (2, 77, 6, 5)])
+def test_gather_neighbour(device, B, N, C, K):
+    g = torch.Generator().manual_seed(N + C)
+    pc = torch.randn(B, N, C, generator=g)
+    idx = torch.randint(0, N, (B, N, K), generator=g)
+    got = ops.gather_neighbour(pc.to(device), idx.to(device))
+    assert got.shape == (B, N, K, C)
+    assert torch.equal(got.cpu(), ops_ref.gather_neighbour(pc, idx))
+
+
+@pytest.mark.parametrize("B,N,K", [(2, 3072, 16), (1, 100, 16), (3, 33, 7), (1, 12288, 16)])
+def test_relative_pos_encoding(device, B, N, K):
+    g = torch.Generator().manual_seed(N + K)
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    idx = torch.randint(0, N, (B, N, K), generator=g)
+    got = ops.relative_pos_encoding(xyz.to(device), idx.to(device)).cpu()
+    want = ops_ref.relative_pos_encoding(xyz, idx)
+    assert got.shape == (B, N, K, 10)
+    assert torch.equal(got[..., 1:], want[..., 1:])              # differences and copies are exact
+    torch.testing.assert_close(got[..., 0], want[..., 0], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,C,N,K", [(2, 32, 3072, 16), (1, 256, 192, 16), (1, 5, 33, 16), (2, 4, 50, 8),
+                                     (1, 3, 20, 32), (1, 3, 20, 4), (1, 6, 11, 5)])
+def test_att_pool(device, B, C, N, K):
+    g = torch.Generator().manual_seed(C + N + K)
+    fs = torch.randn(B, C, N, K, generator=g)
+    act = 4 * torch.randn(B, C, N, K, generator=g)
+    got = ops.att_pool(fs.to(device), act.to(device))
+    assert got.shape == (B, C, N, 1)
+    torch.testing.assert_close(got.cpu(), ops_ref.att_pool(fs, act), **TOL)
+
+
+def test_backward_matches_torch_autograd(device):
+    g = torch.Generator().manual_seed(8)
+    B, C, M, Np, K, U = 2, 6, 40, 17, 16, 90
+    feat = torch.randn(B, C, M, generator=g)
+    pool = torch.randint(0, M, (B, Np, K), generator=g)
+    up = torch.randint(0, M, (B, U, 1), generator=g)
+    pc = torch.randn(B, M, 8, generator=g)
+    nei = torch.randint(0, M, (B, M, K), generator=g)
+    fs = torch.randn(B, C, 21, K, generator=g)
+    act = torch.randn(B, C, 21, K, generator=g)
+
+    def grads(fn, *leaves):
+        ls = [l.clone().requires_grad_(True) for l in leaves]
+        out = fn(*ls)
+        w = torch.linspace(-1, 1, out.numel(), device=out.device).view_as(out)
+        (out * w).sum().backward()
+        return [l.grad.cpu() for l in ls]
+
+    d = lambda x: x.to(device)
+    (a,), (b,) = grads(lambda f: ops.random_sample(f, d(pool)), d(feat)), grads(lambda f: ops_ref.random_sample(f, pool), feat)
+    torch.testing.assert_close(a, b, **TOL)
+    (a,), (b,) = grads(lambda f: ops.nearest_interpolation(f.unsqueeze(3), d(up)), d(feat)), \
+        grads(lambda f: ops_ref.nearest_interpolation(f.unsqueeze(3), up), feat)
+    torch.testing.assert_close(a, b, **TOL)
+    (a,), (b,) = grads(lambda p: ops.gather_neighbour(p, d(nei)), d(pc)), grads(lambda p: ops_ref.gather_neighbour(p, nei), pc)
+    torch.testing.assert_close(a, b, **TOL)
+    a, b = grads(ops.att_pool, d(fs), d(act)), grads(ops_ref.att_pool, fs, act)
+    torch.testing.assert_close(a[0], b[0], **TOL)
+    torch.testing.assert_close(a[1], b[1], **TOL)
+
+
+def test_index_range_check(device):
+    idx = torch.tensor([[0, 5, 9, 10, -1]], device=device)
+    assert ops.check_index_range(idx, 10) == 2
+    assert ops.check_index_range(idx.int()[:, :3], 10) == 0

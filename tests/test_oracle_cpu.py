@@ -1,0 +1,116 @@
+"""CPU suite: the oracle (our restatement of the reference algorithm) against the golden
+vectors produced by the reference itself, and -- where /root/reference exists -- against
+the reference's own compiled kd-tree."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from ffb6d_amd import synth
+from oracle import knn as oknn
+from oracle import ops_ref
+from oracle import pyramid as opyr
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def knn_small():
+    return np.load(os.path.join(GOLDEN, "knn_small.npz"))
+
+
+def case_names(z):
+    return sorted({k.split("/")[0] for k in z.files})
+
+
+def test_oracle_knn_matches_reference_goldens(knn_small):
+    for name in case_names(knn_small):
+        sup, qry = knn_small[name + "/support"], knn_small[name + "/query"]
+        K = int(knn_small[name + "/K"])
+        got = oknn.knn_batch(sup, qry, K)
+        assert got.dtype == np.int64 and got.shape == (sup.shape[0], qry.shape[1], K)
+        np.testing.assert_array_equal(got.astype(np.int32), knn_small[name + "/idx"], err_msg=name)
+
+
+def test_oracle_knn_sorted_and_exact_by_numpy():
+    rng = np.random.RandomState(5)
+    sup = rng.rand(1, 700, 3).astype(np.float32)
+    qry = rng.rand(1, 50, 3).astype(np.float32)
+    idx, dist = oknn.knn_batch(sup, qry, 16, return_dist=True)
+    assert (np.diff(dist, axis=-1) >= 0).all()
+    d = qry[0][:, None, :] - sup[0][None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    ref = np.argsort(d2, axis=1, kind="stable")[:, :16]
+    np.testing.assert_array_equal(idx[0], ref)
+
+
+def test_oracle_knn_duplicate_points_lowest_index_first():
+    base = np.random.RandomState(9).rand(40, 3).astype(np.float32)
+    sup = np.concatenate([base, base, base], axis=0)[None]  # every point three times
+    idx, dist = oknn.knn_batch(sup, base[None], 3, return_dist=True)
+    np.testing.assert_array_equal(dist[0], 0.0)
+    np.testing.assert_array_equal(idx[0], np.arange(40)[:, None] + np.array([0, 40, 80])[None])
+
+
+@pytest.mark.parametrize("tag", ["c2_s0_n12288", "c2_s1_n12288"])
+def test_oracle_pyramid_matches_reference_hashes(tag):
+    with open(os.path.join(GOLDEN, "knn_pyramid_hashes.json")) as fh:
+        gold = json.load(fh)[tag]
+    f = synth.make_frame(synth.frame_seed(gold["config"], gold["sample"]), n_points=gold["n_points"])
+    assert sha(f["cld"]) == gold["cld_sha256"], "synthetic frame generator drifted"
+    assert sha(f["dpt_xyz"]) == gold["dpt_xyz_sha256"]
+    pyr = opyr.build_pyramid(f["cld"], f["dpt_xyz"], oknn.knn_search)
+    calls = opyr.knn_calls(pyr, f["dpt_xyz"])
+    for k, v in pyr.items():
+        assert list(v.shape) == gold[k]["shape"] and str(v.dtype) == gold[k]["dtype"], k
+        if k in calls:   # tie runs in canonical (distance, index) order, see oracle.knn.canonical_ties
+            v, _ = oknn.canonical_ties(v, *calls[k])
+        assert sha(v.astype(np.int32) if k in calls else v) == gold[k]["sha256"], \
+            f"{k} differs from the reference kd-tree result"
+
+
+def test_ops_ref_matches_reference_goldens():
+    z = np.load(os.path.join(GOLDEN, "ops_small.npz"))
+    t = torch.from_numpy
+    np.testing.assert_array_equal(ops_ref.random_sample(t(z["feat"]), t(z["pool_idx"])).numpy(), z["random_sample"])
+    np.testing.assert_array_equal(ops_ref.nearest_interpolation(t(z["feat"]).unsqueeze(3), t(z["interp_idx"])).numpy(),
+                                  z["nearest_interpolation"])
+    np.testing.assert_array_equal(ops_ref.gather_neighbour(t(z["pc"]), t(z["nei"])).numpy(), z["gather_neighbour"])
+    np.testing.assert_allclose(ops_ref.relative_pos_encoding(t(z["xyz"]), t(z["nei"])).numpy(),
+                               z["relative_pos_encoding"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(ops_ref.att_pool(t(z["fs"]), t(z["act"])).numpy(), z["att_pool"], rtol=1e-6, atol=1e-6)
+
+
+# ---- direct comparisons with the reference's own code (build container only) ------------
+@pytest.mark.reference
+@pytest.mark.parametrize("B,S,Q,K", [(1, 3000, 3000, 16), (2, 777, 1500, 1), (1, 4800, 48, 16), (1, 48, 4800, 1)])
+def test_oracle_knn_equals_reference_kdtree(B, S, Q, K):
+    from oracle import ref_harness as rh
+    rng = np.random.RandomState(S + Q + K)
+    sup = rng.rand(B, S, 3).astype(np.float32)
+    qry = rng.rand(B, Q, 3).astype(np.float32)
+    np.testing.assert_array_equal(oknn.knn_batch(sup, qry, K), rh.ref_knn_batch(sup, qry, K, omp=True))
+
+
+@pytest.mark.reference
+def test_ops_ref_equals_reference_functions():
+    from oracle import ref_harness as rh
+    m_ffb6d, m_randla, _ = rh.reference_modules()
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(2, 7, 120, 1, generator=g)
+    pool = torch.randint(0, 120, (2, 33, 16), generator=g)
+    up = torch.randint(0, 120, (2, 500, 1), generator=g)
+    xyz = torch.rand(2, 120, 3, generator=g)
+    nei = torch.randint(0, 120, (2, 120, 16), generator=g)
+    assert torch.equal(ops_ref.random_sample(feat, pool), m_ffb6d.FFB6D.random_sample(feat, pool))
+    assert torch.equal(ops_ref.nearest_interpolation(feat, up), m_ffb6d.FFB6D.nearest_interpolation(feat, up))
+    pc = torch.randn(2, 120, 9, generator=g)
+    assert torch.equal(ops_ref.gather_neighbour(pc, nei), m_randla.Building_block.gather_neighbour(pc, nei))
+    bb = m_randla.Building_block(16)
+    assert torch.equal(ops_ref.relative_pos_encoding(xyz, nei), bb.relative_pos_encoding(xyz, nei))
