@@ -1,0 +1,358 @@
+"""FFB6D network with the reference's parameter names (checkpoints load unchanged) whose
+point branch and pixel<->point fusion run on the gfx950 kernels of this package.
+
+Reference: ffb6d/models/ffb6d.py:16-337 (FFB6D), ffb6d/models/RandLA/RandLANet.py:170-250
+(Dilated_res_block / Building_block / Att_pooling), the two conv+BN wrappers
+(ffb6d/models/pytorch_utils.py:75-129, ffb6d/models/RandLA/pytorch_utils.py:35-111) and the
+ResNet34-PSPNet colour branch (ffb6d/models/cnn/extractors.py, pspnet.py).  The module
+tree reproduces the reference's `state_dict()` keys and shapes exactly
+(tests/golden/state_dict_keys.json); `FFB6D.forward(inputs)` takes the same input dict and
+returns the same `end_points`.
+
+What is different from the reference (MI355X-first, eval mode):
+  * every gather / pooling / encoding step is one HIP kernel call (ffb6d_amd.ops) instead of
+    index.repeat + torch.gather + permute().contiguous() chains;
+  * every shared MLP (1x1 conv + BatchNorm + activation) is folded into one GEMM with the
+    BatchNorm scale/shift absorbed into the weights (inference only; training mode keeps
+    the unfused conv -> BN -> act so gradients and running statistics behave as upstream);
+  * the dense 3x3/7x7 convolutions of the colour branch stay on MIOpen (out of scope for
+    hand-written kernels).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+D_OUT = (32, 64, 128, 256)   # ConfigRandLA.d_out (ffb6d/common.py:26)
+IN_C = 9                     # ConfigRandLA.in_c
+DS_RGB_OC = (64, 128, 512, 1024)
+UP_RGB_OC = (256, 64, 64)
+
+
+# --------------------------------------------------------------------------------------
+# shared MLP = 1x1 conv (+BN) (+activation), two naming flavours
+# --------------------------------------------------------------------------------------
+class _BN(nn.Sequential):
+    def __init__(self, ch, dims, eps, momentum):
+        super().__init__()
+        cls = nn.BatchNorm1d if dims == 1 else nn.BatchNorm2d
+        self.add_module("bn", cls(ch, eps=eps, momentum=momentum))
+
+
+class SharedMLP(nn.Module):
+    """`flavour='randla'`: children conv / bn.bn, BN(eps=1e-6, momentum=0.99), LeakyReLU(0.2)
+       (RandLA/pytorch_utils.py:35-111);
+       `flavour='pvn'`: children conv / normlayer.bn, default BN, ReLU (models/pytorch_utils.py:75-129).
+    The conv has a bias only without BN, as upstream."""
+
+    def __init__(self, cin, cout, dims=2, bn=True, act=True, flavour="randla"):
+        super().__init__()
+        conv_cls = nn.Conv1d if dims == 1 else nn.Conv2d
+        ks = 1 if dims == 1 else (1, 1)
+        self.conv = conv_cls(cin, cout, ks, bias=not bn)
+        nn.init.kaiming_normal_(self.conv.weight)
+        if not bn:
+            nn.init.constant_(self.conv.bias, 0)
+        self.flavour, self.has_bn, self.act = flavour, bn, act
+        if bn:
+            if flavour == "randla":
+                self.bn = _BN(cout, dims, 1e-6, 0.99)
+            else:
+                self.normlayer = _BN(cout, dims, 1e-5, 0.1)
+        self._folded = None
+
+    def _bn_module(self):
+        return (self.bn if self.flavour == "randla" else self.normlayer).bn
+
+    def activation(self, y):
+        if not self.act:
+            return y
+        return F.leaky_relu_(y, 0.2) if self.flavour == "randla" else F.relu_(y)
+
+    def folded(self):
+        """(W [Cout,Cin], b [Cout]) with eval-mode BatchNorm absorbed."""
+        if self._folded is None:
+            w = self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1)
+            if self.has_bn:
+                bn = self._bn_module()
+                scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+                w = w * scale[:, None]
+                b = bn.bias.detach() - bn.running_mean * scale
+            else:
+                b = self.conv.bias.detach()
+            self._folded = (w.contiguous(), b.contiguous())
+        return self._folded
+
+    def train(self, mode=True):
+        self._folded = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._folded = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def forward(self, x):
+        if self.training or torch.is_grad_enabled():   # autograd path: unfused conv -> BN -> act
+            y = self.conv(x)
+            if self.has_bn:
+                y = (self.bn if self.flavour == "randla" else self.normlayer)(y)
+            return self.activation(y)
+        return self.activation(channel_gemm(x, *self.folded()))
+
+
+def channel_gemm(x, w, b):
+    """y[b,:,p] = W @ x[b,:,p] + bias for a channel-major tensor [B,Cin,*spatial]."""
+    B, cin = x.shape[0], x.shape[1]
+    x3 = x.reshape(B, cin, -1)
+    y = torch.baddbmm(b.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), x3)
+    return y.view(B, w.shape[0], *x.shape[2:])
+
+
+# --------------------------------------------------------------------------------------
+# RandLA-Net local feature aggregation (point branch)
+# --------------------------------------------------------------------------------------
+class AttPooling(nn.Module):
+    """RandLANet.py:237-250."""
+
+    def __init__(self, d_in, d_out):
+        super().__init__()
+        self.fc = nn.Conv2d(d_in, d_in, (1, 1), bias=False)
+        self.mlp = SharedMLP(d_in, d_out)
+
+    def forward(self, feature_set):
+        if self.training or torch.is_grad_enabled():
+            att = self.fc(feature_set)
+        else:
+            w = self.fc.weight.reshape(self.fc.weight.shape[0], -1)
+            B, C, N, K = feature_set.shape
+            att = torch.matmul(w, feature_set.reshape(B, C, N * K)).view(B, C, N, K)
+        return self.mlp(ops.att_pool(feature_set, att))
+
+
+class BuildingBlock(nn.Module):
+    """RandLANet.py:187-214 (local spatial encoding + two attentive poolings)."""
+
+    def __init__(self, d_out):
+        super().__init__()
+        self.mlp1 = SharedMLP(10, d_out // 2)
+        self.att_pooling_1 = AttPooling(d_out, d_out // 2)
+        self.mlp2 = SharedMLP(d_out // 2, d_out // 2)
+        self.att_pooling_2 = AttPooling(d_out, d_out)
+
+    def forward(self, xyz, feature, neigh_idx):
+        f_xyz = ops.relative_pos_encoding(xyz, neigh_idx).permute(0, 3, 1, 2).contiguous()
+        f_xyz = self.mlp1(f_xyz)
+        f_nei = ops.gather_neighbour(feature.squeeze(-1).transpose(1, 2).contiguous(), neigh_idx)
+        f_cat = torch.cat([f_nei.permute(0, 3, 1, 2), f_xyz], dim=1)
+        f_agg = self.att_pooling_1(f_cat)
+        f_xyz = self.mlp2(f_xyz)
+        f_nei = ops.gather_neighbour(f_agg.squeeze(-1).transpose(1, 2).contiguous(), neigh_idx)
+        f_cat = torch.cat([f_nei.permute(0, 3, 1, 2), f_xyz], dim=1)
+        return self.att_pooling_2(f_cat)
+
+
+class DilatedResBlock(nn.Module):
+    """RandLANet.py:170-184."""
+
+    def __init__(self, d_in, d_out):
+        super().__init__()
+        self.mlp1 = SharedMLP(d_in, d_out // 2)
+        self.lfa = BuildingBlock(d_out)
+        self.mlp2 = SharedMLP(d_out, d_out * 2, act=False)
+        self.shortcut = SharedMLP(d_in, d_out * 2, act=False)
+
+    def forward(self, feature, xyz, neigh_idx):
+        f = self.lfa(xyz, self.mlp1(feature), neigh_idx)
+        return F.leaky_relu(self.mlp2(f) + self.shortcut(feature), negative_slope=0.2)
+
+
+# --------------------------------------------------------------------------------------
+# colour branch: ResNet34 + pyramid pooling + up-sampling (dense convs -> MIOpen)
+# --------------------------------------------------------------------------------------
+class ResBlock(nn.Module):
+    """extractors.py:34-63 (BasicBlock)."""
+
+    def __init__(self, cin, cout, stride, project):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = F.relu_(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return F.relu_(y + x)
+
+
+def res_layer(cin, cout, blocks, stride):
+    # extractors.py:133-156: with output_stride=32 never reached, layers 3 and 4 keep stride 1
+    # and dilation 1 (the `dilation=` argument upstream is ignored)
+    layers = [ResBlock(cin, cout, stride, project=(stride != 1 or cin != cout))]
+    layers += [ResBlock(cout, cout, 1, False) for _ in range(blocks - 1)]
+    return nn.Sequential(*layers)
+
+
+class PyramidPooling(nn.Module):
+    """pspnet.py:7-31."""
+
+    def __init__(self, ch=512, out_ch=1024, sizes=(1, 2, 3, 6)):
+        super().__init__()
+        self.stages = nn.ModuleList(
+            nn.Sequential(nn.AdaptiveAvgPool2d((s, s)), nn.Conv2d(ch, ch, 1, bias=False)) for s in sizes)
+        self.bottleneck = nn.Conv2d(ch * (len(sizes) + 1), out_ch, 1)
+
+    def forward(self, x):
+        h, w = x.shape[2:]
+        pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]
+        return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
+
+
+class UpBlock(nn.Module):
+    """pspnet.py:34-45 (PSPUpsample)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
+                                  nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.PReLU())
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+def _head(cin, cout):
+    """ffb6d.py:135-157: three conv1d+BN+ReLU then a plain conv1d (pt_utils.Seq numbering)."""
+    seq = nn.Sequential()
+    for i in range(3):
+        seq.add_module(str(i), SharedMLP(cin if i == 0 else 128, 128, dims=1, flavour="pvn"))
+    seq.add_module("3", SharedMLP(128, cout, dims=1, bn=False, act=False, flavour="pvn"))
+    return seq
+
+
+class FFB6D(nn.Module):
+    def __init__(self, n_classes, n_pts, rndla_cfg=None, n_kps=8):
+        super().__init__()
+        self.n_cls, self.n_pts, self.n_kps = n_classes, n_pts, n_kps
+        d_out = tuple(getattr(rndla_cfg, "d_out", D_OUT))
+        in_c = getattr(rndla_cfg, "in_c", IN_C)
+
+        # ---- colour branch (names follow ffb6d.py:30-47,82-88) ----
+        self.cnn_pre_stages = nn.Sequential(
+            nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, 2, 1))
+        self.cnn_ds_stages = nn.ModuleList([
+            res_layer(64, 64, 3, 1),
+            res_layer(64, 128, 4, 2),
+            nn.Sequential(res_layer(128, 256, 6, 1), res_layer(256, 512, 3, 1)),
+            nn.Sequential(PyramidPooling(512, 1024), nn.Dropout2d(p=0.3)),
+        ])
+        final = nn.Sequential(nn.Conv2d(64, 64, 1), nn.LogSoftmax(dim=1))  # shared by stages 2 and 3
+        self.cnn_up_stages = nn.ModuleList([
+            nn.Sequential(UpBlock(1024, 256), nn.Dropout2d(p=0.15)),
+            nn.Sequential(UpBlock(256, 64), nn.Dropout2d(p=0.15)),
+            nn.Sequential(final),
+            nn.Sequential(UpBlock(64, 64), final),
+        ])
+
+        # ---- point branch (RandLANet.py:16-36 pieces that FFB6D reuses) ----
+        self.rndla_pre_stages = SharedMLP(in_c, 8, dims=1)
+        self.rndla_ds_stages = nn.ModuleList()
+        d_in = 8
+        for d in d_out:
+            self.rndla_ds_stages.append(DilatedResBlock(d_in, d))
+            d_in = 2 * d
+        ds_rndla_oc = [2 * d for d in d_out]
+        self.rndla_up_stages = nn.ModuleList()
+        d_cur = d_in
+        for j in range(4):
+            if j < 3:
+                cin, d_cur = d_cur + 2 * d_out[-j - 2], 2 * d_out[-j - 2]
+            else:
+                cin, d_cur = 4 * d_out[-4], 2 * d_out[-4]
+            self.rndla_up_stages.append(SharedMLP(cin, d_cur))
+        up_rndla_oc = [ds_rndla_oc[-j - 2] if j < 3 else ds_rndla_oc[0] for j in range(4)]
+
+        # ---- bidirectional fusion layers (ffb6d.py:51-80,100-129) ----
+        def fuse_lists(rgb_oc, pt_oc, n):
+            r2p_pre, r2p_fuse, p2r_pre, p2r_fuse = (nn.ModuleList() for _ in range(4))
+            for i in range(n):
+                r2p_pre.append(SharedMLP(rgb_oc[i], pt_oc[i], flavour="pvn"))
+                r2p_fuse.append(SharedMLP(pt_oc[i] * 2, pt_oc[i], flavour="pvn"))
+                p2r_pre.append(SharedMLP(pt_oc[i], rgb_oc[i], flavour="pvn"))
+                p2r_fuse.append(SharedMLP(rgb_oc[i] * 2, rgb_oc[i], flavour="pvn"))
+            return r2p_pre, r2p_fuse, p2r_pre, p2r_fuse
+
+        (self.ds_fuse_r2p_pre_layers, self.ds_fuse_r2p_fuse_layers,
+         self.ds_fuse_p2r_pre_layers, self.ds_fuse_p2r_fuse_layers) = fuse_lists(DS_RGB_OC, ds_rndla_oc, 4)
+        (self.up_fuse_r2p_pre_layers, self.up_fuse_r2p_fuse_layers,
+         self.up_fuse_p2r_pre_layers, self.up_fuse_p2r_fuse_layers) = fuse_lists(UP_RGB_OC, up_rndla_oc, 3)
+
+        # ---- per-point heads (ffb6d.py:135-157) ----
+        c = up_rndla_oc[-1] + UP_RGB_OC[-1]
+        self.rgbd_seg_layer = _head(c, n_classes)
+        self.ctr_ofst_layer = _head(c, 3)
+        self.kp_ofst_layer = _head(c, n_kps * 3)
+
+    # the reference exposes these two as static methods of the model (ffb6d.py:159-194)
+    random_sample = staticmethod(ops.random_sample)
+    nearest_interpolation = staticmethod(ops.nearest_interpolation)
+
+    def _fuse(self, i, pre_p2r, fuse_p2r, pre_r2p, fuse_r2p, rgb_emb0, p_emb0, p2r_idx, r2p_idx):
+        """One bidirectional fusion step (ffb6d.py:245-263 / 281-298); both directions read
+        the pre-fusion tensors, so they are independent."""
+        bs, c, hr, wr = rgb_emb0.shape
+        p2r = ops.nearest_interpolation(pre_p2r[i](p_emb0), p2r_idx).view(bs, -1, hr, wr)
+        rgb_emb = fuse_p2r[i](torch.cat((rgb_emb0, p2r), dim=1))
+        r2p = ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx)
+        p_emb = fuse_r2p[i](torch.cat((p_emb0, pre_r2p[i](r2p)), dim=1))
+        return rgb_emb, p_emb
+
+    def forward(self, inputs, end_points=None, scale=1):
+        if not end_points:
+            end_points = {}
+        rgb_emb = self.cnn_pre_stages(inputs['rgb'])
+        p_emb = self.rndla_pre_stages(inputs['cld_rgb_nrm']).unsqueeze(3)
+
+        ds_emb = []
+        for i in range(4):
+            rgb_emb0 = self.cnn_ds_stages[i](rgb_emb)
+            f_enc = self.rndla_ds_stages[i](p_emb, inputs['cld_xyz%d' % i], inputs['cld_nei_idx%d' % i])
+            p_emb0 = ops.random_sample(f_enc, inputs['cld_sub_idx%d' % i])
+            if i == 0:
+                ds_emb.append(f_enc)
+            rgb_emb, p_emb = self._fuse(
+                i, self.ds_fuse_p2r_pre_layers, self.ds_fuse_p2r_fuse_layers,
+                self.ds_fuse_r2p_pre_layers, self.ds_fuse_r2p_fuse_layers, rgb_emb0, p_emb0,
+                inputs['p2r_ds_nei_idx%d' % i], inputs['r2p_ds_nei_idx%d' % i])
+            ds_emb.append(p_emb)
+
+        n_up = len(self.rndla_up_stages)
+        for i in range(n_up - 1):
+            rgb_emb0 = self.cnn_up_stages[i](rgb_emb)
+            f_interp = ops.nearest_interpolation(p_emb, inputs['cld_interp_idx%d' % (n_up - i - 1)])
+            p_emb0 = self.rndla_up_stages[i](torch.cat([ds_emb[-i - 2], f_interp], dim=1))
+            rgb_emb, p_emb = self._fuse(
+                i, self.up_fuse_p2r_pre_layers, self.up_fuse_p2r_fuse_layers,
+                self.up_fuse_r2p_pre_layers, self.up_fuse_r2p_fuse_layers, rgb_emb0, p_emb0,
+                inputs['p2r_up_nei_idx%d' % i], inputs['r2p_up_nei_idx%d' % i])
+
+        rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
+        f_interp = ops.nearest_interpolation(p_emb, inputs['cld_interp_idx0'])
+        p_emb = self.rndla_up_stages[n_up - 1](torch.cat([ds_emb[0], f_interp], dim=1)).squeeze(-1)
+
+        bs = rgb_emb.shape[0]
+        rgb_emb_c = ops.choose_gather(rgb_emb, inputs['choose'])
+        rgbd_emb = torch.cat([rgb_emb_c, p_emb], dim=1)
+
+        end_points['pred_rgbd_segs'] = self.rgbd_seg_layer(rgbd_emb)
+        end_points['pred_kp_ofs'] = self.kp_ofst_layer(rgbd_emb).view(
+            bs, self.n_kps, 3, -1).permute(0, 1, 3, 2).contiguous()
+        end_points['pred_ctr_ofs'] = self.ctr_ofst_layer(rgbd_emb).view(
+            bs, 1, 3, -1).permute(0, 1, 3, 2).contiguous()
+        return end_points

@@ -97,14 +97,21 @@ def _tensor_seed(name, seed):
 
 
 def synth_tensor(name, shape, seed=0):
-    """float32/int64 numpy array for state-dict entry `name` (shape from the module)."""
+    """float32/int64 numpy array for state-dict entry `name` (shape from the module).
+
+    The values are chosen so that activations stay O(1)-O(100) through the ~110 layers, as a
+    trained network's do: He-normal conv weights, BatchNorm statistics close to identity, a
+    small gain on the last BatchNorm of every residual block (otherwise the 16 residual adds
+    grow the signal by 2^16 and the softmax poolings see logits of 1e6, which makes the
+    network chaotic and every fp32 comparison meaningless), and the two input layers scaled
+    for raw 0..255 colour values."""
     rng = np.random.RandomState(_tensor_seed(name, seed))
     shape = tuple(int(s) for s in shape)
     leaf = name.rsplit(".", 1)[-1]
     if leaf == "num_batches_tracked":
         return np.zeros(shape, dtype=np.int64)
     if leaf == "running_var":
-        return rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        return rng.uniform(0.8, 1.25, size=shape).astype(np.float32)
     if leaf == "running_mean":
         return (0.1 * rng.standard_normal(shape)).astype(np.float32)
     if leaf == "bias":
@@ -112,9 +119,16 @@ def synth_tensor(name, shape, seed=0):
     if len(shape) <= 1:  # BatchNorm gamma / PReLU slope
         if shape == (1,):
             return np.full(shape, 0.25, dtype=np.float32)
-        return rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        if name.endswith(".bn2.weight"):          # residual-branch gain
+            return rng.uniform(0.1, 0.3, size=shape).astype(np.float32)
+        return rng.uniform(0.8, 1.2, size=shape).astype(np.float32)
     fan_in = int(np.prod(shape[1:]))
-    return (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+    w = (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+    if name == "cnn_pre_stages.0.weight":          # consumes raw 0..255 rgb
+        w *= np.float32(0.01)
+    if name == "rndla_pre_stages.conv.weight":     # channels 3..5 of cld_rgb_nrm are raw rgb
+        w[:, 3:6] *= np.float32(0.01)
+    return w
 
 
 def synth_state_dict(module, seed=0):
@@ -128,4 +142,29 @@ def synth_state_dict(module, seed=0):
         key = (t.data_ptr(), tuple(t.shape)) if t.numel() > 0 else (name, ())
         src = first_name.setdefault(key, name)
         out[name] = torch.from_numpy(synth_tensor(src, t.shape, seed)).to(t.dtype)
+    return out
+
+
+# parameters that alias one tensor in the reference model: `cnn.final` is registered under
+# both cnn_up_stages[2] and cnn_up_stages[3] (ffb6d.py:86-87)
+REFERENCE_ALIASES = {
+    "cnn_up_stages.3.1.0.weight": "cnn_up_stages.2.0.0.weight",
+    "cnn_up_stages.3.1.0.bias": "cnn_up_stages.2.0.0.bias",
+}
+
+
+def synth_state_dict_from_shapes(shapes, seed=0, n_classes=None):
+    """Same values as synth_state_dict(reference_model), built from a {name: shape} map
+    (tests/golden/state_dict_keys.json) instead of a module.  `n_classes` overrides the
+    output width of the segmentation head (the only class-count dependent tensors)."""
+    import torch
+
+    out = {}
+    for name, shape in shapes.items():
+        shape = list(shape)
+        if n_classes is not None and name.startswith("rgbd_seg_layer.3.conv."):
+            shape[0] = n_classes
+        src = REFERENCE_ALIASES.get(name, name)
+        a = synth_tensor(src, shape, seed)
+        out[name] = torch.from_numpy(a)
     return out

@@ -114,3 +114,31 @@ def test_ops_ref_equals_reference_functions():
     assert torch.equal(ops_ref.gather_neighbour(pc, nei), m_randla.Building_block.gather_neighbour(pc, nei))
     bb = m_randla.Building_block(16)
     assert torch.equal(ops_ref.relative_pos_encoding(xyz, nei), bb.relative_pos_encoding(xyz, nei))
+
+
+# ---- whole-forward restatement (oracle/forward_ref.py) against the reference's end_points ----
+def _oracle_forward(config, bs, n_points, h, w, n_classes):
+    from oracle import forward_ref
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as fh:
+        shapes = json.load(fh)
+    sd = synth.synth_state_dict_from_shapes(shapes, seed=0, n_classes=n_classes)
+    frames = synth.make_batch(config, bs, n_points=n_points, height=h, width=w)
+    pyr = opyr.build_batch(frames, oknn.knn_search)
+    inputs = {"rgb": torch.from_numpy(frames["rgb"].astype(np.float32)),
+              "cld_rgb_nrm": torch.from_numpy(frames["cld_rgb_nrm"]),
+              "choose": torch.from_numpy(frames["choose"].astype(np.int64))}
+    for k, v in pyr.items():
+        inputs[k] = torch.from_numpy(v.astype(np.int64) if v.dtype == np.int32 else v)
+    with torch.no_grad():
+        return forward_ref.ffb6d_forward(sd, inputs)
+
+
+def test_oracle_forward_matches_reference_small_golden():
+    """2 frames of 120x160, N=1024, 5 classes: full end_points of the reference FFB6D."""
+    gold = np.load(os.path.join(GOLDEN, "forward_small.npz"))
+    ep = _oracle_forward(7, 2, 1024, 120, 160, 5)
+    for k in ("pred_rgbd_segs", "pred_kp_ofs", "pred_ctr_ofs"):
+        assert ep[k].shape == gold[k].shape
+        scale = float(np.abs(gold[k]).max())
+        err = float(np.abs(ep[k].numpy() - gold[k]).max())
+        assert err <= 1e-5 * max(scale, 1.0), (k, err, scale)
