@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- FFB6D hot-path benchmark on MI355X (driver contract: see the task statement).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch of synthetic RGB-D frames that is already
+resident in HBM: the on-device index pyramid (the 22 exact-KNN searches per frame that the
+reference runs on the CPU in its DataLoader, linemod_dataset.py:318-353) followed by
+FFB6D.forward (ffb6d.py:203-337) in fp32, eval mode.  Workload = BASELINE.json configs[1]:
+bs=8, N=12288 points, 480x640, 4 encoder + 3 decoder fusion layers, one MI355X.  With N>1
+ranks every rank runs its own batch of 8 (weak scaling, no data-path collective: batch items
+are independent in the forward pass -- SURVEY.md section 8e); value = total frames / max-over-ranks time.
+
+The JSON line also carries
+  roofline      achieved algorithmic GB/s of the dominant hand-written kernel, measured live with
+                HIP events on its launch stream during the timed steps;
+  cpu_baseline  the CPU oracle path (reference nanoflann from oracle/_ref when present, else the
+                C restatement, + the plain-torch forward of oracle/forward_ref.py) timed on this
+                host's cores on a bounded sample (a few single frames).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (FMA counted as 2)
+METRIC = "RGB-D frames/sec fwd (480x640, N=12288, bs=8)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--n-points", type=int, default=12288)
+    ap.add_argument("--n-classes", type=int, default=22)
+    ap.add_argument("--index-dtype", choices=["int64", "int32"], default="int64")
+    ap.add_argument("--roofline-op", default="auto", help="op whose launches are event-timed in the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=5)
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--trace-all", action="store_true", help="extra untimed pass: per-op table to stderr")
+    ap.add_argument("--mark-region", action="store_true",
+                    help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
+                         "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
+    return ap.parse_args()
+
+
+def state_dict(n_classes):
+    from ffb6d_amd import synth
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as fh:
+        shapes = json.load(fh)
+    return synth.synth_state_dict_from_shapes(shapes, seed=0, n_classes=n_classes)
+
+
+def cpu_baseline(args, sd):
+    """Oracle path on the host CPU: single frames (bs=1), all cores for the forward; the KNN
+    pyramid is single-threaded per frame by construction in the reference (knn_.cxx:108)."""
+    from ffb6d_amd import synth
+    from oracle import forward_ref
+    from oracle import knn as oknn
+    from oracle import pyramid as opyr
+    from oracle import ref_harness
+
+    use_ref = os.path.exists(ref_harness.REF_KNN_SO)
+    if use_ref:
+        def search(s, q, k):
+            return ref_harness.ref_knn_batch(s, q, k, omp=True).astype(np.int32)
+    else:
+        search = oknn.knn_search
+    # more threads than ~32 make the CPU path slower (oversubscribed small convolutions, OpenMP
+    # team start-up inside the per-frame KNN calls): measured 108 s/frame at 256 threads on the
+    # 256-thread bench host vs ~1 s/frame at 8 threads on the build container
+    cores = min(os.cpu_count() or 1, args.cpu_threads)
+    torch.set_num_threads(cores)
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=cores)
+    except Exception:  # pragma: no cover
+        pass
+    t_knn, t_fwd = [], []
+    t_start = time.perf_counter()
+    for i in range(args.cpu_frames + 1):        # first frame = warm-up
+        if i > 1 and time.perf_counter() - t_start > 45.0:
+            break
+        frames = synth.make_batch(2, 1, n_points=args.n_points) if i == 0 else \
+            {k: v[i % args.batch: i % args.batch + 1] for k, v in cpu_baseline.frames.items()}
+        t0 = time.perf_counter()
+        pyr = opyr.build_batch(frames, search)
+        t1 = time.perf_counter()
+        inputs = {"rgb": torch.from_numpy(frames["rgb"].astype(np.float32)),
+                  "cld_rgb_nrm": torch.from_numpy(frames["cld_rgb_nrm"]),
+                  "choose": torch.from_numpy(frames["choose"].astype(np.int64))}
+        for k, v in pyr.items():
+            inputs[k] = torch.from_numpy(v.astype(np.int64) if v.dtype == np.int32 else v)
+        with torch.no_grad():
+            forward_ref.ffb6d_forward(sd, inputs)
+        t2 = time.perf_counter()
+        if i > 0:
+            t_knn.append(t1 - t0)
+            t_fwd.append(t2 - t1)
+    knn_s, fwd_s = float(np.median(t_knn)), float(np.median(t_fwd))
+    return {
+        "value": 1.0 / (knn_s + fwd_s), "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{len(t_fwd)} single 480x640 frames (bs=1, N={args.n_points}) after 1 warm-up; "
+                  f"KNN pyramid {'reference nanoflann (oracle/_ref), 1 thread' if use_ref else 'C oracle brute force, all cores'} "
+                  f"{knn_s * 1e3:.0f} ms/frame + plain-torch fp32 forward (oracle/forward_ref.py, {cores} threads) "
+                  f"{fwd_s * 1e3:.0f} ms/frame",
+        "knn_ms_per_frame": knn_s * 1e3, "forward_ms_per_frame": fwd_s * 1e3,
+        "forward_only_fps": 1.0 / fwd_s,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ffb6d_amd import _lib, model, ops, pyramid, synth
+    _lib.load()
+    idt = torch.int64 if args.index_dtype == "int64" else torch.int32
+
+    sd = state_dict(args.n_classes)
+    net = model.FFB6D(n_classes=args.n_classes, n_pts=args.n_points)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+
+    # per-rank batch, resident in HBM before the timed region (seeds 1000*2 + sample, offset by rank)
+    frames = synth.make_batch(2, args.batch, n_points=args.n_points)
+    if rank > 0:
+        frames = {k: np.roll(v, rank, axis=0) for k, v in frames.items()}
+    cpu_baseline.frames = frames
+    rgb = torch.from_numpy(frames["rgb"]).to(dev).float()
+    cld_rgb_nrm = torch.from_numpy(frames["cld_rgb_nrm"]).to(dev)
+    choose = torch.from_numpy(frames["choose"]).to(dev).long()
+    cld = torch.from_numpy(frames["cld"]).to(dev)
+    dpt_xyz = torch.from_numpy(frames["dpt_xyz"]).to(dev)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    phase = {"pyramid": [], "forward": []}
+
+    def step(record=False):
+        e0, e1, e2 = (ev(), ev(), ev()) if record else (None, None, None)
+        if record:
+            e0.record()
+        inputs = pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
+        inputs.update(rgb=rgb, cld_rgb_nrm=cld_rgb_nrm, choose=choose)
+        if record:
+            e1.record()
+        out = net(inputs)
+        if record:
+            e2.record()
+            phase["pyramid"].append((e0, e1))
+            phase["forward"].append((e1, e2))
+        return out
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+
+        roof_op = "knn" if args.roofline_op == "auto" else args.roofline_op
+        tracer = _lib.Tracer([roof_op])
+        _lib.TRACER = tracer
+        marker = torch.zeros(4, dtype=torch.int32, device=dev)
+        if args.mark_region:
+            ops.check_index_range(marker, 1)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(record=True)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        _lib.TRACER = None
+        if args.mark_region:
+            ops.check_index_range(marker, 1)
+
+        if args.trace_all and rank == 0:
+            full = _lib.Tracer(None)
+            _lib.TRACER = full
+            for _ in range(max(2, args.steps // 2)):
+                step()
+            torch.cuda.synchronize()
+            _lib.TRACER = None
+            print("%-24s %9s %10s %10s %10s" % ("op", "launches", "total ms", "avg us", "alg GB/s"), file=sys.stderr)
+            for name, r in sorted(full.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
+                print("%-24s %9d %10.3f %10.1f %10.1f" % (name, r["launches"], r["total_ms"], r["avg_us"], r["gbps"]),
+                      file=sys.stderr)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = args.batch * world * args.steps / elapsed
+        pyr_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["pyramid"]]))
+        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["forward"]]))
+        summ = tracer.summary().get(roof_op)
+        roofline = None
+        if summ and summ["launches"]:
+            ach = summ["gbps"]
+            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": roof_op,
+                        "launches_per_step": summ["launches"] / args.steps,
+                        "avg_launch_us": summ["avg_us"],
+                        "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
+            if roof_op == "knn":
+                # the brute-force KNN is VALU-bound, not HBM-bound: also report pairs/s
+                pairs = sum(tag[0] * tag[1] for _, _, _, tag in tracer.records[roof_op]) * args.batch
+                roofline["valu_gpairs_per_s"] = pairs / (summ["total_ms"] * 1e-3) / 1e9
+                roofline["valu_frac_of_fp32_peak"] = (pairs * 8 / (summ["total_ms"] * 1e-3)) / (VALU_PEAK_TFLOPS * 1e12)
+        line = {
+            "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FFB6D forward incl. on-device 22-call KNN index pyramid; "
+                                   f"bs={args.batch}/GPU, N={args.n_points} pts, 480x640 RGB-D, "
+                                   f"{args.n_classes} classes, fp32, eval",
+                       "global_batch": args.batch * world, "n_points": args.n_points,
+                       "index_dtype": args.index_dtype, "parallelism": f"dp{world} (independent batches)"},
+            "breakdown_ms": {"knn_pyramid": pyr_ms, "forward": fwd_ms},
+            "forward_only_fps": args.batch * world / (fwd_ms * 1e-3),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args, sd)
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

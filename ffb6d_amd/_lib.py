@@ -19,6 +19,11 @@ SIGNATURES = {
     "cpp_knn_batch_omp": (None, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
     "ffb6d_knn_workspace_bytes": (_sz, [_i64, _i64, _i64, _i32]),
     "ffb6d_knn_batch_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ffb6d_knn_prepared_bytes": (_sz, [_i64, _i64]),
+    "ffb6d_knn_prepare_workspace_bytes": (_sz, [_i64, _i64]),
+    "ffb6d_knn_prepare": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp, _sz, _vp]),
+    "ffb6d_knn_search_prepared": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ffb6d_knn_uses_pruning": (_i32, [_i64, _i64, _i64, _i32]),
     "ffb6d_random_sample_f32": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_random_sample_bwd_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "ffb6d_nearest_interpolation_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp]),
@@ -69,3 +74,55 @@ def last_error():
 def check(rc, what):
     if rc != 0:
         raise FFB6DNativeError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+# ------------------------------------------------------------------------------------
+# optional per-call HIP-event tracing (bench.py): when enabled for an op name, every native
+# call of that op is bracketed by two events recorded on the stream the kernel is launched
+# on, and tagged with its algorithmic byte count, so achieved GB/s can be computed live.
+# ------------------------------------------------------------------------------------
+class Tracer:
+    def __init__(self, names=None):
+        self.names = set(names) if names else None   # None = every op
+        self.records = {}                             # name -> list of (start, end, bytes, tag)
+
+    def wants(self, name):
+        return self.names is None or name in self.names
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_us, bytes, gbps); call after a device sync."""
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            nbytes = sum(b for _, _, b, _ in recs)
+            tot = sum(ms)
+            out[name] = dict(launches=len(recs), total_ms=tot, avg_us=1e3 * tot / max(len(recs), 1),
+                             bytes=nbytes, gbps=(nbytes / (tot * 1e-3) / 1e9) if tot > 0 else 0.0)
+        return out
+
+
+TRACER = None
+
+
+class traced:
+    """with traced("name", nbytes, tag): <native call>  -- no-op unless a Tracer is installed."""
+    __slots__ = ("name", "nbytes", "tag", "start")
+
+    def __init__(self, name, nbytes=0, tag=None):
+        self.name, self.nbytes, self.tag, self.start = name, nbytes, tag, None
+
+    def __enter__(self):
+        t = TRACER
+        if t is not None and t.wants(self.name):
+            import torch
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.start is not None:
+            import torch
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            TRACER.records.setdefault(self.name, []).append((self.start, end, self.nbytes, self.tag))
+        return False

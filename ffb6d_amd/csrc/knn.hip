@@ -32,8 +32,8 @@ namespace {
 
 constexpr int KNN_BLOCK = 256;  // 4 waves
 constexpr int KNN_TILE = 1024;  // support points per LDS tile (16 KiB as float4)
-constexpr int KNN_GROUP = 4;    // candidates between queue-occupancy checks
-constexpr int KNN_QCAP = 8;     // queue slots per query (>= 2*GROUP)
+constexpr int KNN_GROUP = 8;    // candidates per unrolled group / between queue-occupancy checks
+constexpr int KNN_QCAP = 16;    // queue slots per query (>= 2*GROUP)
 
 template <int K>
 struct TopK {
@@ -155,10 +155,11 @@ knn_scan_kernel(const float* __restrict__ support, const float* __restrict__ que
         __syncthreads();  // every wave is done with the previous tile
 #pragma unroll
         for (int j = tid; j < KNN_TILE; j += KNN_BLOCK) {
-            float4 p = make_float4(INFINITY, INFINITY, INFINITY, 0.f);  // pad: d = inf, never kept
+            // pad: d = inf, never kept; .w carries the global support index
+            float4 p = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float((uint32_t)(base + j)));
             if (j < n) {
                 const float* s = sup + (size_t)(base + j) * 3;
-                p = make_float4(s[0], s[1], s[2], 0.f);
+                p.x = s[0]; p.y = s[1]; p.z = s[2];
             }
             tile[j] = p;
         }
@@ -166,19 +167,29 @@ knn_scan_kernel(const float* __restrict__ support, const float* __restrict__ que
 
         const int n_pad = (n + KNN_GROUP - 1) / KNN_GROUP * KNN_GROUP;
         for (int j0 = 0; j0 < n_pad; j0 += KNN_GROUP) {
+            // 1) all LDS reads of the group first (wave-uniform addresses: ds_read_b128
+            //    broadcasts), 2) all distances, 3) the rare predicated queue appends.  Keeping
+            //    the three phases apart lets the loads and the arithmetic of a group overlap
+            //    instead of waiting for LDS once per candidate.
+            float4 p[KNN_GROUP];
+#pragma unroll
+            for (int u = 0; u < KNN_GROUP; ++u) p[u] = tile[j0 + u];
+            float d[QPT][KNN_GROUP];
+#pragma unroll
+            for (int u = 0; u < KNN_GROUP; ++u)
+#pragma unroll
+                for (int t = 0; t < QPT; ++t) d[t][u] = sqdist(qx[t], qy[t], qz[t], p[u]);
 #pragma unroll
             for (int u = 0; u < KNN_GROUP; ++u) {
-                const float4 p = tile[j0 + u];  // wave-uniform address: LDS broadcast
-                const uint32_t sidx = (uint32_t)(base + j0 + u);
+                const uint32_t sidx = __float_as_uint(p[u].w);   // global support index rides in .w
 #pragma unroll
                 for (int t = 0; t < QPT; ++t) {
-                    const float d = sqdist(qx[t], qy[t], qz[t], p);
                     if constexpr (K == 1) {
-                        top[t].insert(d, sidx);
+                        top[t].insert(d[t][u], sidx);
                     } else {
-                        if (d < worst[t]) {
+                        if (d[t][u] < worst[t]) {
                             queue[(t * KNN_QCAP + cnt[t]) * KNN_BLOCK + tid] =
-                                make_uint2(__float_as_uint(d), sidx);
+                                make_uint2(__float_as_uint(d[t][u]), sidx);
                             cnt[t]++;
                         }
                     }
@@ -356,9 +367,22 @@ using namespace ffb6d;
 
 extern "C" {
 
+int ffb6d_knn_uses_pruning(int64_t B, int64_t S, int64_t Q, int K)
+{
+    // sorting + tile boxes pay off once the support set is a few tiles long; tiny sets are
+    // cheaper to scan outright
+    return (B >= 1 && Q >= 1 && K >= 1 && K <= 32 && S >= 2048) ? 1 : 0;
+}
+
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
 size_t ffb6d_knn_workspace_bytes(int64_t B, int64_t S, int64_t Q, int K)
 {
     if (B <= 0 || S <= 0 || Q <= 0 || K < 1 || K > 32) return 0;
+    if (ffb6d_knn_uses_pruning(B, S, Q, K)) {
+        return align256(ffb6d_knn_prepared_bytes(B, S)) + align256(ffb6d_knn_prepared_bytes(B, Q)) +
+               align256(ffb6d_knn_prepare_workspace_bytes(B, S > Q ? S : Q));
+    }
     const Plan p = make_plan(B, S, Q, K);
     if (p.nsplit <= 1) return 0;
     return (size_t)B * p.nsplit * Q * p.Kp * (sizeof(float) + sizeof(uint32_t));
@@ -373,11 +397,29 @@ int ffb6d_knn_batch_device(const float* support, const float* query, int64_t B, 
     if (B == 0 || Q == 0) return FFB6D_OK;
     FFB6D_REQUIRE(support && query, "knn: null input pointer");
     FFB6D_REQUIRE(idx64 || idx32 || dist, "knn: no output requested");
-    const Plan p = make_plan(B, S, Q, K);
     const size_t need = ffb6d_knn_workspace_bytes(B, S, Q, K);
     if (need > 0 && (workspace == nullptr || workspace_bytes < need))
         return set_error(FFB6D_ERR_WORKSPACE, "knn: workspace of %zu bytes required, got %zu",
                          need, workspace ? workspace_bytes : (size_t)0);
+    if (ffb6d_knn_uses_pruning(B, S, Q, K)) {
+        // Morton-sort both sets, then the tile-pruned search (knn_pruned.hip)
+        char* ws = static_cast<char*>(workspace);
+        const size_t ps = align256(ffb6d_knn_prepared_bytes(B, S)), pq = align256(ffb6d_knn_prepared_bytes(B, Q));
+        void* prep_s = ws;
+        void* prep_q = ws + ps;
+        void* scratch = ws + ps + pq;
+        const size_t scratch_bytes = workspace_bytes - ps - pq;
+        rc = ffb6d_knn_prepare(support, B, S, prep_s, ps, scratch, scratch_bytes, stream);
+        if (rc != FFB6D_OK) return rc;
+        if (query == support && Q == S) {
+            prep_q = prep_s;
+        } else {
+            rc = ffb6d_knn_prepare(query, B, Q, prep_q, pq, scratch, scratch_bytes, stream);
+            if (rc != FFB6D_OK) return rc;
+        }
+        return ffb6d_knn_search_prepared(prep_s, prep_q, B, S, Q, K, idx64, idx32, dist, stream);
+    }
+    const Plan p = make_plan(B, S, Q, K);
     hipStream_t st = as_stream(stream);
     switch (p.Kp) {
         case 1:  return launch_knn<1, qpt_for(1)>(p, support, query, B, S, Q, K, idx64, idx32, dist, workspace, st);

@@ -1,0 +1,593 @@
+// ffb6d_amd/csrc/knn_pruned.hip -- exact KNN with spatial pruning for gfx950 (MI355X).
+//
+// Same contract as knn.hip (reference: knn_.cxx:104-135, nanoflann.hpp:79-145,323-348: exact
+// K nearest, ascending f32 squared distance ((dx*dx+dy*dy)+dz*dz), lowest index on ties), but
+// the work is cut from S*Q point pairs to a few hundred per query:
+//
+//   prepare   a point set is put into Morton (Z-curve) order once: per-frame bounding box ->
+//             30-bit Morton keys -> one device radix sort of (frame<<32 | key) -> gather into
+//             float4 {x, y, z, original index} + one axis-aligned box per 64-point tile;
+//   search    one lane owns one query (queries are themselves Morton ordered, so the 64 lanes
+//             of a wave sit next to each other in space).  The wave binary-searches the tile
+//             where its queries would fall and walks the tiles outwards from there; a tile is
+//             entered only if its box is within the current K-th distance of some lane
+//             (wave-uniform branch on __any), so after the first couple of tiles almost
+//             everything is skipped.  Tile boxes and tile points are wave-uniform, i.e. they
+//             come through the scalar cache into SGPRs -- no LDS staging, no bank conflicts;
+//             the per-lane top-K lives in registers and takes candidates through the same
+//             per-lane LDS queue + wave-wide drain as the brute-force kernel.
+//
+// Exactness does not depend on the ordering heuristics: the box lower bound is evaluated with
+// the reference's operation order ((gx*gx+gy*gy)+gz*gz) on monotone-rounded gaps, hence it is
+// <= the rounded distance of every point in the box; tiles with bound <= current K-th distance
+// are always entered; candidates are compared as (distance, original index) pairs, so the
+// visiting order cannot change which neighbour wins a tie.
+#include "common.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <cfloat>
+#include <cmath>
+
+namespace ffb6d {
+namespace {
+
+constexpr int PT = 64;      // points per tile (one box per tile)
+constexpr int BLK = 256;
+constexpr int QCAP = 16;    // per-lane queue slots
+constexpr int GRP = 8;      // candidates per unrolled group
+
+constexpr int CELL_BITS = 15;                 // coarse Z-curve cells (top bits of the 30-bit key)
+constexpr int CELL_SHIFT = 30 - CELL_BITS;
+constexpr int NCELL = 1 << CELL_BITS;
+
+struct Layout {
+    int64_t S_pad, nt;
+    size_t pts_off, box_off, key_off, frame_off, cell_off, total;
+};
+
+Layout layout(int64_t B, int64_t S)
+{
+    Layout l;
+    l.S_pad = ceil_div(S, PT) * PT;
+    l.nt = l.S_pad / PT;
+    size_t o = 0;
+    l.pts_off = o;   o += (size_t)B * l.S_pad * sizeof(float4);
+    l.box_off = o;   o += (size_t)B * l.nt * 2 * sizeof(float4);
+    l.key_off = o;   o += (size_t)B * l.S_pad * sizeof(uint32_t);
+    l.frame_off = o; o += (size_t)B * 8 * sizeof(float);
+    l.cell_off = o;  o += (size_t)B * NCELL * sizeof(uint32_t);   // cell -> tile holding its first point
+    l.total = (o + 255) / 256 * 256;
+    return l;
+}
+
+// ---------------------------------------------------------------- prepare -------------
+__device__ __forceinline__ int f2ord(float f)
+{
+    const int b = __float_as_int(f);
+    return b ^ ((b >> 31) & 0x7fffffff);   // monotone float -> int
+}
+__device__ __forceinline__ float ord2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
+
+__global__ void bbox_init_kernel(int* __restrict__ bbox, int n6)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n6) bbox[i] = (i % 6 < 3) ? 0x7fffffff : (int)0x80000000;
+}
+
+__global__ void __launch_bounds__(BLK)
+bbox_kernel(const float* __restrict__ pts, int S, int* __restrict__ bbox)
+{
+    const int b = blockIdx.y;
+    const float* p = pts + (size_t)b * S * 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < S; i += gridDim.x * BLK) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = p[(size_t)i * 3 + c];
+            lo[c] = fminf(lo[c], v);
+            hi[c] = fmaxf(hi[c], v);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[c] = fminf(lo[c], __shfl_xor(lo[c], o, 64));
+            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            atomicMin(bbox + b * 6 + c, f2ord(lo[c]));
+            atomicMax(bbox + b * 6 + 3 + c, f2ord(hi[c]));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// frame = {lo.x, lo.y, lo.z, 0, scale.x, scale.y, scale.z, 0}
+__device__ __forceinline__ uint32_t morton_key(float x, float y, float z, const float* __restrict__ fr)
+{
+    const float cx = fminf(fmaxf((x - fr[0]) * fr[4], 0.f), 1023.f);
+    const float cy = fminf(fmaxf((y - fr[1]) * fr[5], 0.f), 1023.f);
+    const float cz = fminf(fmaxf((z - fr[2]) * fr[6], 0.f), 1023.f);
+    return spread10((uint32_t)cx) | (spread10((uint32_t)cy) << 1) | (spread10((uint32_t)cz) << 2);
+}
+
+__global__ void frame_kernel(const int* __restrict__ bbox, float* __restrict__ frame, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float lo = ord2f(bbox[b * 6 + c]), hi = ord2f(bbox[b * 6 + 3 + c]);
+        const float ext = hi - lo;
+        frame[b * 8 + c] = lo;
+        frame[b * 8 + 4 + c] = (ext > 0.f && ext < INFINITY) ? 1024.f / ext : 0.f;
+    }
+    frame[b * 8 + 3] = 0.f;
+    frame[b * 8 + 7] = 0.f;
+}
+
+__global__ void __launch_bounds__(BLK)
+morton_kernel(const float* __restrict__ pts, int S, const float* __restrict__ frame,
+              unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= S) return;
+    const float* p = pts + ((size_t)b * S + i) * 3;
+    const uint32_t k = morton_key(p[0], p[1], p[2], frame + b * 8);
+    keys[(size_t)b * S + i] = ((unsigned long long)b << 32) | k;
+    vals[(size_t)b * S + i] = (uint32_t)i;
+}
+
+// one wave per tile: gather the sorted points, build the tile box
+__global__ void __launch_bounds__(BLK)
+gather_box_kernel(const float* __restrict__ pts, int S, int S_pad, int nt,
+                  const unsigned long long* __restrict__ skeys, const uint32_t* __restrict__ perm,
+                  float4* __restrict__ out_pts, float4* __restrict__ boxes, uint32_t* __restrict__ out_keys)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    if (t >= nt) return;
+    const int lane = threadIdx.x & 63;
+    const int slot = t * PT + lane;
+    float4 p = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(0xffffffffu));
+    uint32_t key = 0xffffffffu;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (slot < S) {
+        const uint32_t src = perm[(size_t)b * S + slot];
+        const float* s = pts + ((size_t)b * S + src) * 3;
+        p = make_float4(s[0], s[1], s[2], __uint_as_float(src));
+        key = (uint32_t)skeys[(size_t)b * S + slot];
+        lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[c] = fminf(lo[c], __shfl_xor(lo[c], o, 64));
+            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64));
+        }
+    }
+    out_pts[(size_t)b * S_pad + slot] = p;
+    out_keys[(size_t)b * S_pad + slot] = key;
+    if (lane == 0) {
+        boxes[((size_t)b * nt + t) * 2 + 0] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        boxes[((size_t)b * nt + t) * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+}
+
+// cell -> index of the tile that holds the first point whose key is >= (cell << CELL_SHIFT)
+__global__ void __launch_bounds__(BLK)
+cell_table_kernel(const uint32_t* __restrict__ keys, int S, int S_pad, int nt, uint32_t* __restrict__ table)
+{
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * BLK + threadIdx.x;
+    if (c >= NCELL) return;
+    const uint32_t* k = keys + (size_t)b * S_pad;
+    const uint32_t want = (uint32_t)c << CELL_SHIFT;
+    int lo = 0, hi = S;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (k[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    table[(size_t)b * NCELL + c] = (uint32_t)min(lo / PT, nt - 1);
+}
+
+// ---------------------------------------------------------------- search --------------
+// running top-K as packed 64-bit keys (distance bits << 32 | original index): non-negative
+// floats order like their bit patterns, so one unsigned 64-bit compare is the lexicographic
+// (distance, index) compare the tie rule needs
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 pack_key(float d, uint32_t i) { return ((u64)__float_as_uint(d) << 32) | i; }
+constexpr u64 KEY_EMPTY = ((u64)0x7f7fffffu << 32) | 0xffffffffu;   // (FLT_MAX, 0xffffffff)
+
+template <int K>
+struct TopKL {
+    u64 k[K];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int j = 0; j < K; ++j) k[j] = KEY_EMPTY;
+    }
+    __device__ __forceinline__ float worst() const { return __uint_as_float((uint32_t)(k[K - 1] >> 32)); }
+    __device__ __forceinline__ bool beats_last(u64 nk) const { return nk < k[K - 1]; }
+    // precondition: beats_last(nk).  One compare per slot: slot j takes its left neighbour when
+    // that neighbour sorts after nk, takes nk when only the slot itself does.
+    __device__ __forceinline__ void insert(u64 nk)
+    {
+        bool cur_after = true;
+#pragma unroll
+        for (int j = K - 1; j >= 1; --j) {
+            const bool prev_after = k[j - 1] > nk;
+            k[j] = prev_after ? k[j - 1] : (cur_after ? nk : k[j]);
+            cur_after = prev_after;
+        }
+        if (cur_after) k[0] = nk;
+    }
+};
+
+__device__ __forceinline__ float sqdist3(float qx, float qy, float qz, float px, float py, float pz)
+{
+    const float dx = __fsub_rn(qx, px), dy = __fsub_rn(qy, py), dz = __fsub_rn(qz, pz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// lower bound of sqdist3(q, p) over all p inside [lo, hi]; same op order, monotone rounding
+__device__ __forceinline__ float box_bound(float qx, float qy, float qz, const float4& lo, const float4& hi)
+{
+    const float gx = fmaxf(fmaxf(__fsub_rn(lo.x, qx), __fsub_rn(qx, hi.x)), 0.f);
+    const float gy = fmaxf(fmaxf(__fsub_rn(lo.y, qy), __fsub_rn(qy, hi.y)), 0.f);
+    const float gz = fmaxf(fmaxf(__fsub_rn(lo.z, qz), __fsub_rn(qz, hi.z)), 0.f);
+    return __fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz));
+}
+
+// conservative bound between the wave's query box [qlo,qhi] and a tile box [lo,hi]
+__device__ __forceinline__ float boxbox_bound(const float qlo[3], const float qhi[3], const float4& lo, const float4& hi)
+{
+    const float gx = fmaxf(fmaxf(__fsub_rn(lo.x, qhi[0]), __fsub_rn(qlo[0], hi.x)), 0.f);
+    const float gy = fmaxf(fmaxf(__fsub_rn(lo.y, qhi[1]), __fsub_rn(qlo[1], hi.y)), 0.f);
+    const float gz = fmaxf(fmaxf(__fsub_rn(lo.z, qhi[2]), __fsub_rn(qlo[2], hi.z)), 0.f);
+    return __fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz));
+}
+
+// value of `v` in lane `l` (l wave-uniform), bit-exact
+__device__ __forceinline__ float lane_bcast(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// grid = (ceil(Q_pad / 256), B); queries come Morton ordered with their original index in .w.
+// Each wave works on its own: 64 neighbouring queries, tiles tested 64 at a time (one tile box
+// per lane against the wave's query box), surviving tiles fetched with one coalesced load and
+// broadcast through a wave-private LDS slice.
+template <int K>
+__global__ void __launch_bounds__(BLK)
+knn_pruned_kernel(const float4* __restrict__ spts, const float4* __restrict__ boxes,
+                  const uint32_t* __restrict__ skeys, const float* __restrict__ sframe,
+                  const uint32_t* __restrict__ scell, int S, int S_pad, int nt,
+                  const float4* __restrict__ qpts, int Q, int Q_pad,
+                  int64_t* __restrict__ idx64, int32_t* __restrict__ idx32, float* __restrict__ dist,
+                  int Kout)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* tile_all = reinterpret_cast<float4*>(smem);                               // [4 waves][PT]
+    uint2* queue = reinterpret_cast<uint2*>(smem + (BLK / 64) * PT * sizeof(float4));   // [QCAP][BLK]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    float4* tile = tile_all + (tid >> 6) * PT;
+    const int b = blockIdx.y;
+    const int slot = blockIdx.x * BLK + tid;
+    const float4 q = qpts[(size_t)b * Q_pad + min(slot, Q_pad - 1)];
+    const uint32_t q_orig = __float_as_uint(q.w);
+    const bool live = slot < Q_pad && q_orig != 0xffffffffu;
+    const unsigned long long alive = __ballot(live);
+    if (!alive) return;   // whole wave is padding (wave-uniform exit; no block barriers below)
+
+    const float4* sp = spts + (size_t)b * S_pad;
+    const float4* bx = boxes + (size_t)b * nt * 2;
+
+    // the wave's query box
+    float qlo[3], qhi[3];
+    qlo[0] = wave_min(live ? q.x : INFINITY);  qhi[0] = wave_max(live ? q.x : -INFINITY);
+    qlo[1] = wave_min(live ? q.y : INFINITY);  qhi[1] = wave_max(live ? q.y : -INFINITY);
+    qlo[2] = wave_min(live ? q.z : INFINITY);  qhi[2] = wave_max(live ? q.z : -INFINITY);
+
+    // every lane looks up the tile its own query falls into on the support's Z-curve
+    const uint32_t key = morton_key(q.x, q.y, q.z, sframe + b * 8);
+    const int my_tile = live ? (int)scell[(size_t)b * NCELL + (key >> CELL_SHIFT)] : 0;
+    const int mid_lane = ((alive >> 32) & 1ull) ? 32 : (int)(__ffsll((long long)alive) - 1);
+    const int t0 = __builtin_amdgcn_readlane(my_tile, mid_lane);   // where the sweep starts
+
+    TopKL<K> top;
+    top.init();
+    float worst = live ? FLT_MAX : -1.0f;   // dead lanes never ask for a tile or a candidate
+    int cnt = 0;
+
+    auto drain = [&]() {
+        if constexpr (K > 1) {
+            for (int it = 0; __any(it < cnt); ++it) {
+                if (it < cnt) {
+                    const uint2 e = queue[it * BLK + tid];
+                    const u64 nk = ((u64)e.x << 32) | e.y;
+                    if (top.beats_last(nk)) top.insert(nk);
+                }
+            }
+            cnt = 0;
+            worst = top.worst();
+        }
+    };
+
+    // take one candidate (d, sidx) for this lane if it can still matter
+    auto offer = [&](float d, uint32_t sidx, float limit) {
+        if constexpr (K == 1) {
+            const u64 nk = pack_key(d, sidx);
+            if (d <= limit && top.beats_last(nk)) { top.k[0] = nk; worst = d; }
+        } else {
+            if (d <= limit) {
+                queue[cnt * BLK + tid] = make_uint2(__float_as_uint(d), sidx);
+                cnt++;
+            }
+        }
+    };
+
+    // 1) seed: each lane scans the tile of its OWN query (per-lane addresses), which gives it a
+    //    tight K-th distance before the wave-uniform sweep starts; otherwise a lane would meet
+    //    ever closer tiles during the sweep and insert nearly every point of them.
+    {
+        const float4* tp = sp + (size_t)my_tile * PT;
+#pragma unroll 1
+        for (int j0 = 0; j0 < PT; j0 += GRP) {
+            float4 p[GRP];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) p[u] = tp[j0 + u];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u)
+                offer(sqdist3(q.x, q.y, q.z, p[u].x, p[u].y, p[u].z), __float_as_uint(p[u].w), worst);
+            if constexpr (K > 1) {
+                if (__any(cnt > QCAP - GRP)) drain();
+            }
+        }
+        drain();
+    }
+
+    // scan one tile (all 64 points) for every lane whose bound allows it
+    auto scan_tile = [&](int t, const float4& blo, const float4& bhi) {
+        const float lb = box_bound(q.x, q.y, q.z, blo, bhi);
+        const float limit = (t == my_tile) ? -1.0f : worst;   // own seed tile is already in the list
+        if (!__any(lb <= limit)) return;
+        __builtin_amdgcn_wave_barrier();
+        tile[lane] = sp[(size_t)t * PT + lane];          // one coalesced 1 KiB load per wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+        for (int j0 = 0; j0 < PT; j0 += GRP) {
+            float4 p[GRP];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) p[u] = tile[j0 + u];       // wave-uniform: LDS broadcast
+            float d[GRP];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) d[u] = sqdist3(q.x, q.y, q.z, p[u].x, p[u].y, p[u].z);
+            const float lim = (t == my_tile) ? -1.0f : worst;
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) offer(d[u], __float_as_uint(p[u].w), lim);
+            if constexpr (K > 1) {
+                if (__any(cnt > QCAP - GRP)) drain();
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // 2) sweep: chunks of 64 tiles outwards from t0's chunk; lane l tests tile c*64+l against the
+    //    wave's query box and the largest K-th distance in the wave
+    const int nchunk = (nt + 63) >> 6;
+    const int c0 = t0 >> 6;
+    for (int s = 0; s < 2 * nchunk; ++s) {
+        const int c = (s & 1) ? c0 - ((s + 1) >> 1) : c0 + (s >> 1);
+        if (c < 0 || c >= nchunk) continue;
+        const int t = (c << 6) + lane;
+        float4 blo = make_float4(0, 0, 0, 0), bhi = blo;
+        bool want = false;
+        const float wmax = wave_max(worst);
+        if (t < nt) {
+            blo = bx[t * 2];
+            bhi = bx[t * 2 + 1];
+            want = boxbox_bound(qlo, qhi, blo, bhi) <= wmax;
+        }
+        unsigned long long mask = __ballot(want);
+        while (mask) {
+            const int l = (int)__ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            float4 lo4, hi4;
+            lo4.x = lane_bcast(blo.x, l); lo4.y = lane_bcast(blo.y, l); lo4.z = lane_bcast(blo.z, l); lo4.w = 0.f;
+            hi4.x = lane_bcast(bhi.x, l); hi4.y = lane_bcast(bhi.y, l); hi4.z = lane_bcast(bhi.z, l); hi4.w = 0.f;
+            scan_tile((c << 6) + l, lo4, hi4);
+        }
+    }
+    drain();
+
+    if (live) {
+        const size_t o = ((size_t)b * Q + q_orig) * (size_t)Kout;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (k < Kout) {
+                const uint32_t id = (uint32_t)top.k[k];
+                if (idx64) idx64[o + k] = (int64_t)id;
+                if (idx32) idx32[o + k] = (int32_t)id;
+                if (dist) dist[o + k] = __uint_as_float((uint32_t)(top.k[k] >> 32));
+            }
+        }
+    }
+}
+
+int pad_k(int K)
+{
+    int p = 1;
+    while (p < K) p <<= 1;
+    return p;
+}
+
+size_t sort_temp_bound(size_t n)
+{
+    // rocPRIM onesweep radix sort: two alternate key/value buffers + histograms/look-back state
+    return n * (sizeof(unsigned long long) + sizeof(uint32_t)) + (size_t)(4u << 20);
+}
+
+struct PrepWs {
+    size_t keys_in, keys_out, vals_in, vals_out, bbox, temp, temp_bytes, total;
+};
+
+PrepWs prep_ws(int64_t B, int64_t S)
+{
+    PrepWs w;
+    const size_t n = (size_t)B * S;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
+    w.keys_in = take(n * 8);
+    w.keys_out = take(n * 8);
+    w.vals_in = take(n * 4);
+    w.vals_out = take(n * 4);
+    w.bbox = take((size_t)B * 6 * 4);
+    w.temp_bytes = sort_temp_bound(n);
+    w.temp = take(w.temp_bytes);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+using namespace ffb6d;
+
+extern "C" {
+
+size_t ffb6d_knn_prepared_bytes(int64_t B, int64_t S)
+{
+    if (B <= 0 || S <= 0) return 0;
+    return layout(B, S).total;
+}
+
+size_t ffb6d_knn_prepare_workspace_bytes(int64_t B, int64_t S)
+{
+    if (B <= 0 || S <= 0) return 0;
+    return prep_ws(B, S).total;
+}
+
+int ffb6d_knn_prepare(const float* pts, int64_t B, int64_t S, void* prepared, size_t prepared_bytes,
+                      void* workspace, size_t workspace_bytes, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(B >= 1 && S >= 1, "knn_prepare: empty point set");
+    FFB6D_REQUIRE(S < (1LL << 31) && B < 65536, "knn_prepare: size too large");
+    FFB6D_REQUIRE(pts && prepared && workspace, "knn_prepare: null pointer");
+    const Layout L = layout(B, S);
+    const PrepWs W = prep_ws(B, S);
+    if (prepared_bytes < L.total || workspace_bytes < W.total)
+        return set_error(FFB6D_ERR_WORKSPACE, "knn_prepare: need %zu prepared + %zu workspace bytes, got %zu + %zu",
+                         L.total, W.total, prepared_bytes, workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    char* pp = static_cast<char*>(prepared);
+    auto* keys_in = reinterpret_cast<unsigned long long*>(ws + W.keys_in);
+    auto* keys_out = reinterpret_cast<unsigned long long*>(ws + W.keys_out);
+    auto* vals_in = reinterpret_cast<uint32_t*>(ws + W.vals_in);
+    auto* vals_out = reinterpret_cast<uint32_t*>(ws + W.vals_out);
+    int* bbox = reinterpret_cast<int*>(ws + W.bbox);
+    float* frame = reinterpret_cast<float*>(pp + L.frame_off);
+
+    hipLaunchKernelGGL(bbox_init_kernel, dim3((unsigned)ceil_div(B * 6, 64)), dim3(64), 0, st, bbox, (int)(B * 6));
+    const unsigned rb = (unsigned)std::min<int64_t>(ceil_div(S, BLK), 64);
+    hipLaunchKernelGGL(bbox_kernel, dim3(rb, (unsigned)B), dim3(BLK), 0, st, pts, (int)S, bbox);
+    hipLaunchKernelGGL(frame_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, st, bbox, frame, (int)B);
+    hipLaunchKernelGGL(morton_kernel, dim3((unsigned)ceil_div(S, BLK), (unsigned)B), dim3(BLK), 0, st, pts, (int)S,
+                       frame, keys_in, vals_in);
+    FFB6D_LAUNCH_CHECK();
+
+    const size_t n = (size_t)B * S;
+    unsigned end_bit = 32;
+    while ((1LL << (end_bit - 32)) < B) ++end_bit;
+    size_t need = 0;
+    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
+    if (need > W.temp_bytes)
+        return set_error(FFB6D_ERR_WORKSPACE, "knn_prepare: radix sort wants %zu temp bytes, reserved %zu", need,
+                         W.temp_bytes);
+    size_t have = W.temp_bytes;
+    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(ws + W.temp, have, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
+
+    hipLaunchKernelGGL(gather_box_kernel, dim3((unsigned)ceil_div(L.nt, BLK / 64), (unsigned)B), dim3(BLK), 0, st, pts,
+                       (int)S, (int)L.S_pad, (int)L.nt, keys_out, vals_out,
+                       reinterpret_cast<float4*>(pp + L.pts_off), reinterpret_cast<float4*>(pp + L.box_off),
+                       reinterpret_cast<uint32_t*>(pp + L.key_off));
+    hipLaunchKernelGGL(cell_table_kernel, dim3(NCELL / BLK, (unsigned)B), dim3(BLK), 0, st,
+                       reinterpret_cast<const uint32_t*>(pp + L.key_off), (int)S, (int)L.S_pad, (int)L.nt,
+                       reinterpret_cast<uint32_t*>(pp + L.cell_off));
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+int ffb6d_knn_search_prepared(const void* prep_support, const void* prep_query, int64_t B, int64_t S,
+                              int64_t Q, int K, int64_t* idx64, int32_t* idx32, float* dist,
+                              ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(K >= 1 && K <= 32, "knn_search_prepared: K must be in [1,32] (got %d)", K);
+    FFB6D_REQUIRE(B >= 1 && S >= 1 && Q >= 1, "knn_search_prepared: empty problem");
+    FFB6D_REQUIRE(S >= K, "knn_search_prepared: npts (%lld) < K (%d)", (long long)S, K);
+    FFB6D_REQUIRE(prep_support && prep_query, "knn_search_prepared: null prepared set");
+    FFB6D_REQUIRE(idx64 || idx32 || dist, "knn_search_prepared: no output requested");
+    const Layout LS = layout(B, S), LQ = layout(B, Q);
+    const char* ps = static_cast<const char*>(prep_support);
+    const char* pq = static_cast<const char*>(prep_query);
+    const float4* spts = reinterpret_cast<const float4*>(ps + LS.pts_off);
+    const float4* boxes = reinterpret_cast<const float4*>(ps + LS.box_off);
+    const uint32_t* skeys = reinterpret_cast<const uint32_t*>(ps + LS.key_off);
+    const float* sframe = reinterpret_cast<const float*>(ps + LS.frame_off);
+    const uint32_t* scell = reinterpret_cast<const uint32_t*>(ps + LS.cell_off);
+    const float4* qpts = reinterpret_cast<const float4*>(pq + LQ.pts_off);
+    dim3 grid((unsigned)ceil_div(LQ.S_pad, BLK), (unsigned)B);
+    hipStream_t st = as_stream(stream);
+    const int Kp = pad_k(K);
+    const size_t lds = (size_t)(BLK / 64) * PT * sizeof(float4) + (Kp > 1 ? (size_t)QCAP * BLK * sizeof(uint2) : 0);
+#define FFB6D_LAUNCH_PRUNED(KK)                                                                              \
+    hipLaunchKernelGGL((knn_pruned_kernel<KK>), grid, dim3(BLK), lds, st, spts, boxes, skeys, sframe, scell, (int)S, \
+                       (int)LS.S_pad, (int)LS.nt, qpts, (int)Q, (int)LQ.S_pad, idx64, idx32, dist, K)
+    switch (Kp) {
+        case 1: FFB6D_LAUNCH_PRUNED(1); break;
+        case 2: FFB6D_LAUNCH_PRUNED(2); break;
+        case 4: FFB6D_LAUNCH_PRUNED(4); break;
+        case 8: FFB6D_LAUNCH_PRUNED(8); break;
+        case 16: FFB6D_LAUNCH_PRUNED(16); break;
+        case 32: FFB6D_LAUNCH_PRUNED(32); break;
+        default: return set_error(FFB6D_ERR_ARG, "knn_search_prepared: unsupported K=%d", K);
+    }
+#undef FFB6D_LAUNCH_PRUNED
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+}  // extern "C"

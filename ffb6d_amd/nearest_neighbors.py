@@ -56,6 +56,64 @@ def knn_batch(pts, queries, K, omp=False):
     return indices
 
 
+class PreparedPoints:
+    """A point set [B,S,3] in Morton order with per-tile bounding boxes (opaque device blob
+    built by ffb6d_knn_prepare); reusable as support and/or query of knn_prepared()."""
+
+    def __init__(self, points):
+        import torch
+
+        lib = _lib.load()
+        if not points.is_cuda:
+            raise _lib.FFB6DNativeError("PreparedPoints needs a GPU tensor (no CPU fallback)")
+        if points.dtype != torch.float32 or points.dim() != 3 or points.shape[2] != 3:
+            raise TypeError("points must be float32 [B,S,3]")
+        self.points = points.contiguous()
+        self.B, self.S = int(points.shape[0]), int(points.shape[1])
+        if self.B < 1 or self.S < 1:
+            raise ValueError("empty point set")
+        nbytes = lib.ffb6d_knn_prepared_bytes(self.B, self.S)
+        wbytes = lib.ffb6d_knn_prepare_workspace_bytes(self.B, self.S)
+        self.blob = torch.empty((nbytes,), dtype=torch.uint8, device=points.device)
+        ws = torch.empty((wbytes,), dtype=torch.uint8, device=points.device)
+        with torch.cuda.device(points.device), _lib.traced("knn_prepare", 12 * self.B * self.S, (self.S,)):
+            rc = lib.ffb6d_knn_prepare(self.points.data_ptr(), self.B, self.S, self.blob.data_ptr(), nbytes,
+                                       ws.data_ptr(), wbytes, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "ffb6d_knn_prepare")
+
+
+def knn_prepared(support, query, K, dtype=None, return_dist=False):
+    """Exact KNN between two PreparedPoints (same results as knn_batch_device)."""
+    import torch
+
+    lib = _lib.load()
+    if support.B != query.B:
+        raise ValueError("batch sizes differ")
+    K = int(K)
+    if not 1 <= K <= 32:
+        raise ValueError(f"K must be in [1, 32], got {K}")
+    if support.S < K:
+        raise ValueError(f"npts ({support.S}) < K ({K})")
+    dtype = dtype or torch.int64
+    dev = support.points.device
+    B, S, Q = support.B, support.S, query.S
+    idx = torch.empty((B, Q, K), dtype=dtype, device=dev)
+    dist = torch.empty((B, Q, K), dtype=torch.float32, device=dev) if return_dist else None
+    nbytes = 12 * B * S + 12 * B * Q + idx.element_size() * B * Q * K
+    with torch.cuda.device(dev), _lib.traced("knn", nbytes, (S, Q, K)):
+        rc = lib.ffb6d_knn_search_prepared(
+            support.blob.data_ptr(), query.blob.data_ptr(), B, S, Q, K,
+            idx.data_ptr() if dtype == torch.int64 else None,
+            idx.data_ptr() if dtype == torch.int32 else None,
+            dist.data_ptr() if dist is not None else None, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "ffb6d_knn_search_prepared")
+    return (idx, dist) if return_dist else idx
+
+
+def uses_pruning(B, S, Q, K):
+    return bool(_lib.load().ffb6d_knn_uses_pruning(B, S, Q, K))
+
+
 def knn_batch_device(support, query, K, dtype=None, return_dist=False):
     """Device entry: support [B,S,3], query [B,Q,3] float32 CUDA(HIP) tensors ->
     index tensor [B,Q,K] (torch.int64 default, or torch.int32) on the same device,
@@ -67,6 +125,7 @@ def knn_batch_device(support, query, K, dtype=None, return_dist=False):
         raise _lib.FFB6DNativeError("knn_batch_device needs GPU tensors (no CPU fallback)")
     if support.dtype != torch.float32 or query.dtype != torch.float32:
         raise TypeError("support/query must be float32")
+    support_in = query if query is support else None   # self-KNN: one prepare serves both sides
     support = support.contiguous()
     query = query.contiguous()
     K = _check(support, query, K, 3)
@@ -79,10 +138,11 @@ def knn_batch_device(support, query, K, dtype=None, return_dist=False):
     dist = torch.empty((B, Q, K), dtype=torch.float32, device=support.device) if return_dist else None
     wbytes = lib.ffb6d_knn_workspace_bytes(B, S, Q, K)
     ws = torch.empty((wbytes,), dtype=torch.uint8, device=support.device) if wbytes else None
-    with torch.cuda.device(support.device):
+    nbytes = 12 * B * S + 12 * B * Q + idx.element_size() * B * Q * K   # 12S + 12Q + idx
+    with torch.cuda.device(support.device), _lib.traced("knn", nbytes, (S, Q, K)):
         stream = torch.cuda.current_stream().cuda_stream
         rc = lib.ffb6d_knn_batch_device(
-            support.data_ptr(), query.data_ptr(), B, S, Q, K,
+            support.data_ptr(), (support if query is support_in else query).data_ptr(), B, S, Q, K,
             idx.data_ptr() if dtype == torch.int64 else None,
             idx.data_ptr() if dtype == torch.int32 else None,
             dist.data_ptr() if dist is not None else None,

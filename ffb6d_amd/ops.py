@@ -51,7 +51,8 @@ class _RandomSample(torch.autograd.Function):
         out = torch.empty((B, C, Np), dtype=torch.float32, device=feature.device)
         need_arg = feature.requires_grad
         arg = torch.empty((B, C, Np), dtype=torch.int32, device=feature.device) if need_arg else None
-        with torch.cuda.device(feature.device):
+        nbytes = 4 * B * C * M + (bits // 8) * B * Np * K + 4 * B * C * Np
+        with torch.cuda.device(feature.device), _lib.traced("random_sample", nbytes, (C, M, Np)):
             rc = lib.ffb6d_random_sample_f32(feature.data_ptr(), idx.data_ptr(), bits, out.data_ptr(),
                                              arg.data_ptr() if need_arg else None,
                                              B, C, M, Np, K, _stream(feature))
@@ -98,7 +99,8 @@ class _NearestInterp(torch.autograd.Function):
         U = interp_idx.shape[1]
         idx, bits = _idx(interp_idx)
         out = torch.empty((B, C, U), dtype=torch.float32, device=feature.device)
-        with torch.cuda.device(feature.device):
+        nbytes = 4 * B * C * M + (bits // 8) * B * U + 4 * B * C * U
+        with torch.cuda.device(feature.device), _lib.traced("nearest_interpolation", nbytes, (C, M, U)):
             rc = lib.ffb6d_nearest_interpolation_f32(feature.data_ptr(), idx.data_ptr(), bits,
                                                      out.data_ptr(), B, C, M, U, _stream(feature))
         _lib.check(rc, "ffb6d_nearest_interpolation_f32")
@@ -152,7 +154,8 @@ class _GatherNeighbour(torch.autograd.Function):
         N, K = neighbor_idx.shape[1], neighbor_idx.shape[2]
         idx, bits = _idx(neighbor_idx)
         out = torch.empty((B, N, K, C), dtype=torch.float32, device=pc.device)
-        with torch.cuda.device(pc.device):
+        nbytes = 4 * B * M * C + (bits // 8) * B * N * K + 4 * B * N * K * C
+        with torch.cuda.device(pc.device), _lib.traced("gather_neighbour", nbytes, (M, C)):
             rc = lib.ffb6d_gather_neighbour_f32(pc.data_ptr(), idx.data_ptr(), bits, out.data_ptr(),
                                                 B, M, C, N, K, _stream(pc))
         _lib.check(rc, "ffb6d_gather_neighbour_f32")
@@ -196,7 +199,8 @@ def relative_pos_encoding(xyz, neigh_idx):
     B, N, _ = xyz_c.shape
     K = idx.shape[2]
     out = torch.empty((B, N, K, 10), dtype=torch.float32, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    nbytes = 12 * B * N + (bits // 8) * B * N * K + 40 * B * N * K
+    with torch.cuda.device(xyz.device), _lib.traced("relative_pos_encoding", nbytes, (N,)):
         rc = lib.ffb6d_relative_pos_encoding_f32(xyz_c.data_ptr(), idx.data_ptr(), bits, out.data_ptr(),
                                                  B, N, K, _stream(xyz_c))
     _lib.check(rc, "ffb6d_relative_pos_encoding_f32")
@@ -209,7 +213,8 @@ class _AttPool(torch.autograd.Function):
         lib = _lib.load()
         B, C, N, K = feature_set.shape
         out = torch.empty((B, C, N), dtype=torch.float32, device=feature_set.device)
-        with torch.cuda.device(feature_set.device):
+        nbytes = 2 * 4 * B * C * N * K + 4 * B * C * N
+        with torch.cuda.device(feature_set.device), _lib.traced("att_pool", nbytes, (C, N)):
             rc = lib.ffb6d_att_pool_f32(feature_set.data_ptr(), att_activation.data_ptr(),
                                         out.data_ptr(), B, C, N, K, _stream(feature_set))
         _lib.check(rc, "ffb6d_att_pool_f32")

@@ -16,7 +16,7 @@ grid[s] = xyz image at stride s, pixel (y*s, x*s), flattened row-major (:299-311
 """
 import torch
 
-from .nearest_neighbors import knn_batch_device
+from .nearest_neighbors import PreparedPoints, knn_batch_device, knn_prepared, uses_pruning
 
 RGB_DS_SR = (4, 8, 8, 8)
 RGB_UP_SR = (4, 2, 2)
@@ -40,26 +40,39 @@ def build_index_pyramid(cld, dpt_xyz, index_dtype=torch.int64):
     int32 is what the dataset stores (halves the index traffic of every gather)."""
     if cld.dim() != 3 or cld.shape[2] != 3 or dpt_xyz.dim() != 4 or dpt_xyz.shape[1] != 3:
         raise ValueError(f"bad shapes {tuple(cld.shape)} / {tuple(dpt_xyz.shape)}")
+    B = cld.shape[0]
     grids = {s: strided_grid(dpt_xyz, s) for s in sorted(set(RGB_DS_SR + RGB_UP_SR))}
+    prepared = {}
+
+    def search(support, query, k):
+        """Route big supports through Morton-prepared sets (each set is sorted once and reused by
+        every search that touches it), small ones through the brute-force scan."""
+        if not uses_pruning(B, support.shape[1], query.shape[1], k):
+            return knn_batch_device(support, query, k, dtype=index_dtype)
+        for t in (support, query):
+            if id(t) not in prepared:
+                prepared[id(t)] = PreparedPoints(t)
+        return knn_prepared(prepared[id(support)], prepared[id(query)], k, dtype=index_dtype)
+
     out = {}
     cur = cld.contiguous()
     for i in range(4):
         n_sub = cur.shape[1] // SUB_RATIO[i]
-        nei = knn_batch_device(cur, cur, K_NEI, dtype=index_dtype)
+        nei = search(cur, cur, K_NEI)
         sub = cur[:, :n_sub, :].contiguous()
         out['cld_xyz%d' % i] = cur
         out['cld_nei_idx%d' % i] = nei
         out['cld_sub_idx%d' % i] = nei[:, :n_sub, :].contiguous()
-        out['cld_interp_idx%d' % i] = knn_batch_device(sub, cur, 1, dtype=index_dtype)
+        out['cld_interp_idx%d' % i] = search(sub, cur, 1)
         g = grids[RGB_DS_SR[i]]
-        out['r2p_ds_nei_idx%d' % i] = knn_batch_device(g, sub, K_NEI, dtype=index_dtype)
-        out['p2r_ds_nei_idx%d' % i] = knn_batch_device(sub, g, 1, dtype=index_dtype)
+        out['r2p_ds_nei_idx%d' % i] = search(g, sub, K_NEI)
+        out['p2r_ds_nei_idx%d' % i] = search(sub, g, 1)
         cur = sub
     for i in range(3):
         g = grids[RGB_UP_SR[i]]
         pts = out['cld_xyz%d' % (3 - i)]
-        out['r2p_up_nei_idx%d' % i] = knn_batch_device(g, pts, K_NEI, dtype=index_dtype)
-        out['p2r_up_nei_idx%d' % i] = knn_batch_device(pts, g, 1, dtype=index_dtype)
+        out['r2p_up_nei_idx%d' % i] = search(g, pts, K_NEI)
+        out['p2r_up_nei_idx%d' % i] = search(pts, g, 1)
     return out
 
 

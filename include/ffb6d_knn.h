@@ -84,6 +84,30 @@ int ffb6d_knn_batch_device(const float* support, const float* query,
                            int64_t* idx64, int32_t* idx32, float* dist,
                            void* workspace, size_t workspace_bytes, ffb6d_stream_t stream);
 
+/* ---- prepared (spatially sorted) point sets ------------------------------------------------
+ * The 22 searches of one FFB6D index pyramid reuse 8 point sets (4 cloud levels, 3 image
+ * grids, ...).  A set is put into Morton order once (ffb6d_knn_prepare) and can then serve as
+ * support and/or query of any number of ffb6d_knn_search_prepared calls; the search visits only
+ * the 64-point tiles whose bounding box can still hold one of the K nearest neighbours.  Results
+ * are identical to ffb6d_knn_batch_device (exact, same tie rule, original index space/order).
+ *
+ *   prepared   : opaque device buffer of ffb6d_knn_prepared_bytes(B, npts) bytes
+ *   workspace  : device scratch of ffb6d_knn_prepare_workspace_bytes(B, npts) bytes (only needed
+ *                during ffb6d_knn_prepare)
+ */
+size_t ffb6d_knn_prepared_bytes(int64_t batch_size, int64_t npts);
+size_t ffb6d_knn_prepare_workspace_bytes(int64_t batch_size, int64_t npts);
+int ffb6d_knn_prepare(const float* points /* [B,npts,3] device */, int64_t batch_size, int64_t npts,
+                      void* prepared, size_t prepared_bytes, void* workspace, size_t workspace_bytes,
+                      ffb6d_stream_t stream);
+int ffb6d_knn_search_prepared(const void* prepared_support, const void* prepared_query,
+                              int64_t batch_size, int64_t npts, int64_t nqueries, int K,
+                              int64_t* idx64, int32_t* idx32, float* dist, ffb6d_stream_t stream);
+
+/* 1 when ffb6d_knn_batch_device would take the prepared/pruned route for this shape
+ * (large support sets), 0 when it scans brute force. */
+int ffb6d_knn_uses_pruning(int64_t batch_size, int64_t npts, int64_t nqueries, int K);
+
 #ifdef __cplusplus
 }
 #endif

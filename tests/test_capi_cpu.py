@@ -41,9 +41,15 @@ def test_library_exports_every_declared_symbol(native_lib):
 
 
 def test_workspace_query_is_pure_host_logic(native_lib):
-    # many query blocks -> no split, no scratch; few queries against a big grid -> split-S scratch
-    assert native_lib.ffb6d_knn_workspace_bytes(64, 12288, 12288, 16) == 0
-    assert native_lib.ffb6d_knn_workspace_bytes(8, 76800, 768, 16) > 0
+    # small support, many query blocks -> brute-force scan without split, no scratch
+    assert native_lib.ffb6d_knn_uses_pruning(64, 1024, 12288, 16) == 0
+    assert native_lib.ffb6d_knn_workspace_bytes(64, 1024, 12288, 16) == 0
+    # small support, few queries -> split-S partial lists need scratch
+    assert native_lib.ffb6d_knn_workspace_bytes(1, 2000, 100, 16) > 0
+    # big support -> Morton-prepared sets + sort scratch
+    assert native_lib.ffb6d_knn_uses_pruning(8, 76800, 768, 16) == 1
+    need = native_lib.ffb6d_knn_workspace_bytes(8, 76800, 768, 16)
+    assert need >= native_lib.ffb6d_knn_prepared_bytes(8, 76800) + native_lib.ffb6d_knn_prepared_bytes(8, 768)
     assert native_lib.ffb6d_knn_workspace_bytes(0, 10, 10, 16) == 0
 
 
