@@ -44,8 +44,6 @@ def test_workspace_query_is_pure_host_logic(native_lib):
     # small support, many query blocks -> brute-force scan without split, no scratch
     assert native_lib.ffb6d_knn_uses_pruning(64, 1024, 12288, 16) == 0
     assert native_lib.ffb6d_knn_workspace_bytes(64, 1024, 12288, 16) == 0
-    # small support, few queries -> split-S partial lists need scratch
-    assert native_lib.ffb6d_knn_workspace_bytes(1, 2000, 100, 16) > 0
     # big support -> Morton-prepared sets + sort scratch
     assert native_lib.ffb6d_knn_uses_pruning(8, 76800, 768, 16) == 1
     need = native_lib.ffb6d_knn_workspace_bytes(8, 76800, 768, 16)
