@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--trace-all", action="store_true", help="extra untimed pass: per-op table to stderr")
+    ap.add_argument("--cudnn-benchmark", type=int, default=1,
+                    help="torch.backends.cudnn.benchmark (MIOpen find mode for the colour branch's dense convs)")
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
@@ -134,6 +136,7 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ffb6d_relative_pos_encoding_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_att_pool_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_att_pool_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_bilinear_resize_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_check_index_range": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
 }
 

@@ -41,9 +41,11 @@ constexpr int CELL_BITS = 15;                 // coarse Z-curve cells (top bits 
 constexpr int CELL_SHIFT = 30 - CELL_BITS;
 constexpr int NCELL = 1 << CELL_BITS;
 
+constexpr int FAN = 16;                       // tiles per level-2 box
+
 struct Layout {
-    int64_t S_pad, nt;
-    size_t pts_off, box_off, key_off, frame_off, cell_off, total;
+    int64_t S_pad, nt, nt2;
+    size_t pts_off, box_off, box2_off, key_off, frame_off, cell_off, total;
 };
 
 Layout layout(int64_t B, int64_t S)
@@ -51,9 +53,11 @@ Layout layout(int64_t B, int64_t S)
     Layout l;
     l.S_pad = ceil_div(S, PT) * PT;
     l.nt = l.S_pad / PT;
+    l.nt2 = ceil_div(l.nt, FAN);
     size_t o = 0;
     l.pts_off = o;   o += (size_t)B * l.S_pad * sizeof(float4);
     l.box_off = o;   o += (size_t)B * l.nt * 2 * sizeof(float4);
+    l.box2_off = o;  o += (size_t)B * l.nt2 * 2 * sizeof(float4);
     l.key_off = o;   o += (size_t)B * l.S_pad * sizeof(uint32_t);
     l.frame_off = o; o += (size_t)B * 8 * sizeof(float);
     l.cell_off = o;  o += (size_t)B * NCELL * sizeof(uint32_t);   // cell -> tile holding its first point
@@ -188,6 +192,23 @@ gather_box_kernel(const float* __restrict__ pts, int S, int S_pad, int nt,
         boxes[((size_t)b * nt + t) * 2 + 0] = make_float4(lo[0], lo[1], lo[2], 0.f);
         boxes[((size_t)b * nt + t) * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
     }
+}
+
+// level-2 boxes: the hull of FAN consecutive tile boxes
+__global__ void __launch_bounds__(BLK)
+box2_kernel(const float4* __restrict__ boxes, int nt, int nt2, float4* __restrict__ boxes2)
+{
+    const int b = blockIdx.y;
+    const int g = blockIdx.x * BLK + threadIdx.x;
+    if (g >= nt2) return;
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+    for (int t = g * FAN; t < min(nt, (g + 1) * FAN); ++t) {
+        const float4 a = boxes[((size_t)b * nt + t) * 2], c = boxes[((size_t)b * nt + t) * 2 + 1];
+        lo.x = fminf(lo.x, a.x); lo.y = fminf(lo.y, a.y); lo.z = fminf(lo.z, a.z);
+        hi.x = fmaxf(hi.x, c.x); hi.y = fmaxf(hi.y, c.y); hi.z = fmaxf(hi.z, c.z);
+    }
+    boxes2[((size_t)b * nt2 + g) * 2] = lo;
+    boxes2[((size_t)b * nt2 + g) * 2 + 1] = hi;
 }
 
 // cell -> index of the tile that holds the first point whose key is >= (cell << CELL_SHIFT)
@@ -447,6 +468,154 @@ knn_pruned_kernel(const float4* __restrict__ spts, const float4* __restrict__ bo
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K <= 16: one ROW of 16 lanes (a DPP row, 4 rows per wave) owns one query.
+//   * lane r of the row holds rank r of the running top-16 as a packed (distance, index) key;
+//     an insert is a 16-lane ballot (how many entries sort before the candidate) plus one
+//     row_shr:1 DPP shift -- no per-lane register lists, no LDS queues;
+//   * the row tests 16 boxes at a time (one per lane): level-2 boxes first, then the 16 tile
+//     boxes of every level-2 box that survives, then the 64 points of every surviving tile in
+//     4 coalesced 256-byte row loads.  Every lane does useful work whether the queries of a
+//     wave are neighbours in space or not, so sparse query sets (a few hundred points against
+//     a 76800-pixel grid) cost the same per query as dense ones.
+// grid = (ceil(Q_pad / 16), B)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t row_bits(unsigned long long ballot, int lane)
+{
+    return (uint32_t)(ballot >> (lane & 48)) & 0xffffu;
+}
+__device__ __forceinline__ u64 row_get(u64 v, int j)   // value of v in lane j of my row
+{
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, j, 16);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), j, 16);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 row_shr1(u64 v)         // lane r gets lane r-1 (lane 0 keeps its own)
+{
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x111, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x111, 0xf, 0xf, false);
+    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+template <int K>
+__global__ void __launch_bounds__(BLK)
+knn_row16_kernel(const float4* __restrict__ spts, const float4* __restrict__ boxes,
+                 const float4* __restrict__ boxes2, const float* __restrict__ sframe,
+                 const uint32_t* __restrict__ skeys, int S, int S_pad, int nt, int nt2,
+                 const float4* __restrict__ qpts, int Q, int Q_pad,
+                 int64_t* __restrict__ idx64, int32_t* __restrict__ idx32, float* __restrict__ dist,
+                 int Kout)
+{
+    static_assert(K >= 2 && K <= 16, "row kernel holds one rank per lane");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r = tid & 15;
+    const int b = blockIdx.y;
+    const int qslot = blockIdx.x * (BLK / 16) + (tid >> 4);
+    const float4 q = qpts[(size_t)b * Q_pad + min(qslot, Q_pad - 1)];
+    const uint32_t q_orig = __float_as_uint(q.w);
+    const bool live = qslot < Q_pad && q_orig != 0xffffffffu;
+    if (!__any(live)) return;
+
+    const float4* sp = spts + (size_t)b * S_pad;
+    const float4* bx = boxes + (size_t)b * nt * 2;
+    const float4* bx2 = boxes2 + (size_t)b * nt2 * 2;
+
+    u64 L = KEY_EMPTY;                       // rank r of the row's sorted top-16
+    float worst = live ? FLT_MAX : -1.0f;    // row-uniform; -1 = this row never takes anything
+
+    // offer the row's 16 candidate keys (one per lane, `pass` marks the useful ones)
+    auto merge = [&](u64 key, bool pass) {
+        uint32_t m = row_bits(__ballot(pass), lane);
+        while (__any(m != 0)) {
+            if (m != 0) {                                    // row-uniform
+                const int j = __ffs((int)m) - 1;
+                m &= m - 1;
+                const u64 x = row_get(key, j);
+                const int p = __popc(row_bits(__ballot(L < x), lane));   // entries sorting before x
+                const u64 prev = row_shr1(L);
+                L = (r < p) ? L : ((r == p) ? x : prev);
+            }
+        }
+        worst = live ? __uint_as_float((uint32_t)(row_get(L, K - 1) >> 32)) : -1.0f;
+    };
+
+    auto scan_tile = [&](int t) {                            // t row-uniform
+        const float4* tp = sp + (size_t)t * PT;
+        float4 p[PT / 16];
+#pragma unroll
+        for (int c = 0; c < PT / 16; ++c) p[c] = tp[c * 16 + r];   // 4 x 256 B per row, all in flight
+#pragma unroll
+        for (int c = 0; c < PT / 16; ++c) {
+            const float d = sqdist3(q.x, q.y, q.z, p[c].x, p[c].y, p[c].z);
+            merge(pack_key(d, __float_as_uint(p[c].w)), d <= worst);
+        }
+    };
+
+    // seed with the tile holding the query's own position on the support's Z-curve:
+    // 17-ary lower_bound over the sorted keys, 16 probes per step (one per lane of the row)
+    int my_tile = 0;
+    {
+        const uint32_t kq = morton_key(q.x, q.y, q.z, sframe + b * 8);
+        const uint32_t* sk = skeys + (size_t)b * S_pad;
+        int lo = 0, hi = live ? S : 0;
+        while (__any(hi > lo)) {
+            if (hi > lo) {                                   // row-uniform
+                const long long span = hi - lo;
+                const int pos = lo + (int)((span * (r + 1)) / 17);
+                const int c = __popc(row_bits(__ballot(sk[pos] < kq), lane));   // probes below kq: 1..1 0..0
+                const int new_lo = c > 0 ? lo + (int)((span * c) / 17) + 1 : lo;
+                const int new_hi = c < 16 ? lo + (int)((span * (c + 1)) / 17) : hi;
+                lo = new_lo;
+                hi = new_hi;
+            }
+        }
+        my_tile = min(lo / PT, nt - 1);
+    }
+    // the query's own tile and its two neighbours on the curve (a Z-curve neighbour on one
+    // side can be far away in space, the one on the other side is then usually close)
+    const int seed_lo = max(my_tile - 1, 0), seed_hi = min(my_tile + 1, nt - 1);
+    if (live) {
+        scan_tile(my_tile);
+        if (seed_lo != my_tile) scan_tile(seed_lo);
+        if (seed_hi != my_tile) scan_tile(seed_hi);
+    }
+
+    // level 2 -> level 1 -> points
+    for (int g0 = 0; g0 < nt2; g0 += 16) {                   // uniform trip count
+        const int g = g0 + r;
+        bool want2 = false;
+        if (g < nt2) want2 = box_bound(q.x, q.y, q.z, bx2[g * 2], bx2[g * 2 + 1]) <= worst;
+        uint32_t m2 = row_bits(__ballot(want2), lane);
+        while (__any(m2 != 0)) {
+            if (m2 != 0) {
+                const int gsel = g0 + __ffs((int)m2) - 1;     // row-uniform level-2 box
+                m2 &= m2 - 1;
+                const int t = gsel * FAN + r;
+                float lb1 = INFINITY;                         // this lane's tile bound
+                if (t < nt && (t < seed_lo || t > seed_hi)) lb1 = box_bound(q.x, q.y, q.z, bx[t * 2], bx[t * 2 + 1]);
+                uint32_t m1 = row_bits(__ballot(lb1 <= worst), lane);
+                while (m1 != 0) {                             // row-uniform loop
+                    const int j = __ffs((int)m1) - 1;
+                    m1 &= m1 - 1;
+                    // the K-th distance may have tightened since the ballot: re-check the bound
+                    // (held by lane j of the row) before paying for the tile
+                    const float lbj = __shfl(lb1, j, 16);
+                    if (lbj <= worst) scan_tile(gsel * FAN + j);
+                }
+            }
+        }
+    }
+
+    if (live && r < Kout) {
+        const size_t o = ((size_t)b * Q + q_orig) * (size_t)Kout + r;
+        const uint32_t id = (uint32_t)L;
+        if (idx64) idx64[o] = (int64_t)id;
+        if (idx32) idx32[o] = (int32_t)id;
+        if (dist) dist[o] = __uint_as_float((uint32_t)(L >> 32));
+    }
+}
+
 int pad_k(int K)
 {
     int p = 1;
@@ -544,6 +713,9 @@ int ffb6d_knn_prepare(const float* pts, int64_t B, int64_t S, void* prepared, si
                        (int)S, (int)L.S_pad, (int)L.nt, keys_out, vals_out,
                        reinterpret_cast<float4*>(pp + L.pts_off), reinterpret_cast<float4*>(pp + L.box_off),
                        reinterpret_cast<uint32_t*>(pp + L.key_off));
+    hipLaunchKernelGGL(box2_kernel, dim3((unsigned)ceil_div(L.nt2, BLK), (unsigned)B), dim3(BLK), 0, st,
+                       reinterpret_cast<const float4*>(pp + L.box_off), (int)L.nt, (int)L.nt2,
+                       reinterpret_cast<float4*>(pp + L.box2_off));
     hipLaunchKernelGGL(cell_table_kernel, dim3(NCELL / BLK, (unsigned)B), dim3(BLK), 0, st,
                        reinterpret_cast<const uint32_t*>(pp + L.key_off), (int)S, (int)L.S_pad, (int)L.nt,
                        reinterpret_cast<uint32_t*>(pp + L.cell_off));
@@ -572,6 +744,22 @@ int ffb6d_knn_search_prepared(const void* prep_support, const void* prep_query, 
     dim3 grid((unsigned)ceil_div(LQ.S_pad, BLK), (unsigned)B);
     hipStream_t st = as_stream(stream);
     const int Kp = pad_k(K);
+    if (K >= 2 && K <= 16) {   // row-cooperative kernel: 16 lanes per query
+        const float4* boxes2 = reinterpret_cast<const float4*>(ps + LS.box2_off);
+        dim3 rgrid((unsigned)ceil_div(LQ.S_pad, BLK / 16), (unsigned)B);
+#define FFB6D_LAUNCH_ROW(KK)                                                                                  \
+    hipLaunchKernelGGL((knn_row16_kernel<KK>), rgrid, dim3(BLK), 0, st, spts, boxes, boxes2, sframe, skeys,    \
+                       (int)S, (int)LS.S_pad, (int)LS.nt, (int)LS.nt2, qpts, (int)Q, (int)LQ.S_pad, idx64, idx32, dist, K)
+        switch (Kp) {
+            case 2: FFB6D_LAUNCH_ROW(2); break;
+            case 4: FFB6D_LAUNCH_ROW(4); break;
+            case 8: FFB6D_LAUNCH_ROW(8); break;
+            default: FFB6D_LAUNCH_ROW(16); break;
+        }
+#undef FFB6D_LAUNCH_ROW
+        FFB6D_LAUNCH_CHECK();
+        return FFB6D_OK;
+    }
     const size_t lds = (size_t)(BLK / 64) * PT * sizeof(float4) + (Kp > 1 ? (size_t)QCAP * BLK * sizeof(uint2) : 0);
 #define FFB6D_LAUNCH_PRUNED(KK)                                                                              \
     hipLaunchKernelGGL((knn_pruned_kernel<KK>), grid, dim3(BLK), lds, st, spts, boxes, skeys, sframe, scell, (int)S, \

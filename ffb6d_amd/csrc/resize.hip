@@ -1,0 +1,98 @@
+// ffb6d_amd/csrc/resize.hip -- bilinear resize of NCHW float32 feature maps for gfx950.
+//
+// The colour branch of FFB6D up-samples seven times per forward (pspnet.py:24-28: four
+// F.upsample(size=(h,w), mode='bilinear') in the pyramid-pooling module, align_corners=False;
+// pspnet.py:37-42: three nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)).
+// These are pure HBM streams (each writes up to 629 MB at bs=8); the stock kernel spends
+// ~8 ms per forward on them.  Here one lane produces four consecutive output pixels of one
+// row (a single 16-byte store), source rows stay L1/L2 resident.
+//
+// Arithmetic follows ATen's upsample_bilinear2d (area_pixel_compute_source_index +
+// the h0lambda/h1lambda blend) operation by operation, so results agree with the reference to
+// float rounding.
+#include "common.h"
+#include "ffb6d_ops.h"
+
+namespace ffb6d {
+namespace {
+
+constexpr int BLK = 256;
+
+__device__ __forceinline__ float src_index(float scale, int dst, bool align_corners)
+{
+    if (align_corners) return scale * (float)dst;
+    const float s = scale * ((float)dst + 0.5f) - 0.5f;
+    return s < 0.f ? 0.f : s;
+}
+
+template <int V>
+__global__ void __launch_bounds__(BLK)
+bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int IH, int IW, int OH, int OW,
+                float rh, float rw, int align_corners, size_t total /* planes*OH*OW/V */)
+{
+    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (t >= total) return;
+    const int owv = OW / V;
+    const int xg = (int)(t % owv);
+    const size_t row = t / owv;              // plane*OH + oy
+    const int oy = (int)(row % OH);
+    const size_t plane = row / OH;
+    const float h1r = src_index(rh, oy, align_corners);
+    const int h1 = (int)h1r;
+    const int h1p = (h1 < IH - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const float* r0 = in + (plane * IH + h1) * (size_t)IW;
+    const float* r1 = r0 + (size_t)h1p * IW;
+    float res[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int ox = xg * V + v;
+        const float w1r = src_index(rw, ox, align_corners);
+        const int w1 = (int)w1r;
+        const int w1p = (w1 < IW - 1) ? 1 : 0;
+        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        res[v] = h0l * (w0l * r0[w1] + w1l * r0[w1 + w1p]) + h1l * (w0l * r1[w1] + w1l * r1[w1 + w1p]);
+    }
+    float* o = out + row * (size_t)OW + (size_t)xg * V;
+    if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+    } else {
+        o[0] = res[0];
+    }
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+using namespace ffb6d;
+
+extern "C" int ffb6d_bilinear_resize_f32(const float* in, float* out, int64_t planes, int64_t IH, int64_t IW,
+                                         int64_t OH, int64_t OW, int align_corners, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(planes >= 0 && IH >= 1 && IW >= 1 && OH >= 1 && OW >= 1, "bilinear_resize: bad shape");
+    FFB6D_REQUIRE(IH < (1 << 24) && IW < (1 << 24) && OH < (1 << 24) && OW < (1 << 24), "bilinear_resize: too large");
+    if (planes == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(in && out, "bilinear_resize: null pointer");
+    // ATen: align_corners -> (in-1)/(out-1) (0 when out == 1), else in/out
+    float rh, rw;
+    if (align_corners) {
+        rh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;
+        rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+    } else {
+        rh = (float)IH / (float)OH;
+        rw = (float)IW / (float)OW;
+    }
+    hipStream_t st = as_stream(stream);
+    const bool vec = (OW % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (vec) {
+        const size_t total = (size_t)planes * OH * (OW / 4);
+        hipLaunchKernelGGL((bilinear_kernel<4>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, st, in, out,
+                           (int)IH, (int)IW, (int)OH, (int)OW, rh, rw, align_corners, total);
+    } else {
+        const size_t total = (size_t)planes * OH * OW;
+        hipLaunchKernelGGL((bilinear_kernel<1>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, st, in, out,
+                           (int)IH, (int)IW, (int)OH, (int)OW, rh, rw, align_corners, total);
+    }
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}

@@ -210,7 +210,10 @@ class PyramidPooling(nn.Module):
 
     def forward(self, x):
         h, w = x.shape[2:]
-        pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]
+        if torch.is_grad_enabled() or not x.is_cuda:
+            pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]
+        else:
+            pri = [ops.bilinear_resize(st(x), (h, w), align_corners=False) for st in self.stages]
         return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
 
 
@@ -223,7 +226,10 @@ class UpBlock(nn.Module):
                                   nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.PReLU())
 
     def forward(self, x):
-        return self.conv(x)
+        if torch.is_grad_enabled() or not x.is_cuda:
+            return self.conv(x)
+        y = ops.bilinear_resize(x, (2 * x.shape[2], 2 * x.shape[3]), align_corners=True)
+        return self.conv[3](self.conv[2](self.conv[1](y)))
 
 
 def _head(cin, cout):

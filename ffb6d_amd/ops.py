@@ -246,6 +246,26 @@ def att_pool(feature_set, att_activation):
     return _AttPool.apply(_f32(feature_set), _f32(att_activation)).unsqueeze(3)
 
 
+def bilinear_resize(x, size, align_corners):
+    """x [B,C,IH,IW] float32 -> [B,C,OH,OW], bilinear, the two conventions of the colour branch
+    (pspnet.py:24-28 align_corners=False; pspnet.py:37-42 align_corners=True).  Inference only
+    (no autograd): callers fall back to torch's differentiable op when gradients are needed."""
+    _need_gpu(x)
+    if x.dim() != 4:
+        raise ValueError(f"expected [B,C,H,W], got {tuple(x.shape)}")
+    lib = _lib.load()
+    xc = _f32(x.detach())
+    B, C, IH, IW = xc.shape
+    OH, OW = int(size[0]), int(size[1])
+    out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+    nbytes = 4 * B * C * (IH * IW + OH * OW)
+    with torch.cuda.device(x.device), _lib.traced("bilinear_resize", nbytes, (C, OH, OW)):
+        rc = lib.ffb6d_bilinear_resize_f32(xc.data_ptr(), out.data_ptr(), B * C, IH, IW, OH, OW,
+                                           1 if align_corners else 0, _stream(xc))
+    _lib.check(rc, "ffb6d_bilinear_resize_f32")
+    return out
+
+
 def check_index_range(idx, M):
     """Number of entries of `idx` outside [0, M) (debug aid; the kernels do not bounds-check)."""
     _need_gpu(idx)

@@ -80,6 +80,13 @@ int ffb6d_att_pool_bwd_f32(const float* grad_out, const float* feat, const float
                            float* grad_feat, float* grad_act,
                            int64_t B, int64_t C, int64_t N, int K, ffb6d_stream_t stream);
 
+/* Bilinear resize of `planes` = B*C independent [IH,IW] float32 images to [OH,OW], the two
+ * flavours the colour branch uses: align_corners = 0 (F.upsample(size=...), pspnet.py:24-28) and
+ * align_corners = 1 (nn.Upsample(scale_factor=2, align_corners=True), pspnet.py:37-42).
+ * Same arithmetic as ATen's upsample_bilinear2d. */
+int ffb6d_bilinear_resize_f32(const float* in, float* out, int64_t planes, int64_t IH, int64_t IW,
+                              int64_t OH, int64_t OW, int align_corners, ffb6d_stream_t stream);
+
 /* Debug helper: number of entries of idx[0:count] outside [0, M) written to *bad (device int32). */
 int ffb6d_check_index_range(const void* idx, int idx_bits, int64_t count, int64_t M,
                             int32_t* bad, ffb6d_stream_t stream);

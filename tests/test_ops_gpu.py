@@ -134,3 +134,13 @@ def test_index_range_check(device):
     idx = torch.tensor([[0, 5, 9, 10, -1]], device=device)
     assert ops.check_index_range(idx, 10) == 2
     assert ops.check_index_range(idx.int()[:, :3], 10) == 0
+
+
+@pytest.mark.parametrize("shape,size,ac", [((2, 16, 60, 80), (120, 160), True), ((1, 3, 7, 5), (14, 10), True),
+                                           ((2, 8, 6, 6), (60, 80), False), ((1, 4, 1, 1), (60, 80), False),
+                                           ((1, 5, 3, 3), (9, 7), False), ((1, 2, 240, 320), (480, 640), True)])
+def test_bilinear_resize_matches_torch(device, shape, size, ac):
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
+    want = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=ac)   # CPU ATen
+    got = ops.bilinear_resize(x.to(device), size, ac).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
