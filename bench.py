@@ -127,23 +127,19 @@ def cpu_baseline(args, sd):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus and world_env > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from ffb6d_amd import _lib, model, ops, pyramid, synth
+    from ffb6d_amd import _lib, distributed, model, ops, pyramid, synth
+    group = distributed.init_from_env(backend="nccl", device=dev)   # nccl == RCCL on ROCm
+    rank, world = group.rank, group.world
     _lib.load()
     idt = torch.int64 if args.index_dtype == "int64" else torch.int32
 
@@ -152,10 +148,9 @@ def main():
     net.load_state_dict(sd)
     net = net.to(dev).eval()
 
-    # per-rank batch, resident in HBM before the timed region (seeds 1000*2 + sample, offset by rank)
-    frames = synth.make_batch(2, args.batch, n_points=args.n_points)
-    if rank > 0:
-        frames = {k: np.roll(v, rank, axis=0) for k, v in frames.items()}
+    # per-rank batch, resident in HBM before the timed region: rank r holds samples
+    # [r*batch, (r+1)*batch) of the config-2 synthetic stream (seeds 1000*2 + sample)
+    frames = distributed.shard_frames(2, args.batch, rank, None, n_points=args.n_points)
     cpu_baseline.frames = frames
     rgb = torch.from_numpy(frames["rgb"]).to(dev).float()
     cld_rgb_nrm = torch.from_numpy(frames["cld_rgb_nrm"]).to(dev)
@@ -181,29 +176,20 @@ def main():
             phase["forward"].append((e1, e2))
         return out
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-
-        roof_op = "knn" if args.roofline_op == "auto" else args.roofline_op
-        tracer = _lib.Tracer([roof_op])
-        _lib.TRACER = tracer
+        # every hand-written op is bracketed by HIP events on its launch stream during the timed
+        # steps (two event records per launch; the GPU stays the bottleneck)
+        tracer = _lib.Tracer(None if args.roofline_op == "auto" else [args.roofline_op])
         marker = torch.zeros(4, dtype=torch.int32, device=dev)
-        if args.mark_region:
-            ops.check_index_range(marker, 1)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(record=True)
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
+
+        def one_step(timed):
+            if timed and _lib.TRACER is None:
+                if args.mark_region:
+                    ops.check_index_range(marker, 1)
+                _lib.TRACER = tracer
+            step(record=timed)
+
+        elapsed = distributed.timed_steps(one_step, args.warmup, args.steps, group, sync=torch.cuda.synchronize)
         _lib.TRACER = None
         if args.mark_region:
             ops.check_index_range(marker, 1)
@@ -219,31 +205,42 @@ def main():
             for name, r in sorted(full.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
                 print("%-24s %9d %10.3f %10.1f %10.1f" % (name, r["launches"], r["total_ms"], r["avg_us"], r["gbps"]),
                       file=sys.stderr)
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            print("--- by shape ---", file=sys.stderr)
+            for (name, tag), r in sorted(full.summary(by_tag=True).items(), key=lambda kv: -kv[1]["total_ms"])[:40]:
+                print("%-24s %-22s %5d %9.3f %9.1f %9.1f" % (name, str(tag), r["launches"], r["total_ms"], r["avg_us"],
+                                                            r["gbps"]), file=sys.stderr)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.batch * world * args.steps / elapsed
         pyr_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["pyramid"]]))
         fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["forward"]]))
-        summ = tracer.summary().get(roof_op)
+        summary = tracer.summary()
+        hbm_ops = {k: v for k, v in summary.items() if not k.startswith("knn") and v["launches"]}
+        roof_op = args.roofline_op if args.roofline_op != "auto" else \
+            (max(hbm_ops, key=lambda k: hbm_ops[k]["total_ms"]) if hbm_ops else None)
+        summ = summary.get(roof_op)
         roofline = None
         if summ and summ["launches"]:
             ach = summ["gbps"]
+            traffic = None
+            pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc_file):      # HBM bytes per launch measured offline with rocprofv3 --pmc
+                with open(pmc_file) as fh:
+                    traffic = json.load(fh).get(roof_op, {}).get("hbm_bytes_per_launch")
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": roof_op,
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": roof_op,
                         "launches_per_step": summ["launches"] / args.steps,
                         "avg_launch_us": summ["avg_us"],
+                        "algorithmic_bytes_per_launch": summ["bytes"] / summ["launches"],
                         "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
-            if roof_op == "knn":
-                # the brute-force KNN is VALU-bound, not HBM-bound: also report pairs/s
-                pairs = sum(tag[0] * tag[1] for _, _, _, tag in tracer.records[roof_op]) * args.batch
-                roofline["valu_gpairs_per_s"] = pairs / (summ["total_ms"] * 1e-3) / 1e9
-                roofline["valu_frac_of_fp32_peak"] = (pairs * 8 / (summ["total_ms"] * 1e-3)) / (VALU_PEAK_TFLOPS * 1e12)
+        ops_table = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["total_ms"] / args.steps,
+                         "algorithmic_GBps": v["gbps"]} for k, v in summary.items()}
+        if "knn" in summary:
+            # exact KNN is VALU/latency bound, not HBM bound: report brute-force-equivalent pairs/s
+            pairs = sum(tag[0] * tag[1] for _, _, _, tag in tracer.records["knn"]) * args.batch
+            sec = summary["knn"]["total_ms"] * 1e-3
+            ops_table["knn"]["bruteforce_equivalent_Gpairs_per_s"] = pairs / sec / 1e9
         line = {
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -256,15 +253,14 @@ def main():
             "breakdown_ms": {"knn_pyramid": pyr_ms, "forward": fwd_ms},
             "forward_only_fps": args.batch * world / (fwd_ms * 1e-3),
             "roofline": roofline,
+            "hot_path_ops": ops_table,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, sd)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

@@ -90,10 +90,15 @@ class Tracer:
     def wants(self, name):
         return self.names is None or name in self.names
 
-    def summary(self):
-        """name -> dict(launches, total_ms, avg_us, bytes, gbps); call after a device sync."""
-        out = {}
+    def summary(self, by_tag=False):
+        """name -> dict(launches, total_ms, avg_us, bytes, gbps); call after a device sync.
+        by_tag=True splits every op by its shape tag."""
+        groups = {}
         for name, recs in self.records.items():
+            for rec in recs:
+                groups.setdefault((name, rec[3]) if by_tag else name, []).append(rec)
+        out = {}
+        for name, recs in groups.items():
             ms = [s.elapsed_time(e) for s, e, _, _ in recs]
             nbytes = sum(b for _, _, b, _ in recs)
             tot = sum(ms)

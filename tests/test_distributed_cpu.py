@@ -1,0 +1,76 @@
+"""CPU suite: the multi-process harness of bench.py on the gloo backend, world_size 2
+(the GPU runs use the same code on nccl = RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import numpy as np
+    from ffb6d_amd import distributed as D, synth
+    g = D.init_from_env(backend="gloo")
+    frames = D.shard_frames(3, 2, g.rank, None, n_points=256, height=60, width=80)
+    calls = []
+    def step(timed):
+        calls.append(timed)
+        time.sleep(0.02 * (1 + g.rank))          # rank 1 is the slow one
+    elapsed = D.timed_steps(step, warmup=2, steps=3, group=g)
+    total = g.sum_over_ranks(float(frames["cld"].sum()))
+    out = dict(rank=g.rank, world=g.world, elapsed=elapsed, calls=calls,
+               first_seed_check=float(frames["cld"][0].sum()), total=total)
+    print("RESULT " + json.dumps(out), flush=True)
+    g.close()
+""") % ROOT
+
+
+def test_two_rank_gloo_harness(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs]
+    res.sort(key=lambda r: r["rank"])
+    assert [r["world"] for r in res] == [2, 2]
+    # exactly W untimed + K timed steps on every rank
+    assert all(r["calls"] == [False, False, True, True, True] for r in res)
+    # both ranks report the SAME elapsed = the slow rank's (max over ranks): 3 * 40 ms
+    assert abs(res[0]["elapsed"] - res[1]["elapsed"]) < 1e-9
+    assert res[0]["elapsed"] >= 3 * 0.04 * 0.9
+    # disjoint shards: rank r holds samples [2r, 2r+1] of config 3
+    from ffb6d_amd import synth
+    for r in res:
+        want = synth.make_frame(synth.frame_seed(3, 2 * r["rank"]), n_points=256, height=60, width=80)
+        assert abs(r["first_seed_check"] - float(want["cld"].sum())) < 1e-3
+    assert abs(res[0]["total"] - res[1]["total"]) < 1e-6   # SUM all-reduce agrees
+
+
+def test_single_process_group_is_a_noop():
+    from ffb6d_amd import distributed as D
+    g = D.Group()
+    g.barrier()
+    assert g.max_over_ranks(1.5) == 1.5 and g.sum_over_ranks(2.0) == 2.0
+    n = []
+    t = D.timed_steps(lambda timed: n.append(timed), warmup=1, steps=2, group=g)
+    assert n == [False, True, True] and t >= 0
