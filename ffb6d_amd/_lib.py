@@ -32,7 +32,12 @@ SIGNATURES = {
     "ffb6d_gather_neighbour_bwd_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_relative_pos_encoding_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_att_pool_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_att_pool2_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "ffb6d_relative_pos_encoding_cm_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_att_pool_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_shared_mlp_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i64, _vp, _i64,
+                                    _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
+    "ffb6d_shared_mlp_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "ffb6d_bilinear_resize_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_check_index_range": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
 }

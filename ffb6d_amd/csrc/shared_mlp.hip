@@ -1,0 +1,353 @@
+// ffb6d_amd/csrc/shared_mlp.hip -- the "shared MLP" of FFB6D / RandLA-Net as one fused fp32 MFMA
+// GEMM for gfx950.
+//
+// Reference: every 1x1 Conv + BatchNorm + activation wrapper on the path
+//   ffb6d/models/pytorch_utils.py:75-129        (pt_utils.Conv1d/Conv2d: conv -> BN(eps 1e-5) -> ReLU)
+//   ffb6d/models/RandLA/pytorch_utils.py:35-111 (conv -> BN(eps 1e-6) -> LeakyReLU(0.2))
+// and the tensor plumbing around them in FFB6D.forward (ffb6d.py:245-263,273-298,302-307):
+//   torch.cat((a, b), dim=1) -> conv            two K-ranges read from two tensors, no cat
+//   conv(cat(a, interp(b)))                     W_a*a + gather(W_b*b): the interpolated half is a
+//                                               column gather of a small pre-multiplied matrix
+//   leaky(mlp2(f) + shortcut(x))  (RandLANet.py:179-184)   one GEMM over K = [f ; x]
+//
+//   out[b, m, p] = act( sum_k Wt[k, m] * X[b, k, p]  + bias[m]  + Y[b, m, gidx[b, p]] )
+//
+// with X = [X1 ; X2] stacked along k.  Channel-major activations (the reference's layout) make
+// X a row-major K x P matrix per frame, so B-operand tiles are plain coalesced float4 row loads;
+// weights arrive pre-transposed ([K, Cout]) with eval-mode BatchNorm folded in.
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles, same peak as the fp32 vector rate, 157 TF;
+// there is no TF32/xf32 on gfx950).  Operand layout: lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; accumulator element r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+// Block = 256 threads = 4 waves, tile BM x 128 x 16; LDS tiles are k-major so a fragment read is
+// 32 consecutive floats per half-wave (conflict free: lanes l and l+32 may share a bank).
+#include "common.h"
+#include "ffb6d_ops.h"
+
+namespace ffb6d {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BLK = 256;
+constexpr int BN = 128;
+constexpr int BK = 16;
+
+struct MlpParams {
+    const float* wt;      // [K1+K2, Cout]
+    const float* bias;    // [Cout] or null
+    const float* x1;      // [B, K1, P]
+    const float* x2;      // [B, K2, P] or null
+    const float* yg;      // [B, Cout, Py] or null
+    const void* gidx;     // [B, P] int32/int64 or null
+    float* out;           // [B, Cout, P]
+    long long x1_bs, x2_bs, yg_bs, out_bs;
+    int k1, k2, cout, P, py, act, idx64;
+    // flat mode (small P): tile columns run over all frames, c = b*P + p; blockIdx.z = K split
+    int nb, kchunk;       // frames; k range per split (multiple of BK)
+    float* part;          // [nsplit, cout, nb*P] partial sums when nsplit > 1
+};
+
+__device__ __forceinline__ float activate(float v, int act)
+{
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v > 0.f ? v : 0.2f * v;
+    return v;
+}
+
+// WM x WN waves; each wave owns TM x TN MFMA tiles of 32x32
+template <int BM, bool FLAT>
+__global__ void __launch_bounds__(BLK)
+shared_mlp_kernel(const MlpParams p)
+{
+    constexpr int WM = BM == 128 ? 2 : 1;           // waves along M
+    constexpr int WN = 4 / WM;                       // waves along N
+    constexpr int TM = BM / (32 * WM);               // 32-row tiles per wave (128: 2, 64: 2, 32: 1)
+    constexpr int TN = BN / (32 * WN);               // 32-col tiles per wave (128: 2, 64: 1, 32: 1)
+    __shared__ __attribute__((aligned(16))) float As[BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int b = FLAT ? 0 : blockIdx.z;
+    const int m0 = blockIdx.y * BM;
+    const int p0 = blockIdx.x * BN;
+    const int K = p.k1 + p.k2;
+    const int kbeg = FLAT ? blockIdx.z * p.kchunk : 0;
+    const int kend = FLAT ? min(K, kbeg + p.kchunk) : K;
+    const int ncols = FLAT ? p.nb * p.P : p.P;          // columns of this launch's N dimension
+    const float* x1 = p.x1 + (size_t)b * p.x1_bs;
+    const float* x2 = p.x2 ? p.x2 + (size_t)b * p.x2_bs : nullptr;
+    // 16-byte loads only when every row start is 16-byte aligned
+    const bool vecP = (p.P & 3) == 0 && ((p.x1_bs | p.x2_bs) & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(p.x1) | reinterpret_cast<uintptr_t>(p.x2)) & 15) == 0;
+    const bool vecM = (p.cout & 3) == 0 && (reinterpret_cast<uintptr_t>(p.wt) & 15) == 0;
+
+    // global -> register staging: A tile BK x BM (rows = k, contiguous in m), B tile BK x BN
+    constexpr int A_F4 = BK * BM / 4 / BLK;          // float4 per thread (128: 2, 64: 1, 32: 0.5 -> handled)
+    constexpr int B_F4 = BK * BN / 4 / BLK;          // 2
+    float4 ra[A_F4 > 0 ? A_F4 : 1], rb[B_F4];
+
+    auto load_tiles = [&](int k0) {
+        // A
+        constexpr int A_TOTAL = BK * BM / 4;
+#pragma unroll
+        for (int i = 0; i < (A_F4 > 0 ? A_F4 : 1); ++i) {
+            const int f = tid + i * BLK;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < A_TOTAL) {
+                const int kr = f / (BM / 4), mc = (f % (BM / 4)) * 4;
+                const int k = k0 + kr, m = m0 + mc;
+                if (k < kend) {
+                    const float* src = p.wt + (size_t)k * p.cout + m;
+                    if (vecM && m + 3 < p.cout) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (m < p.cout) v.x = src[0];
+                        if (m + 1 < p.cout) v.y = src[1];
+                        if (m + 2 < p.cout) v.z = src[2];
+                        if (m + 3 < p.cout) v.w = src[3];
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+        // B
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int f = tid + i * BLK;
+            const int kr = f / (BN / 4), nc = (f % (BN / 4)) * 4;
+            const int k = k0 + kr;
+            int pp = p0 + nc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend) {
+                const float* row;
+                if constexpr (FLAT) {   // column -> (frame, p); P % 4 == 0 keeps a float4 inside one frame
+                    const int fb = pp / p.P;
+                    const int fp = pp - fb * p.P;
+                    row = (k < p.k1) ? p.x1 + (size_t)fb * p.x1_bs + (size_t)k * p.P
+                                     : p.x2 + (size_t)fb * p.x2_bs + (size_t)(k - p.k1) * p.P;
+                    if (pp + 3 < ncols) v = *reinterpret_cast<const float4*>(row + fp);
+                } else {
+                    row = (k < p.k1) ? x1 + (size_t)k * p.P : x2 + (size_t)(k - p.k1) * p.P;
+                    if (vecP && pp + 3 < p.P) {
+                        v = *reinterpret_cast<const float4*>(row + pp);
+                    } else {
+                        if (pp < p.P) v.x = row[pp];
+                        if (pp + 1 < p.P) v.y = row[pp + 1];
+                        if (pp + 2 < p.P) v.z = row[pp + 2];
+                        if (pp + 3 < p.P) v.w = row[pp + 3];
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+        constexpr int A_TOTAL = BK * BM / 4;
+#pragma unroll
+        for (int i = 0; i < (A_F4 > 0 ? A_F4 : 1); ++i) {
+            const int f = tid + i * BLK;
+            if (f < A_TOTAL) {
+                const int kr = f / (BM / 4), mc = (f % (BM / 4)) * 4;
+                *reinterpret_cast<float4*>(&As[kr][mc]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            const int f = tid + i * BLK;
+            const int kr = f / (BN / 4), nc = (f % (BN / 4)) * 4;
+            *reinterpret_cast<float4*>(&Bs[kr][nc]) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kh = lane >> 5;       // which of the 2 k of an MFMA this lane feeds
+    const int l31 = lane & 31;
+    const int am = wm * (TM * 32) + l31;
+    const int bn = wn * (TN * 32) + l31;
+
+    load_tiles(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();            // previous tile fully consumed
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK < kend) load_tiles(k0 + BK);   // next tile's HBM/L2 latency hides under the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], bb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[kk + kh][am + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bb[j] = Bs[kk + kh][bn + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: bias + gathered term + activation; for a fixed accumulator register the 32 lanes
+    // of a half-wave hold 32 consecutive p of one output row -> 128-byte coalesced stores
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = p0 + wn * (TN * 32) + j * 32 + l31;
+        if (col >= ncols) continue;
+        if (FLAT && p.part) {       // K is split: raw partial sums, reduced by shared_mlp_reduce_kernel
+            float* dst = p.part + (size_t)blockIdx.z * p.cout * ncols + col;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (m < p.cout) dst[(size_t)m * ncols] = acc[i][j][r];
+                }
+            continue;
+        }
+        const int fb = FLAT ? col / p.P : b;
+        const int pp = FLAT ? col - fb * p.P : col;
+        float* out = p.out + (size_t)fb * p.out_bs;
+        const float* yg = p.yg ? p.yg + (size_t)fb * p.yg_bs : nullptr;
+        long long gi = 0;
+        if (yg) {
+            gi = p.idx64 ? static_cast<const long long*>(p.gidx)[(size_t)fb * p.P + pp]
+                         : (long long)static_cast<const int*>(p.gidx)[(size_t)fb * p.P + pp];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < p.cout) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[m];
+                    if (yg) v += yg[(size_t)m * p.py + gi];
+                    out[(size_t)m * p.P + pp] = activate(v, p.act);
+                }
+            }
+        }
+    }
+}
+
+// sums the K-split partial slabs and applies the epilogue; one lane per output element
+__global__ void __launch_bounds__(BLK)
+shared_mlp_reduce_kernel(const MlpParams p, int nsplit)
+{
+    const size_t ncols = (size_t)p.nb * p.P;
+    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (t >= ncols * p.cout) return;
+    const int m = (int)(t / ncols);
+    const size_t col = t - (size_t)m * ncols;
+    float v = 0.f;
+    for (int z = 0; z < nsplit; ++z) v += p.part[((size_t)z * p.cout + m) * ncols + col];
+    const int fb = (int)(col / p.P);
+    const int pp = (int)(col - (size_t)fb * p.P);
+    if (p.bias) v += p.bias[m];
+    if (p.yg) {
+        const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[(size_t)fb * p.P + pp]
+                                     : (long long)static_cast<const int*>(p.gidx)[(size_t)fb * p.P + pp];
+        v += p.yg[(size_t)fb * p.yg_bs + (size_t)m * p.py + gi];
+    }
+    p.out[(size_t)fb * p.out_bs + (size_t)m * p.P + pp] = activate(v, p.act);
+}
+
+struct MlpPlan {
+    bool flat;
+    int nsplit, kchunk;
+};
+
+MlpPlan plan_mlp(int64_t B, int64_t cout, int64_t K, int64_t P)
+{
+    MlpPlan pl{false, 1, 0};
+    // small per-frame P: per-frame tiles would be mostly padding and too few to fill 256 CUs
+    if (P >= 2048 || (P & 3) != 0) return pl;
+    pl.flat = true;
+    const int64_t bm = cout > 64 ? 128 : (cout > 32 ? 64 : 32);
+    const int64_t blocks = ceil_div(B * P, BN) * ceil_div(cout, bm);
+    int64_t ns = ceil_div(512, blocks);                  // aim at ~2 blocks per CU
+    const int64_t max_by_k = K / 64 > 0 ? K / 64 : 1;    // keep >= 4 k-steps per split
+    if (ns > max_by_k) ns = max_by_k;
+    if (ns > 32) ns = 32;
+    if (ns < 1) ns = 1;
+    int64_t kc = ceil_div(ceil_div(K, ns), BK) * BK;
+    pl.nsplit = (int)ceil_div(K, kc);
+    pl.kchunk = (int)kc;
+    return pl;
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+using namespace ffb6d;
+
+extern "C" size_t ffb6d_shared_mlp_workspace_bytes(int64_t B, int64_t cout, int64_t K, int64_t P)
+{
+    if (B <= 0 || cout <= 0 || K <= 0 || P <= 0) return 0;
+    const MlpPlan pl = plan_mlp(B, cout, K, P);
+    return pl.nsplit > 1 ? (size_t)pl.nsplit * cout * B * P * sizeof(float) : 0;
+}
+
+extern "C" int ffb6d_shared_mlp_f32(const float* wt, const float* bias, const float* x1, int64_t k1,
+                                    int64_t x1_batch_stride, const float* x2, int64_t k2,
+                                    int64_t x2_batch_stride, const float* ygather, const void* gidx,
+                                    int idx_bits, int64_t py, int64_t yg_batch_stride, float* out,
+                                    int64_t out_batch_stride, int64_t B, int64_t cout, int64_t P, int act,
+                                    void* workspace, size_t workspace_bytes, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(B >= 0 && cout >= 1 && P >= 0 && k1 >= 1 && k2 >= 0, "shared_mlp: bad shape");
+    FFB6D_REQUIRE(act >= 0 && act <= 2, "shared_mlp: act must be 0 (none), 1 (relu) or 2 (leaky 0.2)");
+    FFB6D_REQUIRE(P < (1LL << 31) && cout < (1 << 20) && k1 + k2 < (1 << 20) && B < 65536, "shared_mlp: too large");
+    if (B == 0 || P == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(wt && x1 && out, "shared_mlp: null pointer");
+    FFB6D_REQUIRE((k2 == 0) == (x2 == nullptr), "shared_mlp: x2 and k2 must come together");
+    FFB6D_REQUIRE((ygather == nullptr) == (gidx == nullptr), "shared_mlp: gather term needs values and indices");
+    FFB6D_REQUIRE(!ygather || idx_bits == 32 || idx_bits == 64, "shared_mlp: idx_bits must be 32 or 64");
+    MlpParams p;
+    p.wt = wt; p.bias = bias; p.x1 = x1; p.x2 = x2; p.yg = ygather; p.gidx = gidx; p.out = out;
+    p.x1_bs = x1_batch_stride; p.x2_bs = x2_batch_stride; p.yg_bs = yg_batch_stride; p.out_bs = out_batch_stride;
+    p.k1 = (int)k1; p.k2 = (int)k2; p.cout = (int)cout; p.P = (int)P; p.py = (int)py; p.act = act;
+    p.idx64 = idx_bits == 64;
+    hipStream_t st = as_stream(stream);
+    MlpPlan pl = plan_mlp(B, cout, k1 + k2, P);
+    if (pl.flat && ((x1_batch_stride | x2_batch_stride) & 3 ||
+                    ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2)) & 15)))
+        pl = MlpPlan{false, 1, 0};            // flat mode needs 16-byte aligned rows
+    p.nb = (int)B; p.kchunk = pl.flat ? pl.kchunk : (int)(k1 + k2); p.part = nullptr;
+    if (pl.flat && pl.nsplit > 1) {
+        const size_t need = (size_t)pl.nsplit * cout * B * P * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return set_error(FFB6D_ERR_WORKSPACE, "shared_mlp: workspace of %zu bytes required, got %zu", need,
+                             workspace ? workspace_bytes : (size_t)0);
+        p.part = static_cast<float*>(workspace);
+    }
+    const unsigned gx = (unsigned)ceil_div(pl.flat ? B * P : P, BN);
+    const unsigned gz = pl.flat ? (unsigned)pl.nsplit : (unsigned)B;
+#define FFB6D_LAUNCH_MLP(BMV)                                                                              \
+    do {                                                                                                   \
+        const dim3 grid(gx, (unsigned)ceil_div(cout, BMV), gz);                                            \
+        if (pl.flat) hipLaunchKernelGGL((shared_mlp_kernel<BMV, true>), grid, dim3(BLK), 0, st, p);        \
+        else hipLaunchKernelGGL((shared_mlp_kernel<BMV, false>), grid, dim3(BLK), 0, st, p);               \
+    } while (0)
+    if (cout > 64) FFB6D_LAUNCH_MLP(128);
+    else if (cout > 32) FFB6D_LAUNCH_MLP(64);
+    else FFB6D_LAUNCH_MLP(32);
+#undef FFB6D_LAUNCH_MLP
+    FFB6D_LAUNCH_CHECK();
+    if (p.part) {
+        const size_t total = (size_t)B * P * cout;
+        hipLaunchKernelGGL(shared_mlp_reduce_kernel, dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, st, p,
+                           pl.nsplit);
+    }
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}

@@ -71,7 +71,8 @@ class SharedMLP(nn.Module):
         return F.leaky_relu_(y, 0.2) if self.flavour == "randla" else F.relu_(y)
 
     def folded(self):
-        """(W [Cout,Cin], b [Cout]) with eval-mode BatchNorm absorbed."""
+        """(Wt [Cin,Cout], b [Cout]): transposed weights with eval-mode BatchNorm absorbed --
+        the operand layout of ops.shared_mlp."""
         if self._folded is None:
             w = self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1)
             if self.has_bn:
@@ -81,8 +82,24 @@ class SharedMLP(nn.Module):
                 b = bn.bias.detach() - bn.running_mean * scale
             else:
                 b = self.conv.bias.detach()
-            self._folded = (w.contiguous(), b.contiguous())
+            self._folded = (w.t().contiguous(), b.contiguous())
         return self._folded
+
+    @property
+    def act_code(self):
+        return ops.ACT_NONE if not self.act else (ops.ACT_LEAKY if self.flavour == "randla" else ops.ACT_RELU)
+
+    def fused(self, x, x2=None):
+        """Inference: one fused MFMA GEMM = conv(cat(x, x2)) + folded BN + activation."""
+        wt, b = self.folded()
+        return ops.shared_mlp(x, wt, b, self.act_code, x2=x2)
+
+    def split(self, k1):
+        """(Wt_a [k1,Cout], Wt_b [Cin-k1,Cout], b) for conv(cat(a, gather(b))) == W_a a + gather(W_b b)."""
+        wt, b = self.folded()
+        if getattr(self, "_split", None) is None or self._split[0] is not wt:
+            self._split = (wt, wt[:k1].contiguous(), wt[k1:].contiguous())
+        return self._split[1], self._split[2], b
 
     def train(self, mode=True):
         self._folded = None
@@ -93,20 +110,18 @@ class SharedMLP(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
     def forward(self, x):
-        if self.training or torch.is_grad_enabled():   # autograd path: unfused conv -> BN -> act
+        if _autograd_path(x):   # unfused conv -> BN -> act (training, DDP, CPU)
             y = self.conv(x)
             if self.has_bn:
                 y = (self.bn if self.flavour == "randla" else self.normlayer)(y)
             return self.activation(y)
-        return self.activation(channel_gemm(x, *self.folded()))
+        return self.fused(x)
 
 
-def channel_gemm(x, w, b):
-    """y[b,:,p] = W @ x[b,:,p] + bias for a channel-major tensor [B,Cin,*spatial]."""
-    B, cin = x.shape[0], x.shape[1]
-    x3 = x.reshape(B, cin, -1)
-    y = torch.baddbmm(b.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), x3)
-    return y.view(B, w.shape[0], *x.shape[2:])
+def _autograd_path(x):
+    """True when the differentiable stock-torch path must be used instead of the fused
+    inference kernels (gradients enabled or not on a GPU)."""
+    return torch.is_grad_enabled() or not x.is_cuda
 
 
 # --------------------------------------------------------------------------------------
@@ -121,13 +136,17 @@ class AttPooling(nn.Module):
         self.mlp = SharedMLP(d_in, d_out)
 
     def forward(self, feature_set):
-        if self.training or torch.is_grad_enabled():
-            att = self.fc(feature_set)
-        else:
-            w = self.fc.weight.reshape(self.fc.weight.shape[0], -1)
-            B, C, N, K = feature_set.shape
-            att = torch.matmul(w, feature_set.reshape(B, C, N * K)).view(B, C, N, K)
+        att = self.fc(feature_set)
         return self.mlp(ops.att_pool(feature_set, att))
+
+    def fused(self, f_nei, f_xyz):
+        """Inference: feature_set = cat(f_nei, f_xyz) is never materialised -- the score GEMM
+        reads both halves as two K-ranges, the pooling kernel reads them as two channel blocks."""
+        w = self.fc.weight
+        if getattr(self, "_fct", None) is None or self._fct[0] is not w:
+            self._fct = (w, w.detach().reshape(w.shape[0], -1).t().contiguous())
+        att = ops.shared_mlp(f_nei, self._fct[1], None, ops.ACT_NONE, x2=f_xyz)
+        return self.mlp.fused(ops.att_pool2(f_nei, f_xyz, att))
 
 
 class BuildingBlock(nn.Module):
@@ -141,6 +160,8 @@ class BuildingBlock(nn.Module):
         self.att_pooling_2 = AttPooling(d_out, d_out)
 
     def forward(self, xyz, feature, neigh_idx):
+        if not _autograd_path(feature):
+            return self.fused(xyz, feature, neigh_idx)
         f_xyz = ops.relative_pos_encoding(xyz, neigh_idx).permute(0, 3, 1, 2).contiguous()
         f_xyz = self.mlp1(f_xyz)
         f_nei = ops.gather_neighbour(feature.squeeze(-1).transpose(1, 2).contiguous(), neigh_idx)
@@ -150,6 +171,18 @@ class BuildingBlock(nn.Module):
         f_nei = ops.gather_neighbour(f_agg.squeeze(-1).transpose(1, 2).contiguous(), neigh_idx)
         f_cat = torch.cat([f_nei.permute(0, 3, 1, 2), f_xyz], dim=1)
         return self.att_pooling_2(f_cat)
+
+
+    def fused(self, xyz, feature, neigh_idx):
+        """Inference path, channel-major throughout: no permute/contiguous/cat copies."""
+        B, N, K = neigh_idx.shape
+        flat_idx = neigh_idx.reshape(B, N * K, 1)
+        f_xyz = self.mlp1.fused(ops.relative_pos_encoding_cm(xyz, neigh_idx))            # [B,d/2,N,K]
+        f_nei = ops.nearest_interpolation(feature, flat_idx).view(B, -1, N, K)           # [B,d/2,N,K]
+        f_agg = self.att_pooling_1.fused(f_nei, f_xyz)                                   # [B,d/2,N,1]
+        f_xyz = self.mlp2.fused(f_xyz)
+        f_nei = ops.nearest_interpolation(f_agg, flat_idx).view(B, -1, N, K)
+        return self.att_pooling_2.fused(f_nei, f_xyz)
 
 
 class DilatedResBlock(nn.Module):
@@ -164,7 +197,14 @@ class DilatedResBlock(nn.Module):
 
     def forward(self, feature, xyz, neigh_idx):
         f = self.lfa(xyz, self.mlp1(feature), neigh_idx)
-        return F.leaky_relu(self.mlp2(f) + self.shortcut(feature), negative_slope=0.2)
+        if _autograd_path(feature):
+            return F.leaky_relu(self.mlp2(f) + self.shortcut(feature), negative_slope=0.2)
+        # leaky(mlp2(f) + shortcut(x)) as ONE GEMM over K = [f ; x] with summed biases
+        w2, b2 = self.mlp2.folded()
+        ws, bs = self.shortcut.folded()
+        if getattr(self, "_res", None) is None or self._res[0] is not w2 or self._res[1] is not ws:
+            self._res = (w2, ws, torch.cat([w2, ws], dim=0).contiguous(), (b2 + bs).contiguous())
+        return ops.shared_mlp(f, self._res[2], self._res[3], ops.ACT_LEAKY, x2=feature)
 
 
 # --------------------------------------------------------------------------------------
@@ -313,11 +353,30 @@ class FFB6D(nn.Module):
         """One bidirectional fusion step (ffb6d.py:245-263 / 281-298); both directions read
         the pre-fusion tensors, so they are independent."""
         bs, c, hr, wr = rgb_emb0.shape
-        p2r = ops.nearest_interpolation(pre_p2r[i](p_emb0), p2r_idx).view(bs, -1, hr, wr)
-        rgb_emb = fuse_p2r[i](torch.cat((rgb_emb0, p2r), dim=1))
-        r2p = ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx)
-        p_emb = fuse_r2p[i](torch.cat((p_emb0, pre_r2p[i](r2p)), dim=1))
+        if _autograd_path(rgb_emb0):
+            p2r = ops.nearest_interpolation(pre_p2r[i](p_emb0), p2r_idx).view(bs, -1, hr, wr)
+            rgb_emb = fuse_p2r[i](torch.cat((rgb_emb0, p2r), dim=1))
+            r2p = ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx)
+            p_emb = fuse_r2p[i](torch.cat((p_emb0, pre_r2p[i](r2p)), dim=1))
+            return rgb_emb, p_emb
+        # p2r: conv(cat(rgb0, interp(e))) = W_a rgb0 + gather(W_b e): the point half is multiplied at
+        # N' points instead of h*w pixels and enters the pixel GEMM's epilogue as a column gather
+        e = pre_p2r[i].fused(p_emb0)
+        wa, wb, bias = fuse_p2r[i].split(c)
+        y = ops.shared_mlp(e, wb, None, ops.ACT_NONE)
+        rgb_emb = ops.shared_mlp(rgb_emb0, wa, bias, fuse_p2r[i].act_code, gather=(y, p2r_idx))
+        # r2p: max-pool the 16 nearest pixels, then conv(cat(p0, pre(.))) as a two-source GEMM
+        r2p = pre_r2p[i].fused(ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx))
+        p_emb = fuse_r2p[i].fused(p_emb0, x2=r2p)
         return rgb_emb, p_emb
+
+    def _decode(self, stage, skip, p_emb, interp_idx):
+        """RandLA decoder step conv(cat(skip, interp(p))) (ffb6d.py:273-279,302-307)."""
+        if _autograd_path(skip):
+            return stage(torch.cat([skip, ops.nearest_interpolation(p_emb, interp_idx)], dim=1))
+        wa, wb, bias = stage.split(skip.shape[1])
+        y = ops.shared_mlp(p_emb, wb, None, ops.ACT_NONE)
+        return ops.shared_mlp(skip, wa, bias, stage.act_code, gather=(y, interp_idx))
 
     def forward(self, inputs, end_points=None, scale=1):
         if not end_points:
@@ -341,24 +400,31 @@ class FFB6D(nn.Module):
         n_up = len(self.rndla_up_stages)
         for i in range(n_up - 1):
             rgb_emb0 = self.cnn_up_stages[i](rgb_emb)
-            f_interp = ops.nearest_interpolation(p_emb, inputs['cld_interp_idx%d' % (n_up - i - 1)])
-            p_emb0 = self.rndla_up_stages[i](torch.cat([ds_emb[-i - 2], f_interp], dim=1))
+            p_emb0 = self._decode(self.rndla_up_stages[i], ds_emb[-i - 2], p_emb,
+                                  inputs['cld_interp_idx%d' % (n_up - i - 1)])
             rgb_emb, p_emb = self._fuse(
                 i, self.up_fuse_p2r_pre_layers, self.up_fuse_p2r_fuse_layers,
                 self.up_fuse_r2p_pre_layers, self.up_fuse_r2p_fuse_layers, rgb_emb0, p_emb0,
                 inputs['p2r_up_nei_idx%d' % i], inputs['r2p_up_nei_idx%d' % i])
 
         rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
-        f_interp = ops.nearest_interpolation(p_emb, inputs['cld_interp_idx0'])
-        p_emb = self.rndla_up_stages[n_up - 1](torch.cat([ds_emb[0], f_interp], dim=1)).squeeze(-1)
+        p_emb = self._decode(self.rndla_up_stages[n_up - 1], ds_emb[0], p_emb,
+                             inputs['cld_interp_idx0']).squeeze(-1)
 
         bs = rgb_emb.shape[0]
         rgb_emb_c = ops.choose_gather(rgb_emb, inputs['choose'])
-        rgbd_emb = torch.cat([rgb_emb_c, p_emb], dim=1)
 
-        end_points['pred_rgbd_segs'] = self.rgbd_seg_layer(rgbd_emb)
-        end_points['pred_kp_ofs'] = self.kp_ofst_layer(rgbd_emb).view(
+        def head(seq):
+            if _autograd_path(p_emb):
+                return seq(torch.cat([rgb_emb_c, p_emb], dim=1))
+            y = seq[0].fused(rgb_emb_c, x2=p_emb)          # cat(rgb_c, p_emb) as two K-ranges
+            for layer in list(seq)[1:]:
+                y = layer.fused(y)
+            return y
+
+        end_points['pred_rgbd_segs'] = head(self.rgbd_seg_layer)
+        end_points['pred_kp_ofs'] = head(self.kp_ofst_layer).view(
             bs, self.n_kps, 3, -1).permute(0, 1, 3, 2).contiguous()
-        end_points['pred_ctr_ofs'] = self.ctr_ofst_layer(rgbd_emb).view(
+        end_points['pred_ctr_ofs'] = head(self.ctr_ofst_layer).view(
             bs, 1, 3, -1).permute(0, 1, 3, 2).contiguous()
         return end_points

@@ -207,6 +207,43 @@ def relative_pos_encoding(xyz, neigh_idx):
     return out
 
 
+def relative_pos_encoding_cm(xyz, neigh_idx):
+    """Channel-major position encoding [B,10,N,K] (= relative_pos_encoding(...).permute(0,3,1,2),
+    RandLANet.py:197-198) written directly in that layout."""
+    _need_gpu(xyz, neigh_idx)
+    lib = _lib.load()
+    xyz_c = _f32(xyz.detach())
+    idx, bits = _idx(neigh_idx)
+    B, N, _ = xyz_c.shape
+    K = idx.shape[2]
+    out = torch.empty((B, 10, N, K), dtype=torch.float32, device=xyz.device)
+    nbytes = 12 * B * N + (bits // 8) * B * N * K + 40 * B * N * K
+    with torch.cuda.device(xyz.device), _lib.traced("relative_pos_encoding", nbytes, (N,)):
+        rc = lib.ffb6d_relative_pos_encoding_cm_f32(xyz_c.data_ptr(), idx.data_ptr(), bits, out.data_ptr(),
+                                                    B, N, K, _stream(xyz_c))
+    _lib.check(rc, "ffb6d_relative_pos_encoding_cm_f32")
+    return out
+
+
+def att_pool2(feat1, feat2, att_activation):
+    """att_pool(cat(feat1, feat2, dim=1), att_activation) without the cat (inference only).
+    feat1 [B,C1,N,K], feat2 [B,C2,N,K], att_activation [B,C1+C2,N,K] -> [B,C1+C2,N,1]."""
+    _need_gpu(feat1, feat2, att_activation)
+    lib = _lib.load()
+    f1, f2, a = _f32(feat1.detach()), _f32(feat2.detach()), _f32(att_activation.detach())
+    B, C1, N, K = f1.shape
+    C2 = f2.shape[1]
+    if f2.shape != (B, C2, N, K) or a.shape != (B, C1 + C2, N, K):
+        raise ValueError(f"bad shapes {tuple(f1.shape)} / {tuple(f2.shape)} / {tuple(a.shape)}")
+    out = torch.empty((B, C1 + C2, N), dtype=torch.float32, device=f1.device)
+    nbytes = 2 * 4 * B * (C1 + C2) * N * K + 4 * B * (C1 + C2) * N
+    with torch.cuda.device(f1.device), _lib.traced("att_pool", nbytes, (C1 + C2, N)):
+        rc = lib.ffb6d_att_pool2_f32(f1.data_ptr(), C1, f2.data_ptr(), C2, a.data_ptr(), out.data_ptr(),
+                                     B, N, K, _stream(f1))
+    _lib.check(rc, "ffb6d_att_pool2_f32")
+    return out.unsqueeze(3)
+
+
 class _AttPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feature_set, att_activation):
@@ -244,6 +281,66 @@ def att_pool(feature_set, att_activation):
     if feature_set.shape != att_activation.shape or feature_set.dim() != 4:
         raise ValueError(f"bad shapes {tuple(feature_set.shape)} / {tuple(att_activation.shape)}")
     return _AttPool.apply(_f32(feature_set), _f32(att_activation)).unsqueeze(3)
+
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _rows(x):
+    """[B,K,*spatial] -> (tensor viewed as [B,K,P] with contiguous rows, batch stride in floats)."""
+    B, K = x.shape[0], x.shape[1]
+    x3 = x.reshape(B, K, -1)
+    if x3.stride(2) != 1 or (K > 1 and x3.stride(1) != x3.shape[2]) or x3.data_ptr() % 16 or x3.stride(0) % 4:
+        x3 = x3.contiguous()
+    return x3, x3.stride(0)
+
+
+def shared_mlp(x1, wt, bias=None, act=ACT_NONE, x2=None, gather=None):
+    """Fused shared MLP on channel-major activations (inference only, no autograd):
+
+        out[b,:,p] = act( wt.T @ cat(x1, x2)[b,:,p] + bias + Y[b,:,idx[b,p]] )
+
+    x1 [B,K1,*S], x2 [B,K2,*S] or None, wt [K1+K2, Cout] (transposed, BatchNorm folded),
+    bias [Cout] or None, gather = (Y [B,Cout,Py], idx [B,P] int32/int64) or None.
+    Returns [B,Cout,*S]."""
+    _need_gpu(x1, wt)
+    lib = _lib.load()
+    if x1.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
+        raise TypeError("float32 expected")
+    a, a_bs = _rows(x1.detach())
+    B, K1, P = a.shape
+    K2 = 0
+    b3, b_bs = None, 0
+    if x2 is not None:
+        b3, b_bs = _rows(x2.detach())
+        if b3.shape[0] != B or b3.shape[2] != P:
+            raise ValueError(f"x2 {tuple(x2.shape)} does not match x1 {tuple(x1.shape)}")
+        K2 = b3.shape[1]
+    if wt.dim() != 2 or wt.shape[0] != K1 + K2 or not wt.is_contiguous() or wt.dtype != torch.float32:
+        raise ValueError(f"wt must be contiguous float32 [{K1 + K2}, Cout], got {tuple(wt.shape)}")
+    Cout = wt.shape[1]
+    y = gi = None
+    py = ybs = bits = 0
+    if gather is not None:
+        y, gi = gather
+        y = _f32(y.detach()).reshape(B, Cout, -1)
+        gi, bits = _idx(gi.reshape(B, -1))
+        if gi.shape[1] != P:
+            raise ValueError("gather index must have one entry per output column")
+        py, ybs = y.shape[2], y.stride(0)
+    out = torch.empty((B, Cout, P), dtype=torch.float32, device=x1.device)
+    wbytes = lib.ffb6d_shared_mlp_workspace_bytes(B, Cout, K1 + K2, P)
+    ws = torch.empty((wbytes,), dtype=torch.uint8, device=x1.device) if wbytes else None
+    nbytes = 4 * ((K1 + K2) * Cout + B * (K1 + K2) * P + B * Cout * P) + (B * P * bits // 8 + 4 * B * Cout * py if y is not None else 0)
+    with torch.cuda.device(x1.device), _lib.traced("shared_mlp", nbytes, (K1 + K2, Cout, P)):
+        rc = lib.ffb6d_shared_mlp_f32(
+            wt.data_ptr(), bias.data_ptr() if bias is not None else None,
+            a.data_ptr(), K1, a_bs, b3.data_ptr() if b3 is not None else None, K2, b_bs,
+            y.data_ptr() if y is not None else None, gi.data_ptr() if gi is not None else None, bits, py, ybs,
+            out.data_ptr(), out.stride(0), B, Cout, P, int(act),
+            ws.data_ptr() if ws is not None else None, wbytes, _stream(x1))
+    _lib.check(rc, "ffb6d_shared_mlp_f32")
+    return out.view(B, Cout, *x1.shape[2:])
 
 
 def bilinear_resize(x, size, align_corners):

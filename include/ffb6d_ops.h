@@ -75,10 +75,39 @@ int ffb6d_relative_pos_encoding_f32(const float* xyz, const void* idx, int idx_b
 int ffb6d_att_pool_f32(const float* feat, const float* act, float* out,
                        int64_t B, int64_t C, int64_t N, int K, ffb6d_stream_t stream);
 
+/* Same pooling with the feature set given as two channel blocks, cat(feat1 [B,C1,N,K], feat2 [B,C2,N,K])
+ * (RandLANet.py:204,212) without materialising the concatenation; act [B,C1+C2,N,K], out [B,C1+C2,N]. */
+int ffb6d_att_pool2_f32(const float* feat1, int64_t C1, const float* feat2, int64_t C2, const float* act,
+                        float* out, int64_t B, int64_t N, int K, ffb6d_stream_t stream);
+
+/* relative_pos_encoding written channel-major: out [B,10,N,K] (what RandLANet.py:198 permutes to). */
+int ffb6d_relative_pos_encoding_cm_f32(const float* xyz, const void* idx, int idx_bits, float* out,
+                                       int64_t B, int64_t N, int K, ffb6d_stream_t stream);
+
 /* grad_feat = g*s ; grad_act = g*s*(feat - out)  with g = grad_out[b,c,n] broadcast over k */
 int ffb6d_att_pool_bwd_f32(const float* grad_out, const float* feat, const float* act,
                            float* grad_feat, float* grad_act,
                            int64_t B, int64_t C, int64_t N, int K, ffb6d_stream_t stream);
+
+/* Fused shared MLP (1x1 conv + folded BatchNorm + activation, pytorch_utils.py:75-129 and
+ * RandLA/pytorch_utils.py:35-111) on channel-major activations, fp32 MFMA:
+ *   out[b,m,p] = act( sum_k wt[k,m] * X[b,k,p] + bias[m] + ygather[b,m,gidx[b,p]] )
+ * X = [x1 ; x2] stacked along k (replaces torch.cat(dim=1) in front of a conv, ffb6d.py:252,261,277);
+ * ygather/gidx (both or neither) add a column gather of a pre-multiplied matrix: conv(cat(a,
+ * interp(b))) == W_a*a + gather(W_b*b) (ffb6d.py:247-253,273-279,283-289).
+ * wt [k1+k2, cout] (transposed weights, BN folded), bias [cout] or NULL, x1 [B,k1,P] / x2 [B,k2,P]
+ * with the given batch strides (in floats; rows contiguous), ygather [B,cout,py], gidx [B,P]
+ * (idx_bits 32/64), out [B,cout,P].  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).
+ * workspace: ffb6d_shared_mlp_workspace_bytes(...) bytes of device scratch (may be NULL when 0). */
+int ffb6d_shared_mlp_f32(const float* wt, const float* bias, const float* x1, int64_t k1,
+                         int64_t x1_batch_stride, const float* x2, int64_t k2, int64_t x2_batch_stride,
+                         const float* ygather, const void* gidx, int idx_bits, int64_t py,
+                         int64_t yg_batch_stride, float* out, int64_t out_batch_stride, int64_t B,
+                         int64_t cout, int64_t P, int act, void* workspace, size_t workspace_bytes,
+                         ffb6d_stream_t stream);
+/* Scratch for ffb6d_shared_mlp_f32 with K = k1 + k2 (non-zero only for small per-frame P, where the
+ * K loop is split across workgroups and reduced by a second kernel). */
+size_t ffb6d_shared_mlp_workspace_bytes(int64_t B, int64_t cout, int64_t K, int64_t P);
 
 /* Bilinear resize of `planes` = B*C independent [IH,IW] float32 images to [OH,OW], the two
  * flavours the colour branch uses: align_corners = 0 (F.upsample(size=...), pspnet.py:24-28) and

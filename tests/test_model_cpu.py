@@ -51,9 +51,13 @@ def test_batchnorm_folding_is_exact_algebra(flavour, dims):
     x = torch.randn(3, 12, 50) if dims == 1 else torch.randn(3, 12, 50, 4)
     with torch.enable_grad():
         want = mlp(x.clone())                 # unfused conv -> BN -> act
-    with torch.no_grad():
-        got = mlp(x.clone())                  # folded GEMM
-    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    wt, b = mlp.folded()                      # what the fused GPU kernel consumes: [Cin,Cout], [Cout]
+    assert wt.shape == (12, 7) and b.shape == (7,)
+    y = torch.einsum("km,bkp->bmp", wt, x.reshape(3, 12, -1)) + b.view(1, -1, 1)
+    y = torch.nn.functional.leaky_relu(y, 0.2) if flavour == "randla" else torch.relu(y)
+    torch.testing.assert_close(y.view_as(want), want, rtol=1e-5, atol=1e-5)
+    wa, wb, b2 = mlp.split(5)
+    assert torch.equal(torch.cat([wa, wb]), wt) and b2 is b
     mlp.train()
     assert mlp._folded is None
 

@@ -144,3 +144,67 @@ def test_bilinear_resize_matches_torch(device, shape, size, ac):
     want = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=ac)   # CPU ATen
     got = ops.bilinear_resize(x.to(device), size, ac).cpu()
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def _mlp_ref(x1, w, bias, act, x2=None, gather=None):
+    x = x1 if x2 is None else torch.cat([x1, x2], dim=1)
+    B, K = x.shape[:2]
+    y = torch.einsum("km,bkp->bmp", w.double(), x.reshape(B, K, -1).double())
+    if bias is not None:
+        y = y + bias.double().view(1, -1, 1)
+    if gather is not None:
+        Y, idx = gather
+        y = y + torch.gather(Y.double(), 2, idx.long().unsqueeze(1).expand(-1, Y.shape[1], -1))
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = torch.nn.functional.leaky_relu(y, 0.2)
+    return y.float()
+
+
+# (B, K1, K2, Cout, P, act, gather) -- shapes of FFB6D's shared MLPs incl. ragged ones
+@pytest.mark.parametrize("B,K1,K2,Cout,P,act,py", [
+    (2, 9, 0, 8, 12288, 2, 0), (1, 10, 0, 16, 3072 * 16, 2, 0), (2, 32, 0, 32, 768 * 16, 0, 0),
+    (2, 64, 64, 64, 3072, 1, 0), (1, 1024, 0, 1024, 4800, 1, 48), (2, 128, 0, 64, 4800, 1, 768),
+    (1, 256, 512, 256, 192, 2, 0), (1, 128, 0, 22, 12288, 0, 0), (3, 17, 5, 37, 301, 1, 13),
+    (1, 2048, 0, 1024, 640, 1, 0), (2, 128, 0, 128, 130, 2, 0),
+    # small per-frame P: flat columns over frames + split-K partial slabs
+    (8, 1024, 0, 512, 48, 1, 0), (8, 512, 512, 256, 192, 2, 0), (8, 256, 0, 256, 192, 1, 48),
+    (4, 128, 0, 22, 768, 0, 0), (2, 48, 16, 40, 1024, 1, 100),
+])
+def test_shared_mlp_matches_fp64_reference(device, B, K1, K2, Cout, P, act, py):
+    g = torch.Generator().manual_seed(K1 + Cout + P)
+    x1 = torch.randn(B, K1, P, generator=g)
+    x2 = torch.randn(B, K2, P, generator=g) if K2 else None
+    w = torch.randn(K1 + K2, Cout, generator=g) / (K1 + K2) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    gather = (torch.randn(B, Cout, py, generator=g), torch.randint(0, py, (B, P), generator=g)) if py else None
+    want = _mlp_ref(x1, w, bias, act, x2, gather)
+    d = lambda t: None if t is None else t.to(device)
+    got = ops.shared_mlp(d(x1), d(w), d(bias), act, x2=d(x2),
+                         gather=None if gather is None else (d(gather[0]), d(gather[1]))).cpu()
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_shared_mlp_4d_views_and_channel_slices(device):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 48, 100, 16, generator=g).to(device)        # [B,C,N,K] like the LFA tensors
+    w = (torch.randn(16, 24, generator=g) / 4).to(device)
+    got = ops.shared_mlp(x[:, 16:32], w, None, ops.ACT_LEAKY)       # channel slice, batch stride != K*P
+    want = _mlp_ref(x[:, 16:32].cpu(), w.cpu(), None, 2).view(2, 24, 100, 16)
+    assert got.shape == (2, 24, 100, 16)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_channel_major_variants_match_the_reference_layout_ops(device):
+    g = torch.Generator().manual_seed(12)
+    xyz = (torch.rand(2, 300, 3, generator=g) * 2 - 1).to(device)
+    idx = torch.randint(0, 300, (2, 300, 16), generator=g).to(device)
+    a = ops.relative_pos_encoding_cm(xyz, idx)
+    b = ops.relative_pos_encoding(xyz, idx).permute(0, 3, 1, 2).contiguous()
+    assert torch.equal(a, b)
+    f1 = torch.randn(2, 8, 77, 16, generator=g).to(device)
+    f2 = torch.randn(2, 24, 77, 16, generator=g).to(device)
+    act = (3 * torch.randn(2, 32, 77, 16, generator=g)).to(device)
+    assert torch.equal(ops.att_pool2(f1, f2, act), ops.att_pool(torch.cat([f1, f2], 1), act))
