@@ -161,3 +161,61 @@ extern "C" int ffb6d_bilinear_resize_f32(const float* in, float* out, int64_t pl
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Per-channel affine + residual + activation on NCHW maps: the eval-mode BatchNorm / ReLU / PReLU /
+// residual-add glue between the colour branch's convolutions (extractors.py:49-63 BasicBlock,
+// pspnet.py:34-45 PSPUpsample, ffb6d.py:30-34 stem) as ONE pass instead of up to five:
+//     out = act( scale[c]*x + shift[c] + (res ? rscale[c]*res + rshift[c] : 0) )
+// ------------------------------------------------------------------------------------------
+namespace ffb6d {
+namespace {
+
+__global__ void __launch_bounds__(256)
+affine_act_kernel(const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                  const float4* __restrict__ res, const float* __restrict__ rscale,
+                  const float* __restrict__ rshift, float4* __restrict__ out, int C, int hw4, size_t total4,
+                  int act, float slope)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const int c = (int)((t / hw4) % C);
+    const float s = scale[c], b = shift[c];
+    float4 v = x[t];
+    v.x = v.x * s + b; v.y = v.y * s + b; v.z = v.z * s + b; v.w = v.w * s + b;
+    if (res) {
+        const float4 r = res[t];
+        const float rs = rscale ? rscale[c] : 1.f, rb = rshift ? rshift[c] : 0.f;
+        v.x += r.x * rs + rb; v.y += r.y * rs + rb; v.z += r.z * rs + rb; v.w += r.w * rs + rb;
+    }
+    if (act == 1) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if (act == 2) {
+        v.x = v.x > 0.f ? v.x : slope * v.x; v.y = v.y > 0.f ? v.y : slope * v.y;
+        v.z = v.z > 0.f ? v.z : slope * v.z; v.w = v.w > 0.f ? v.w : slope * v.w;
+    }
+    out[t] = v;
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+extern "C" int ffb6d_affine_act_f32(const float* x, const float* scale, const float* shift, const float* res,
+                                    const float* rscale, const float* rshift, float* out, int64_t B, int64_t C,
+                                    int64_t HW, int act, float slope, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(B >= 0 && C >= 1 && HW >= 0, "affine_act: bad shape");
+    FFB6D_REQUIRE(act >= 0 && act <= 2, "affine_act: act must be 0 (none), 1 (relu) or 2 (leaky/prelu with slope)");
+    if (B == 0 || HW == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(x && scale && shift && out, "affine_act: null pointer");
+    FFB6D_REQUIRE(HW % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
+                                   reinterpret_cast<uintptr_t>(res)) & 15) == 0,
+                  "affine_act: H*W must be a multiple of 4 and the maps 16-byte aligned");
+    const size_t total4 = (size_t)B * C * (HW / 4);
+    hipLaunchKernelGGL(ffb6d::affine_act_kernel, dim3((unsigned)ffb6d::ceil_div((int64_t)total4, 256)), dim3(256), 0,
+                       ffb6d::as_stream(stream), reinterpret_cast<const float4*>(x), scale, shift,
+                       reinterpret_cast<const float4*>(res), rscale, rshift, reinterpret_cast<float4*>(out), (int)C,
+                       (int)(HW / 4), total4, act, slope);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}

@@ -224,11 +224,19 @@ class ResBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        y = F.relu_(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
+        if _autograd_path(x) or (x.shape[2] * x.shape[3]) % 4:
+            y = F.relu_(self.bn1(self.conv1(x)))
+            y = self.bn2(self.conv2(y))
+            if self.downsample is not None:
+                x = self.downsample(x)
+            return F.relu_(y + x)
+        # inference: BN+ReLU and BN+add(+BN of the projection)+ReLU as one pass each
+        y = ops.affine_act_(self.conv1(x), *ops.bn_fold(self.bn1), act=ops.ACT_RELU)
+        y = self.conv2(y)
         if self.downsample is not None:
-            x = self.downsample(x)
-        return F.relu_(y + x)
+            return ops.affine_act_(y, *ops.bn_fold(self.bn2), act=ops.ACT_RELU, residual=self.downsample[0](x),
+                                   res_affine=ops.bn_fold(self.downsample[1]))
+        return ops.affine_act_(y, *ops.bn_fold(self.bn2), act=ops.ACT_RELU, residual=x)
 
 
 def res_layer(cin, cout, blocks, stride):
@@ -269,7 +277,13 @@ class UpBlock(nn.Module):
         if torch.is_grad_enabled() or not x.is_cuda:
             return self.conv(x)
         y = ops.bilinear_resize(x, (2 * x.shape[2], 2 * x.shape[3]), align_corners=True)
-        return self.conv[3](self.conv[2](self.conv[1](y)))
+        y = self.conv[1](y)
+        prelu = self.conv[3]
+        if prelu.weight.numel() != 1 or (y.shape[2] * y.shape[3]) % 4:
+            return prelu(self.conv[2](y))
+        if getattr(self, "_slope", None) is None or self._slope[0] != prelu.weight._version:
+            self._slope = (prelu.weight._version, float(prelu.weight.detach().item()))
+        return ops.affine_act_(y, *ops.bn_fold(self.conv[2]), act=ops.ACT_LEAKY, slope=self._slope[1])
 
 
 def _head(cin, cout):
@@ -345,6 +359,15 @@ class FFB6D(nn.Module):
         self.ctr_ofst_layer = _head(c, 3)
         self.kp_ofst_layer = _head(c, n_kps * 3)
 
+    def train(self, mode=True):
+        # drop every cached inference-time fold (BatchNorm scale/shift, split weights): they are
+        # also version-checked, this covers edits made through `.data`
+        for m in self.modules():
+            for attr in ("_ffb6d_fold", "_split", "_res", "_fct", "_slope"):
+                if hasattr(m, attr):
+                    setattr(m, attr, None)
+        return super().train(mode)
+
     # the reference exposes these two as static methods of the model (ffb6d.py:159-194)
     random_sample = staticmethod(ops.random_sample)
     nearest_interpolation = staticmethod(ops.nearest_interpolation)
@@ -381,7 +404,12 @@ class FFB6D(nn.Module):
     def forward(self, inputs, end_points=None, scale=1):
         if not end_points:
             end_points = {}
-        rgb_emb = self.cnn_pre_stages(inputs['rgb'])
+        if _autograd_path(inputs['rgb']) or (inputs['rgb'].shape[2] * inputs['rgb'].shape[3]) % 16:
+            rgb_emb = self.cnn_pre_stages(inputs['rgb'])
+        else:   # stem: conv7x7 -> [BN+ReLU in one pass] -> maxpool
+            y = ops.affine_act_(self.cnn_pre_stages[0](inputs['rgb']), *ops.bn_fold(self.cnn_pre_stages[1]),
+                                act=ops.ACT_RELU)
+            rgb_emb = self.cnn_pre_stages[3](y)
         p_emb = self.rndla_pre_stages(inputs['cld_rgb_nrm']).unsqueeze(3)
 
         ds_emb = []

@@ -363,6 +363,48 @@ def bilinear_resize(x, size, align_corners):
     return out
 
 
+def bn_fold(bn):
+    """(scale, shift) of an eval-mode BatchNorm: y = scale*x + shift.  Cached on the module and
+    recomputed whenever one of its tensors was modified in place (load_state_dict, training)."""
+    ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.device)
+    cache = getattr(bn, "_ffb6d_fold", None)
+    if cache is None or cache[0] != ver:
+        with torch.no_grad():
+            scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+            shift = (bn.bias - bn.running_mean * scale).contiguous()
+        cache = (ver, scale, shift)
+        bn._ffb6d_fold = cache
+    return cache[1], cache[2]
+
+
+def affine_act_(x, scale, shift, act=ACT_NONE, slope=0.0, residual=None, res_affine=None):
+    """In-place per-channel affine + optional (affine) residual + activation on [B,C,H,W]
+    (inference only): x <- act(scale*x + shift + res_scale*residual + res_shift)."""
+    _need_gpu(x)
+    lib = _lib.load()
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise ValueError("affine_act_ needs a contiguous float32 tensor")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    r = rs = rb = None
+    if residual is not None:
+        r = _f32(residual)
+        if r.shape != x.shape:
+            raise ValueError("residual shape mismatch")
+        if res_affine is not None:
+            rs, rb = res_affine
+    nbytes = 4 * x.numel() * (3 if r is not None else 2)
+    with torch.cuda.device(x.device), _lib.traced("affine_act", nbytes, (C, HW)):
+        rc = lib.ffb6d_affine_act_f32(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                      r.data_ptr() if r is not None else None,
+                                      rs.data_ptr() if rs is not None else None,
+                                      rb.data_ptr() if rb is not None else None,
+                                      x.data_ptr(), B, C, HW, int(act), float(slope), _stream(x))
+    _lib.check(rc, "ffb6d_affine_act_f32")
+    return x
+
+
 def check_index_range(idx, M):
     """Number of entries of `idx` outside [0, M) (debug aid; the kernels do not bounds-check)."""
     _need_gpu(idx)

@@ -116,6 +116,14 @@ size_t ffb6d_shared_mlp_workspace_bytes(int64_t B, int64_t cout, int64_t K, int6
 int ffb6d_bilinear_resize_f32(const float* in, float* out, int64_t planes, int64_t IH, int64_t IW,
                               int64_t OH, int64_t OW, int align_corners, ffb6d_stream_t stream);
 
+/* Per-channel affine (+ affine residual) + activation on [B,C,HW] maps, in place allowed:
+ *   out = act(scale[c]*x + shift[c] + (res ? rscale[c]*res + rshift[c] : 0));  rscale/rshift NULL = 1/0.
+ * The eval-mode BatchNorm + ReLU/PReLU + residual-add glue of the colour branch (extractors.py:49-63,
+ * pspnet.py:34-45) in one pass.  act: 0 none, 1 ReLU, 2 leaky/PReLU with `slope`.  HW % 4 == 0. */
+int ffb6d_affine_act_f32(const float* x, const float* scale, const float* shift, const float* res,
+                         const float* rscale, const float* rshift, float* out, int64_t B, int64_t C,
+                         int64_t HW, int act, float slope, ffb6d_stream_t stream);
+
 /* Debug helper: number of entries of idx[0:count] outside [0, M) written to *bad (device int32). */
 int ffb6d_check_index_range(const void* idx, int idx_bits, int64_t count, int64_t M,
                             int32_t* bad, ffb6d_stream_t stream);

@@ -208,3 +208,26 @@ def test_channel_major_variants_match_the_reference_layout_ops(device):
     f2 = torch.randn(2, 24, 77, 16, generator=g).to(device)
     act = (3 * torch.randn(2, 32, 77, 16, generator=g)).to(device)
     assert torch.equal(ops.att_pool2(f1, f2, act), ops.att_pool(torch.cat([f1, f2], 1), act))
+
+
+def test_affine_act_matches_bn_relu_add(device):
+    g = torch.Generator().manual_seed(3)
+    bn = torch.nn.BatchNorm2d(6).eval()
+    bn2 = torch.nn.BatchNorm2d(6).eval()
+    for m in (bn, bn2):
+        m.weight.data.uniform_(0.5, 1.5, generator=g); m.bias.data.normal_(generator=g)
+        m.running_mean.normal_(generator=g); m.running_var.uniform_(0.5, 2, generator=g)
+    x = torch.randn(2, 6, 10, 12, generator=g)
+    r = torch.randn(2, 6, 10, 12, generator=g)
+    want = torch.relu(bn(x) + bn2(r))
+    bn, bn2 = bn.to(device), bn2.to(device)
+    got = ops.affine_act_(x.to(device).clone(), *ops.bn_fold(bn), act=ops.ACT_RELU, residual=r.to(device),
+                          res_affine=ops.bn_fold(bn2))
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+    want = torch.nn.functional.leaky_relu(bn.cpu()(x), 0.25)
+    got = ops.affine_act_(x.to(device).clone(), *ops.bn_fold(bn.to(device)), act=ops.ACT_LEAKY, slope=0.25)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+    with torch.no_grad():
+        bn.weight.mul_(2.0)                       # in-place edit (optimizer step, load_state_dict) invalidates the fold
+    s2, _ = ops.bn_fold(bn)
+    torch.testing.assert_close(s2, bn.weight * torch.rsqrt(bn.running_var + bn.eps))
