@@ -34,7 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (FMA counted as 2)
+VALU_PEAK_TFLOPS = 157.3     # fp32 peak, vector FMA = f32-input MFMA (MI355X_MICROARCH.md)
 METRIC = "RGB-D frames/sec fwd (480x640, N=12288, bs=8)"
 
 
@@ -216,24 +216,37 @@ def main():
         pyr_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["pyramid"]]))
         fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["forward"]]))
         summary = tracer.summary()
-        hbm_ops = {k: v for k, v in summary.items() if not k.startswith("knn") and v["launches"]}
+        # dominant hand-written op of the timed steps.  KNN is latency/VALU bound (10.7 MB of
+        # algorithmic bytes per frame) and is reported through hot_path_ops instead.
+        cand = {k: v for k, v in summary.items() if not k.startswith("knn") and v["launches"]}
         roof_op = args.roofline_op if args.roofline_op != "auto" else \
-            (max(hbm_ops, key=lambda k: hbm_ops[k]["total_ms"]) if hbm_ops else None)
+            (max(cand, key=lambda k: cand[k]["total_ms"]) if cand else None)
         summ = summary.get(roof_op)
         roofline = None
         if summ and summ["launches"]:
-            ach = summ["gbps"]
             traffic = None
             pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc_file):      # HBM bytes per launch measured offline with rocprofv3 --pmc
                 with open(pmc_file) as fh:
                     traffic = json.load(fh).get(roof_op, {}).get("hbm_bytes_per_launch")
-            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": roof_op,
-                        "launches_per_step": summ["launches"] / args.steps,
-                        "avg_launch_us": summ["avg_us"],
-                        "algorithmic_bytes_per_launch": summ["bytes"] / summ["launches"],
-                        "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
+            sec = summ["total_ms"] * 1e-3
+            if roof_op == "shared_mlp":
+                # fp32 MFMA GEMM: tag = (K, Cout, P) per frame
+                flops = sum(2.0 * args.batch * t[0] * t[1] * t[2] for _, _, _, t in tracer.records[roof_op])
+                ach = flops / sec / 1e12
+                roofline = {"bound": "mfma", "achieved": ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": "shared_mlp_kernel (fp32 MFMA 32x32x2)",
+                            "launches_per_step": summ["launches"] / args.steps, "avg_launch_us": summ["avg_us"],
+                            "algorithmic_flops_per_step": flops / args.steps,
+                            "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
+            else:
+                ach = summ["gbps"]
+                roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": roof_op,
+                            "launches_per_step": summ["launches"] / args.steps,
+                            "avg_launch_us": summ["avg_us"],
+                            "algorithmic_bytes_per_launch": summ["bytes"] / summ["launches"],
+                            "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
         ops_table = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["total_ms"] / args.steps,
                          "algorithmic_GBps": v["gbps"]} for k, v in summary.items()}
         if "knn" in summary:

@@ -22,7 +22,7 @@ SIGNATURES = {
     "ffb6d_knn_prepared_bytes": (_sz, [_i64, _i64]),
     "ffb6d_knn_prepare_workspace_bytes": (_sz, [_i64, _i64]),
     "ffb6d_knn_prepare": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp, _sz, _vp]),
-    "ffb6d_knn_search_prepared": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ffb6d_knn_search_prepared": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "ffb6d_knn_uses_pruning": (_i32, [_i64, _i64, _i64, _i32]),
     "ffb6d_random_sample_f32": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_random_sample_bwd_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),

@@ -417,7 +417,7 @@ int ffb6d_knn_batch_device(const float* support, const float* query, int64_t B, 
             rc = ffb6d_knn_prepare(query, B, Q, prep_q, pq, scratch, scratch_bytes, stream);
             if (rc != FFB6D_OK) return rc;
         }
-        return ffb6d_knn_search_prepared(prep_s, prep_q, B, S, Q, K, idx64, idx32, dist, stream);
+        return ffb6d_knn_search_prepared(prep_s, prep_q, nullptr, B, S, Q, K, idx64, idx32, dist, stream);
     }
     const Plan p = make_plan(B, S, Q, K);
     hipStream_t st = as_stream(stream);

@@ -73,19 +73,16 @@ __device__ __forceinline__ int f2ord(float f)
 }
 __device__ __forceinline__ float ord2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
 
-__global__ void bbox_init_kernel(int* __restrict__ bbox, int n6)
+// per-frame bounding box -> quantisation frame {lo.xyz, 0, scale.xyz, 0}; one 1024-thread
+// block per frame (a frame is at most a few hundred thousand points)
+__global__ void __launch_bounds__(1024)
+frame_kernel(const float* __restrict__ pts, int S, float* __restrict__ frame)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n6) bbox[i] = (i % 6 < 3) ? 0x7fffffff : (int)0x80000000;
-}
-
-__global__ void __launch_bounds__(BLK)
-bbox_kernel(const float* __restrict__ pts, int S, int* __restrict__ bbox)
-{
-    const int b = blockIdx.y;
+    __shared__ float red[6][16];
+    const int b = blockIdx.x;
     const float* p = pts + (size_t)b * S * 3;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = blockIdx.x * BLK + threadIdx.x; i < S; i += gridDim.x * BLK) {
+    for (int i = threadIdx.x; i < S; i += 1024) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float v = p[(size_t)i * 3 + c];
@@ -101,13 +98,21 @@ bbox_kernel(const float* __restrict__ pts, int S, int* __restrict__ bbox)
             hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64));
         }
     }
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            atomicMin(bbox + b * 6 + c, f2ord(lo[c]));
-            atomicMax(bbox + b * 6 + 3 + c, f2ord(hi[c]));
-        }
+        for (int c = 0; c < 3; ++c) { red[c][w] = lo[c]; red[3 + c][w] = hi[c]; }
     }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        float l = INFINITY, h = -INFINITY;
+        for (int i = 0; i < 16; ++i) { l = fminf(l, red[c][i]); h = fmaxf(h, red[3 + c][i]); }
+        const float ext = h - l;
+        frame[b * 8 + c] = l;
+        frame[b * 8 + 4 + c] = (ext > 0.f && ext < INFINITY) ? 1024.f / ext : 0.f;
+    }
+    if (threadIdx.x == 3) { frame[b * 8 + 3] = 0.f; frame[b * 8 + 7] = 0.f; }
 }
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v)
@@ -127,21 +132,6 @@ __device__ __forceinline__ uint32_t morton_key(float x, float y, float z, const 
     const float cy = fminf(fmaxf((y - fr[1]) * fr[5], 0.f), 1023.f);
     const float cz = fminf(fmaxf((z - fr[2]) * fr[6], 0.f), 1023.f);
     return spread10((uint32_t)cx) | (spread10((uint32_t)cy) << 1) | (spread10((uint32_t)cz) << 2);
-}
-
-__global__ void frame_kernel(const int* __restrict__ bbox, float* __restrict__ frame, int B)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float lo = ord2f(bbox[b * 6 + c]), hi = ord2f(bbox[b * 6 + 3 + c]);
-        const float ext = hi - lo;
-        frame[b * 8 + c] = lo;
-        frame[b * 8 + 4 + c] = (ext > 0.f && ext < INFINITY) ? 1024.f / ext : 0.f;
-    }
-    frame[b * 8 + 3] = 0.f;
-    frame[b * 8 + 7] = 0.f;
 }
 
 __global__ void __launch_bounds__(BLK)
@@ -502,7 +492,7 @@ __global__ void __launch_bounds__(BLK)
 knn_row16_kernel(const float4* __restrict__ spts, const float4* __restrict__ boxes,
                  const float4* __restrict__ boxes2, const float* __restrict__ sframe,
                  const uint32_t* __restrict__ skeys, int S, int S_pad, int nt, int nt2,
-                 const float4* __restrict__ qpts, int Q, int Q_pad,
+                 const float4* __restrict__ qpts, const float* __restrict__ qraw, int Q, int Q_pad,
                  int64_t* __restrict__ idx64, int32_t* __restrict__ idx32, float* __restrict__ dist,
                  int Kout)
 {
@@ -512,7 +502,15 @@ knn_row16_kernel(const float4* __restrict__ spts, const float4* __restrict__ box
     const int r = tid & 15;
     const int b = blockIdx.y;
     const int qslot = blockIdx.x * (BLK / 16) + (tid >> 4);
-    const float4 q = qpts[(size_t)b * Q_pad + min(qslot, Q_pad - 1)];
+    // queries either Morton-prepared (float4 with the original index in .w) or the caller's raw
+    // [B,Q,3] array in its own order: a row works alone, so query order only affects cache locality
+    float4 q;
+    if (qraw) {
+        const float* s = qraw + ((size_t)b * Q + min(qslot, Q - 1)) * 3;
+        q = make_float4(s[0], s[1], s[2], __uint_as_float(qslot < Q ? (uint32_t)qslot : 0xffffffffu));
+    } else {
+        q = qpts[(size_t)b * Q_pad + min(qslot, Q_pad - 1)];
+    }
     const uint32_t q_orig = __float_as_uint(q.w);
     const bool live = qslot < Q_pad && q_orig != 0xffffffffu;
     if (!__any(live)) return;
@@ -687,13 +685,9 @@ int ffb6d_knn_prepare(const float* pts, int64_t B, int64_t S, void* prepared, si
     auto* keys_out = reinterpret_cast<unsigned long long*>(ws + W.keys_out);
     auto* vals_in = reinterpret_cast<uint32_t*>(ws + W.vals_in);
     auto* vals_out = reinterpret_cast<uint32_t*>(ws + W.vals_out);
-    int* bbox = reinterpret_cast<int*>(ws + W.bbox);
     float* frame = reinterpret_cast<float*>(pp + L.frame_off);
 
-    hipLaunchKernelGGL(bbox_init_kernel, dim3((unsigned)ceil_div(B * 6, 64)), dim3(64), 0, st, bbox, (int)(B * 6));
-    const unsigned rb = (unsigned)std::min<int64_t>(ceil_div(S, BLK), 64);
-    hipLaunchKernelGGL(bbox_kernel, dim3(rb, (unsigned)B), dim3(BLK), 0, st, pts, (int)S, bbox);
-    hipLaunchKernelGGL(frame_kernel, dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, st, bbox, frame, (int)B);
+    hipLaunchKernelGGL(frame_kernel, dim3((unsigned)B), dim3(1024), 0, st, pts, (int)S, frame);
     hipLaunchKernelGGL(morton_kernel, dim3((unsigned)ceil_div(S, BLK), (unsigned)B), dim3(BLK), 0, st, pts, (int)S,
                        frame, keys_in, vals_in);
     FFB6D_LAUNCH_CHECK();
@@ -723,14 +717,16 @@ int ffb6d_knn_prepare(const float* pts, int64_t B, int64_t S, void* prepared, si
     return FFB6D_OK;
 }
 
-int ffb6d_knn_search_prepared(const void* prep_support, const void* prep_query, int64_t B, int64_t S,
-                              int64_t Q, int K, int64_t* idx64, int32_t* idx32, float* dist,
-                              ffb6d_stream_t stream)
+int ffb6d_knn_search_prepared(const void* prep_support, const void* prep_query, const float* raw_query,
+                              int64_t B, int64_t S, int64_t Q, int K, int64_t* idx64, int32_t* idx32,
+                              float* dist, ffb6d_stream_t stream)
 {
     FFB6D_REQUIRE(K >= 1 && K <= 32, "knn_search_prepared: K must be in [1,32] (got %d)", K);
     FFB6D_REQUIRE(B >= 1 && S >= 1 && Q >= 1, "knn_search_prepared: empty problem");
     FFB6D_REQUIRE(S >= K, "knn_search_prepared: npts (%lld) < K (%d)", (long long)S, K);
-    FFB6D_REQUIRE(prep_support && prep_query, "knn_search_prepared: null prepared set");
+    FFB6D_REQUIRE(prep_support && (prep_query || raw_query), "knn_search_prepared: null point set");
+    FFB6D_REQUIRE(prep_query || (K >= 2 && K <= 16),
+                  "knn_search_prepared: raw (unprepared) queries are supported for 2 <= K <= 16 only");
     FFB6D_REQUIRE(idx64 || idx32 || dist, "knn_search_prepared: no output requested");
     const Layout LS = layout(B, S), LQ = layout(B, Q);
     const char* ps = static_cast<const char*>(prep_support);
@@ -740,16 +736,18 @@ int ffb6d_knn_search_prepared(const void* prep_support, const void* prep_query, 
     const uint32_t* skeys = reinterpret_cast<const uint32_t*>(ps + LS.key_off);
     const float* sframe = reinterpret_cast<const float*>(ps + LS.frame_off);
     const uint32_t* scell = reinterpret_cast<const uint32_t*>(ps + LS.cell_off);
-    const float4* qpts = reinterpret_cast<const float4*>(pq + LQ.pts_off);
+    const float4* qpts = prep_query ? reinterpret_cast<const float4*>(pq + LQ.pts_off) : nullptr;
     dim3 grid((unsigned)ceil_div(LQ.S_pad, BLK), (unsigned)B);
     hipStream_t st = as_stream(stream);
     const int Kp = pad_k(K);
+    FFB6D_REQUIRE(K <= 16 || prep_query, "knn_search_prepared: K > 16 needs prepared queries");
     if (K >= 2 && K <= 16) {   // row-cooperative kernel: 16 lanes per query
         const float4* boxes2 = reinterpret_cast<const float4*>(ps + LS.box2_off);
         dim3 rgrid((unsigned)ceil_div(LQ.S_pad, BLK / 16), (unsigned)B);
 #define FFB6D_LAUNCH_ROW(KK)                                                                                  \
     hipLaunchKernelGGL((knn_row16_kernel<KK>), rgrid, dim3(BLK), 0, st, spts, boxes, boxes2, sframe, skeys,    \
-                       (int)S, (int)LS.S_pad, (int)LS.nt, (int)LS.nt2, qpts, (int)Q, (int)LQ.S_pad, idx64, idx32, dist, K)
+                       (int)S, (int)LS.S_pad, (int)LS.nt, (int)LS.nt2, qpts, prep_query ? nullptr : raw_query, (int)Q,  \
+                       (int)LQ.S_pad, idx64, idx32, dist, K)
         switch (Kp) {
             case 2: FFB6D_LAUNCH_ROW(2); break;
             case 4: FFB6D_LAUNCH_ROW(4); break;

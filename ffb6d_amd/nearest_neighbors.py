@@ -83,10 +83,22 @@ class PreparedPoints:
 
 
 def knn_prepared(support, query, K, dtype=None, return_dist=False):
-    """Exact KNN between two PreparedPoints (same results as knn_batch_device)."""
+    """Exact KNN of `query` in a PreparedPoints `support` (same results as knn_batch_device).
+    `query` is a PreparedPoints or -- for 2 <= K <= 16 -- a raw float32 [B,Q,3] GPU tensor."""
     import torch
 
     lib = _lib.load()
+    raw = None
+    if not isinstance(query, PreparedPoints):
+        raw = query.contiguous()
+        if raw.dtype != torch.float32 or raw.dim() != 3 or raw.shape[2] != 3 or not raw.is_cuda:
+            raise TypeError("raw query must be a float32 [B,Q,3] GPU tensor")
+
+        class _Q:      # shape carrier
+            B, S = int(raw.shape[0]), int(raw.shape[1])
+        query = _Q
+        if not 2 <= int(K) <= 16:
+            raise ValueError("raw queries need 2 <= K <= 16 (prepare the query set otherwise)")
     if support.B != query.B:
         raise ValueError("batch sizes differ")
     K = int(K)
@@ -102,7 +114,8 @@ def knn_prepared(support, query, K, dtype=None, return_dist=False):
     nbytes = 12 * B * S + 12 * B * Q + idx.element_size() * B * Q * K
     with torch.cuda.device(dev), _lib.traced("knn", nbytes, (S, Q, K)):
         rc = lib.ffb6d_knn_search_prepared(
-            support.blob.data_ptr(), query.blob.data_ptr(), B, S, Q, K,
+            support.blob.data_ptr(), None if raw is not None else query.blob.data_ptr(),
+            raw.data_ptr() if raw is not None else None, B, S, Q, K,
             idx.data_ptr() if dtype == torch.int64 else None,
             idx.data_ptr() if dtype == torch.int32 else None,
             dist.data_ptr() if dist is not None else None, torch.cuda.current_stream().cuda_stream)

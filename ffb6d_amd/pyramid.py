@@ -49,9 +49,13 @@ def build_index_pyramid(cld, dpt_xyz, index_dtype=torch.int64):
         every search that touches it), small ones through the brute-force scan."""
         if not uses_pruning(B, support.shape[1], query.shape[1], k):
             return knn_batch_device(support, query, k, dtype=index_dtype)
-        for t in (support, query):
-            if id(t) not in prepared:
-                prepared[id(t)] = PreparedPoints(t)
+        if id(support) not in prepared:
+            prepared[id(support)] = PreparedPoints(support)
+        if k >= 2 and id(query) not in prepared:
+            # 16-lane rows work on one query each: unsorted queries are fine, skip their sort
+            return knn_prepared(prepared[id(support)], query, k, dtype=index_dtype)
+        if id(query) not in prepared:
+            prepared[id(query)] = PreparedPoints(query)
         return knn_prepared(prepared[id(support)], prepared[id(query)], k, dtype=index_dtype)
 
     out = {}

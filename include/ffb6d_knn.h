@@ -100,9 +100,11 @@ size_t ffb6d_knn_prepare_workspace_bytes(int64_t batch_size, int64_t npts);
 int ffb6d_knn_prepare(const float* points /* [B,npts,3] device */, int64_t batch_size, int64_t npts,
                       void* prepared, size_t prepared_bytes, void* workspace, size_t workspace_bytes,
                       ffb6d_stream_t stream);
+/* Queries: either a prepared set (prepared_query) or, for 2 <= K <= 16, the raw [B,nqueries,3]
+ * device array (raw_query, prepared_query = NULL) -- small query sets need no preparation. */
 int ffb6d_knn_search_prepared(const void* prepared_support, const void* prepared_query,
-                              int64_t batch_size, int64_t npts, int64_t nqueries, int K,
-                              int64_t* idx64, int32_t* idx32, float* dist, ffb6d_stream_t stream);
+                              const float* raw_query, int64_t batch_size, int64_t npts, int64_t nqueries,
+                              int K, int64_t* idx64, int32_t* idx32, float* dist, ffb6d_stream_t stream);
 
 /* 1 when ffb6d_knn_batch_device would take the prepared/pruned route for this shape
  * (large support sets), 0 when it scans brute force. */

@@ -151,3 +151,23 @@ def test_knn_rejects_bad_arguments(device):
         nn.knn_batch_device(s.cpu(), s.cpu(), 4)
     e = nn.knn_batch_device(s, torch.zeros(1, 0, 3, device=device), 4)   # empty query set
     assert e.shape == (1, 0, 4)
+
+
+def test_prepared_sets_and_raw_queries_agree_with_the_oracle(device):
+    """ffb6d_knn_prepare / ffb6d_knn_search_prepared: a prepared support serves prepared and raw
+    (unsorted) query sets; results equal the brute-force oracle bit for bit."""
+    rng = np.random.RandomState(77)
+    sup = rng.rand(2, 5000, 3).astype(np.float32)
+    qry = rng.rand(2, 333, 3).astype(np.float32)
+    want_i, want_d = oknn.knn_batch(sup, qry, 16, return_dist=True)
+    ps = nn.PreparedPoints(torch.from_numpy(sup).to(device))
+    q_dev = torch.from_numpy(qry).to(device)
+    got_i, got_d = nn.knn_prepared(ps, q_dev, 16, return_dist=True)                      # raw queries
+    np.testing.assert_array_equal(got_i.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(got_d.cpu().numpy(), want_d)
+    got_i2 = nn.knn_prepared(ps, nn.PreparedPoints(q_dev), 16, dtype=torch.int32)         # prepared queries
+    np.testing.assert_array_equal(got_i2.cpu().numpy(), want_i.astype(np.int32))
+    got_1 = nn.knn_prepared(ps, nn.PreparedPoints(q_dev), 1)                              # K = 1 kernel
+    np.testing.assert_array_equal(got_1.cpu().numpy(), oknn.knn_batch(sup, qry, 1))
+    with pytest.raises(ValueError):
+        nn.knn_prepared(ps, q_dev, 1)                                                     # raw needs 2 <= K <= 16
