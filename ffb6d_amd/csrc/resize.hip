@@ -219,3 +219,53 @@ extern "C" int ffb6d_affine_act_f32(const float* x, const float* scale, const fl
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// log_softmax over the channel axis of an NCHW map (the `final` head of the colour branch,
+// pspnet.py:108-112: nn.LogSoftmax() on a 4-d tensor = dim 1).  One lane owns one pixel and keeps
+// its C <= 64 channel values in registers: one read + one write of the map, both coalesced.
+// ------------------------------------------------------------------------------------------
+namespace ffb6d {
+namespace {
+
+template <int C>
+__global__ void __launch_bounds__(256)
+channel_log_softmax_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, size_t total)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;   // pixel id over B*HW
+    if (t >= total) return;
+    const size_t b = t / HW;
+    const size_t p = t - b * HW;
+    const float* xi = x + b * (size_t)C * HW + p;
+    float v[C];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { v[c] = xi[(size_t)c * HW]; m = fmaxf(m, v[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) s += expf(v[c] - m);
+    const float lse = m + logf(s);
+    float* oi = out + b * (size_t)C * HW + p;
+#pragma unroll
+    for (int c = 0; c < C; ++c) oi[(size_t)c * HW] = v[c] - lse;
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+extern "C" int ffb6d_channel_log_softmax_f32(const float* x, float* out, int64_t B, int64_t C, int64_t HW,
+                                             ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(B >= 0 && HW >= 0, "channel_log_softmax: bad shape");
+    FFB6D_REQUIRE(C == 64 || C == 32 || C == 16, "channel_log_softmax: C must be 16, 32 or 64 (got %lld)", (long long)C);
+    const size_t total = (size_t)B * HW;
+    if (total == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(x && out, "channel_log_softmax: null pointer");
+    const dim3 grid((unsigned)ffb6d::ceil_div((int64_t)total, 256));
+    hipStream_t st = ffb6d::as_stream(stream);
+    if (C == 64) hipLaunchKernelGGL((ffb6d::channel_log_softmax_kernel<64>), grid, dim3(256), 0, st, x, out, (int)HW, total);
+    else if (C == 32) hipLaunchKernelGGL((ffb6d::channel_log_softmax_kernel<32>), grid, dim3(256), 0, st, x, out, (int)HW, total);
+    else hipLaunchKernelGGL((ffb6d::channel_log_softmax_kernel<16>), grid, dim3(256), 0, st, x, out, (int)HW, total);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}

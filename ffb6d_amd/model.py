@@ -260,9 +260,12 @@ class PyramidPooling(nn.Module):
         h, w = x.shape[2:]
         if torch.is_grad_enabled() or not x.is_cuda:
             pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]
-        else:
-            pri = [ops.bilinear_resize(st(x), (h, w), align_corners=False) for st in self.stages]
-        return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
+            return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
+        pri = [ops.bilinear_resize(st(x), (h, w), align_corners=False) for st in self.stages]
+        y = F.conv2d(torch.cat(pri + [x], 1), self.bottleneck.weight, None)
+        if getattr(self, "_ones", None) is None or self._ones.device != y.device:
+            self._ones = torch.ones(y.shape[1], device=y.device)
+        return ops.affine_act_(y, self._ones, self.bottleneck.bias.detach(), act=ops.ACT_RELU)   # bias + ReLU, one pass
 
 
 class UpBlock(nn.Module):
@@ -277,13 +280,38 @@ class UpBlock(nn.Module):
         if torch.is_grad_enabled() or not x.is_cuda:
             return self.conv(x)
         y = ops.bilinear_resize(x, (2 * x.shape[2], 2 * x.shape[3]), align_corners=True)
-        y = self.conv[1](y)
-        prelu = self.conv[3]
+        conv, bn, prelu = self.conv[1], self.conv[2], self.conv[3]
         if prelu.weight.numel() != 1 or (y.shape[2] * y.shape[3]) % 4:
-            return prelu(self.conv[2](y))
+            return prelu(bn(conv(y)))
         if getattr(self, "_slope", None) is None or self._slope[0] != prelu.weight._version:
             self._slope = (prelu.weight._version, float(prelu.weight.detach().item()))
-        return ops.affine_act_(y, *ops.bn_fold(self.conv[2]), act=ops.ACT_LEAKY, slope=self._slope[1])
+        # conv bias rides in the BatchNorm shift: BN(conv(y)+b) = scale*conv(y) + (shift + scale*b)
+        scale, shift = ops.bn_fold(bn)
+        key = (conv.bias._version, bn.bias._version, bn.weight._version, bn.running_mean._version,
+               bn.running_var._version)
+        if getattr(self, "_shift", None) is None or self._shift[0] != key:
+            self._shift = (key, (shift + scale * conv.bias.detach()).contiguous())
+        y = F.conv2d(y, conv.weight, None, conv.stride, conv.padding)
+        return ops.affine_act_(y, scale, self._shift[1], act=ops.ACT_LEAKY, slope=self._slope[1])
+
+
+class FinalHead(nn.Sequential):
+    """pspnet.py:108-112 `final`: Conv2d(64,64,1) + LogSoftmax (implicit dim = 1 on a 4-d map).
+    Inference: the 1x1 conv is the fused MFMA shared-MLP kernel (bias in the epilogue), the
+    log-softmax one register-resident pass."""
+
+    def __init__(self, ch=64):
+        super().__init__(nn.Conv2d(ch, ch, 1), nn.LogSoftmax(dim=1))
+
+    def forward(self, x):
+        conv = self[0]
+        if _autograd_path(x) or conv.out_channels not in (16, 32, 64):
+            return super().forward(x)
+        key = (conv.weight._version, conv.bias._version)
+        if getattr(self, "_wt", None) is None or self._wt[0] != key:
+            self._wt = (key, conv.weight.detach().reshape(conv.out_channels, -1).t().contiguous())
+        y = ops.shared_mlp(x, self._wt[1], conv.bias.detach(), ops.ACT_NONE)
+        return ops.channel_log_softmax_(y)
 
 
 def _head(cin, cout):
@@ -312,7 +340,7 @@ class FFB6D(nn.Module):
             nn.Sequential(res_layer(128, 256, 6, 1), res_layer(256, 512, 3, 1)),
             nn.Sequential(PyramidPooling(512, 1024), nn.Dropout2d(p=0.3)),
         ])
-        final = nn.Sequential(nn.Conv2d(64, 64, 1), nn.LogSoftmax(dim=1))  # shared by stages 2 and 3
+        final = FinalHead(64)  # shared by stages 2 and 3 (ffb6d.py:86-87)
         self.cnn_up_stages = nn.ModuleList([
             nn.Sequential(UpBlock(1024, 256), nn.Dropout2d(p=0.15)),
             nn.Sequential(UpBlock(256, 64), nn.Dropout2d(p=0.15)),
@@ -363,7 +391,7 @@ class FFB6D(nn.Module):
         # drop every cached inference-time fold (BatchNorm scale/shift, split weights): they are
         # also version-checked, this covers edits made through `.data`
         for m in self.modules():
-            for attr in ("_ffb6d_fold", "_split", "_res", "_fct", "_slope"):
+            for attr in ("_ffb6d_fold", "_split", "_res", "_fct", "_slope", "_shift", "_wt", "_ones"):
                 if hasattr(m, attr):
                     setattr(m, attr, None)
         return super().train(mode)

@@ -405,6 +405,20 @@ def affine_act_(x, scale, shift, act=ACT_NONE, slope=0.0, residual=None, res_aff
     return x
 
 
+def channel_log_softmax_(x):
+    """In-place log_softmax over dim 1 of a contiguous [B,C,H,W] float32 map, C in {16,32,64}."""
+    _need_gpu(x)
+    lib = _lib.load()
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise ValueError("channel_log_softmax_ needs a contiguous float32 tensor")
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    with torch.cuda.device(x.device), _lib.traced("channel_log_softmax", 8 * x.numel(), (C, HW)):
+        rc = lib.ffb6d_channel_log_softmax_f32(x.data_ptr(), x.data_ptr(), B, C, HW, _stream(x))
+    _lib.check(rc, "ffb6d_channel_log_softmax_f32")
+    return x
+
+
 def check_index_range(idx, M):
     """Number of entries of `idx` outside [0, M) (debug aid; the kernels do not bounds-check)."""
     _need_gpu(idx)

@@ -124,6 +124,11 @@ int ffb6d_affine_act_f32(const float* x, const float* scale, const float* shift,
                          const float* rscale, const float* rshift, float* out, int64_t B, int64_t C,
                          int64_t HW, int act, float slope, ffb6d_stream_t stream);
 
+/* log_softmax over the channel axis of [B,C,HW] (pspnet.py:108-112 `final`: nn.LogSoftmax() on a 4-d
+ * tensor acts on dim 1), C in {16,32,64}; in place allowed. */
+int ffb6d_channel_log_softmax_f32(const float* x, float* out, int64_t B, int64_t C, int64_t HW,
+                                  ffb6d_stream_t stream);
+
 /* Debug helper: number of entries of idx[0:count] outside [0, M) written to *bad (device int32). */
 int ffb6d_check_index_range(const void* idx, int idx_bits, int64_t count, int64_t M,
                             int32_t* bad, ffb6d_stream_t stream);

@@ -231,3 +231,10 @@ def test_affine_act_matches_bn_relu_add(device):
         bn.weight.mul_(2.0)                       # in-place edit (optimizer step, load_state_dict) invalidates the fold
     s2, _ = ops.bn_fold(bn)
     torch.testing.assert_close(s2, bn.weight * torch.rsqrt(bn.running_var + bn.eps))
+
+
+def test_channel_log_softmax(device):
+    x = torch.randn(2, 64, 30, 40, generator=torch.Generator().manual_seed(1)) * 3
+    want = torch.log_softmax(x, dim=1)
+    got = ops.channel_log_softmax_(x.to(device).clone()).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
