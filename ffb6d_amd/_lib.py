@@ -41,6 +41,8 @@ SIGNATURES = {
     "ffb6d_bilinear_resize_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_affine_act_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _c.c_float, _vp]),
     "ffb6d_channel_log_softmax_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "ffb6d_psp_pool_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "ffb6d_psp_prior_sum_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "ffb6d_check_index_range": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
 }
 

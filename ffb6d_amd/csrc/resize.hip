@@ -269,3 +269,129 @@ extern "C" int ffb6d_channel_log_softmax_f32(const float* x, float* out, int64_t
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Pyramid pooling (pspnet.py:7-31) without the 2560-channel concatenation.
+//   bottleneck(cat(up(conv_i(pool_i(x))), x)) = W_x x + b + sum_i up(W_bi conv_i pool_i(x))
+// (bilinear up-sampling and 1x1 convolutions are both linear and act on different axes, so they
+// commute).  Two helpers:
+//   psp_pool        all adaptive average pools (sizes 1,2,3,6) of a [B,C,H,W] map in ONE pass:
+//                   a block stages one plane in LDS, each wave sums whole bins
+//   psp_prior_sum   S[b,m,y,x] = sum_i bilinear(z_i)[b,m,y,x] for the tiny pre-multiplied maps
+//                   z_i [B,M,s_i,s_i] (align_corners = False), one write of the output
+// The 1x1 bottleneck itself runs on the fused shared-MLP kernel with S as its additive term.
+// ------------------------------------------------------------------------------------------
+namespace ffb6d {
+namespace {
+
+constexpr int PSP_MAX = 4;
+
+struct PspSizes { int n; int s[PSP_MAX]; int off[PSP_MAX + 1]; };   // off = prefix sums of s*s
+
+__global__ void __launch_bounds__(256)
+psp_pool_kernel(const float* __restrict__ x, float* __restrict__ out /* [planes, total_bins] */, int H, int W,
+                PspSizes sz)
+{
+    extern __shared__ float plane[];
+    const size_t pl = blockIdx.x;
+    const int hw = H * W;
+    const float* src = x + pl * (size_t)hw;
+    for (int i = threadIdx.x; i < hw; i += 256) plane[i] = src[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int total = sz.off[sz.n];
+    for (int bin = wave; bin < total; bin += 4) {
+        int lvl = 0;
+        while (bin >= sz.off[lvl + 1]) ++lvl;
+        const int s = sz.s[lvl];
+        const int by = (bin - sz.off[lvl]) / s, bxi = (bin - sz.off[lvl]) % s;
+        // ATen adaptive pooling: start = floor(i*in/out), end = ceil((i+1)*in/out)
+        const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s;
+        const int x0 = (bxi * W) / s, x1 = ((bxi + 1) * W + s - 1) / s;
+        const int rw = x1 - x0, n = (y1 - y0) * rw;
+        float acc = 0.f;
+        for (int i = lane; i < n; i += 64) acc += plane[(y0 + i / rw) * W + x0 + i % rw];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) out[pl * total + bin] = acc / (float)n;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+psp_prior_sum_kernel(const float* __restrict__ z /* [planes, total_bins] */, float* __restrict__ out, int H, int W,
+                     PspSizes sz, size_t total4 /* planes*H*W/4 */)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const int w4 = W >> 2;
+    const int xg = (int)(t % w4);
+    const size_t row = t / w4;
+    const int oy = (int)(row % H);
+    const size_t pl = row / H;
+    const float* zp = z + pl * (size_t)sz.off[sz.n];
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < sz.n; ++l) {
+        const int s = sz.s[l];
+        const float* m = zp + sz.off[l];
+        const float rh = (float)s / (float)H, rw = (float)s / (float)W;
+        const float h1r = src_index(rh, oy, false);
+        const int h1 = (int)h1r;
+        const int h1p = (h1 < s - 1) ? 1 : 0;
+        const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float w1r = src_index(rw, xg * 4 + v, false);
+            const int w1 = (int)w1r;
+            const int w1p = (w1 < s - 1) ? 1 : 0;
+            const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+            res[v] += h0l * (w0l * m[h1 * s + w1] + w1l * m[h1 * s + w1 + w1p]) +
+                      h1l * (w0l * m[(h1 + h1p) * s + w1] + w1l * m[(h1 + h1p) * s + w1 + w1p]);
+        }
+    }
+    *reinterpret_cast<float4*>(out + row * (size_t)W + (size_t)xg * 4) = make_float4(res[0], res[1], res[2], res[3]);
+}
+
+int fill_sizes(PspSizes& sz, const int* sizes, int n)
+{
+    if (n < 1 || n > PSP_MAX) return -1;
+    sz.n = n;
+    sz.off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (sizes[i] < 1 || sizes[i] > 64) return -1;
+        sz.s[i] = sizes[i];
+        sz.off[i + 1] = sz.off[i] + sizes[i] * sizes[i];
+    }
+    return 0;
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+extern "C" int ffb6d_psp_pool_f32(const float* x, float* out, int64_t planes, int64_t H, int64_t W,
+                                  const int* sizes, int nsizes, ffb6d_stream_t stream)
+{
+    ffb6d::PspSizes sz;
+    FFB6D_REQUIRE(ffb6d::fill_sizes(sz, sizes, nsizes) == 0, "psp_pool: 1..4 pool sizes in [1,64] expected");
+    FFB6D_REQUIRE(planes >= 0 && H >= 1 && W >= 1 && H * W * 4 <= 160 * 1024, "psp_pool: plane must fit in LDS");
+    if (planes == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(x && out, "psp_pool: null pointer");
+    hipLaunchKernelGGL(ffb6d::psp_pool_kernel, dim3((unsigned)planes), dim3(256), (size_t)(H * W * 4),
+                       ffb6d::as_stream(stream), x, out, (int)H, (int)W, sz);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+extern "C" int ffb6d_psp_prior_sum_f32(const float* z, float* out, int64_t planes, int64_t H, int64_t W,
+                                       const int* sizes, int nsizes, ffb6d_stream_t stream)
+{
+    ffb6d::PspSizes sz;
+    FFB6D_REQUIRE(ffb6d::fill_sizes(sz, sizes, nsizes) == 0, "psp_prior_sum: 1..4 pool sizes in [1,64] expected");
+    FFB6D_REQUIRE(planes >= 0 && H >= 1 && W >= 4 && W % 4 == 0, "psp_prior_sum: W must be a multiple of 4");
+    if (planes == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(z && out && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "psp_prior_sum: bad pointer");
+    const size_t total4 = (size_t)planes * H * (W / 4);
+    hipLaunchKernelGGL(ffb6d::psp_prior_sum_kernel, dim3((unsigned)ffb6d::ceil_div((int64_t)total4, 256)), dim3(256), 0,
+                       ffb6d::as_stream(stream), z, out, (int)H, (int)W, sz, total4);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}

@@ -261,11 +261,40 @@ class PyramidPooling(nn.Module):
         if torch.is_grad_enabled() or not x.is_cuda:
             pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]
             return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
-        pri = [ops.bilinear_resize(st(x), (h, w), align_corners=False) for st in self.stages]
-        y = F.conv2d(torch.cat(pri + [x], 1), self.bottleneck.weight, None)
-        if getattr(self, "_ones", None) is None or self._ones.device != y.device:
-            self._ones = torch.ones(y.shape[1], device=y.device)
-        return ops.affine_act_(y, self._ones, self.bottleneck.bias.detach(), act=ops.ACT_RELU)   # bias + ReLU, one pass
+        if w % 4 or h * w * 4 > 160 * 1024:
+            pri = [ops.bilinear_resize(st(x), (h, w), align_corners=False) for st in self.stages]
+            return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
+        return self.fused(x)
+
+    def _weights(self):
+        """Per-level products W_b,i @ W_i ([512 -> 1024], the level's 1x1 conv followed by its slice
+        of the bottleneck) and the transposed direct slice W_x^T, cached."""
+        bw = self.bottleneck.weight
+        key = (bw._version,) + tuple(st[1].weight._version for st in self.stages)
+        if getattr(self, "_fold", None) is None or self._fold[0] != key:
+            ch = self.stages[0][1].weight.shape[0]
+            wb = bw.detach().reshape(bw.shape[0], -1)                                 # [1024, 2560]
+            prods = [(wb[:, i * ch:(i + 1) * ch] @ st[1].weight.detach().reshape(ch, ch)).t().contiguous()
+                     for i, st in enumerate(self.stages)]                              # each [512, 1024]
+            wx = wb[:, len(self.stages) * ch:].t().contiguous()                        # [512, 1024]
+            self._fold = (key, prods, wx)
+        return self._fold[1], self._fold[2]
+
+    def fused(self, x):
+        """bottleneck(cat(up_i(conv_i(pool_i(x))), x)) = W_x x + b + sum_i up_i((W_b,i W_i) pool_i(x)):
+        no 2560-channel concatenation, the big GEMM shrinks from K=2560 to K=512."""
+        B, C, h, w = x.shape
+        sizes = [st[0].output_size[0] for st in self.stages]
+        prods, wx = self._weights()
+        pooled = ops.psp_pool(x, sizes)                                                # [B,512,50]
+        zs, off = [], 0
+        for s, wt in zip(sizes, prods):
+            zs.append(ops.shared_mlp(pooled[:, :, off:off + s * s].contiguous(), wt, None, ops.ACT_NONE))
+            off += s * s
+        prior = ops.psp_prior_sum(torch.cat(zs, dim=2), sizes, (h, w))                 # [B,1024,h,w]
+        if getattr(self, "_iota", None) is None or self._iota.shape != (B, h * w) or self._iota.device != x.device:
+            self._iota = torch.arange(h * w, dtype=torch.int32, device=x.device).repeat(B, 1)
+        return ops.shared_mlp(x, wx, self.bottleneck.bias.detach(), ops.ACT_RELU, gather=(prior, self._iota))
 
 
 class UpBlock(nn.Module):
@@ -391,7 +420,7 @@ class FFB6D(nn.Module):
         # drop every cached inference-time fold (BatchNorm scale/shift, split weights): they are
         # also version-checked, this covers edits made through `.data`
         for m in self.modules():
-            for attr in ("_ffb6d_fold", "_split", "_res", "_fct", "_slope", "_shift", "_wt", "_ones"):
+            for attr in ("_ffb6d_fold", "_split", "_res", "_fct", "_slope", "_shift", "_wt", "_fold"):
                 if hasattr(m, attr):
                     setattr(m, attr, None)
         return super().train(mode)

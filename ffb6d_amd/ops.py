@@ -419,6 +419,43 @@ def channel_log_softmax_(x):
     return x
 
 
+def _int_array(values):
+    import ctypes
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
+
+
+def psp_pool(x, sizes):
+    """All adaptive average pools of `sizes` of x [B,C,H,W] in one pass -> [B,C,sum(s*s)]
+    (bins of sizes[0] first, row-major inside a level).  Inference only."""
+    _need_gpu(x)
+    lib = _lib.load()
+    xc = _f32(x.detach())
+    B, C, H, W = xc.shape
+    nb = sum(int(s) * int(s) for s in sizes)
+    out = torch.empty((B, C, nb), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _lib.traced("psp_pool", 4 * xc.numel() + 4 * out.numel(), (C, H * W)):
+        rc = lib.ffb6d_psp_pool_f32(xc.data_ptr(), out.data_ptr(), B * C, H, W, _int_array(sizes), len(sizes),
+                                    _stream(xc))
+    _lib.check(rc, "ffb6d_psp_pool_f32")
+    return out
+
+
+def psp_prior_sum(z, sizes, size):
+    """z [B,M,sum(s*s)] (packing of psp_pool) -> [B,M,H,W] = sum over levels of the bilinear
+    (align_corners=False) up-sampling of each level to (H,W).  Inference only."""
+    _need_gpu(z)
+    lib = _lib.load()
+    zc = _f32(z.detach())
+    B, M, _ = zc.shape
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty((B, M, H, W), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device), _lib.traced("psp_prior_sum", 4 * zc.numel() + 4 * out.numel(), (M, H * W)):
+        rc = lib.ffb6d_psp_prior_sum_f32(zc.data_ptr(), out.data_ptr(), B * M, H, W, _int_array(sizes), len(sizes),
+                                         _stream(zc))
+    _lib.check(rc, "ffb6d_psp_prior_sum_f32")
+    return out
+
+
 def check_index_range(idx, M):
     """Number of entries of `idx` outside [0, M) (debug aid; the kernels do not bounds-check)."""
     _need_gpu(idx)

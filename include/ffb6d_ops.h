@@ -129,6 +129,15 @@ int ffb6d_affine_act_f32(const float* x, const float* scale, const float* shift,
 int ffb6d_channel_log_softmax_f32(const float* x, float* out, int64_t B, int64_t C, int64_t HW,
                                   ffb6d_stream_t stream);
 
+/* Pyramid pooling helpers (pspnet.py:7-31).  psp_pool: all adaptive average pools of `sizes` (<= 4
+ * sizes, e.g. 1,2,3,6) of `planes` = B*C [H,W] maps in one pass; out [planes, sum(s*s)] (bins of size
+ * sizes[0] first, row-major).  psp_prior_sum: out[plane,y,x] = sum_i bilinear(z_i)(y,x) for maps
+ * z [planes, sum(s*s)] in the same packing, align_corners = False, W % 4 == 0. */
+int ffb6d_psp_pool_f32(const float* x, float* out, int64_t planes, int64_t H, int64_t W,
+                       const int* sizes, int nsizes, ffb6d_stream_t stream);
+int ffb6d_psp_prior_sum_f32(const float* z, float* out, int64_t planes, int64_t H, int64_t W,
+                            const int* sizes, int nsizes, ffb6d_stream_t stream);
+
 /* Debug helper: number of entries of idx[0:count] outside [0, M) written to *bad (device int32). */
 int ffb6d_check_index_range(const void* idx, int idx_bits, int64_t count, int64_t M,
                             int32_t* bad, ffb6d_stream_t stream);

@@ -238,3 +238,20 @@ def test_channel_log_softmax(device):
     want = torch.log_softmax(x, dim=1)
     got = ops.channel_log_softmax_(x.to(device).clone()).cpu()
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_psp_pool_and_prior_sum_match_torch(device):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 5, 60, 80, generator=g)
+    sizes = [1, 2, 3, 6]
+    got = ops.psp_pool(x.to(device), sizes).cpu()
+    want = torch.cat([torch.nn.functional.adaptive_avg_pool2d(x, (s, s)).reshape(2, 5, -1) for s in sizes], dim=2)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    z = torch.randn(2, 7, 50, generator=g)
+    got = ops.psp_prior_sum(z.to(device), sizes, (60, 80)).cpu()
+    want, off = 0, 0
+    for s in sizes:
+        want = want + torch.nn.functional.interpolate(z[:, :, off:off + s * s].reshape(2, 7, s, s), size=(60, 80),
+                                                      mode="bilinear", align_corners=False)
+        off += s * s
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
