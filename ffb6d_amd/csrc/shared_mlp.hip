@@ -64,8 +64,9 @@ shared_mlp_kernel(const MlpParams p)
     constexpr int WN = 4 / WM;                       // waves along N
     constexpr int TM = BM / (32 * WM);               // 32-row tiles per wave (128: 2, 64: 2, 32: 1)
     constexpr int TN = BN / (32 * WN);               // 32-col tiles per wave (128: 2, 64: 1, 32: 1)
-    __shared__ __attribute__((aligned(16))) float As[BK][BM];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][BN];
+    // two LDS stages: tile k+1 is written while tile k is multiplied -> one barrier per k-step
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -145,21 +146,21 @@ shared_mlp_kernel(const MlpParams p)
             rb[i] = v;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
         constexpr int A_TOTAL = BK * BM / 4;
 #pragma unroll
         for (int i = 0; i < (A_F4 > 0 ? A_F4 : 1); ++i) {
             const int f = tid + i * BLK;
             if (f < A_TOTAL) {
                 const int kr = f / (BM / 4), mc = (f % (BM / 4)) * 4;
-                *reinterpret_cast<float4*>(&As[kr][mc]) = ra[i];
+                *reinterpret_cast<float4*>(&As[buf][kr][mc]) = ra[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int f = tid + i * BLK;
             const int kr = f / (BN / 4), nc = (f % (BN / 4)) * 4;
-            *reinterpret_cast<float4*>(&Bs[kr][nc]) = rb[i];
+            *reinterpret_cast<float4*>(&Bs[buf][kr][nc]) = rb[i];
         }
     };
 
@@ -177,24 +178,29 @@ shared_mlp_kernel(const MlpParams p)
     const int bn = wn * (TN * 32) + l31;
 
     load_tiles(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();            // previous tile fully consumed
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK < kend) load_tiles(k0 + BK);   // next tile's HBM/L2 latency hides under the MFMAs
+    store_tiles(0);
+    __syncthreads();
+    if (kbeg + BK < kend) load_tiles(kbeg + BK);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
+        // stage k+1 goes to the other LDS buffer (its last readers passed the previous barrier),
+        // the global loads of stage k+2 stay in flight under this stage's MFMAs
+        if (k0 + BK < kend) store_tiles(buf ^ 1);
+        if (k0 + 2 * BK < kend) load_tiles(k0 + 2 * BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[TM], bb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kk + kh][am + i * 32];
+            for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + kh][am + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bb[j] = Bs[kk + kh][bn + j * 32];
+            for (int j = 0; j < TN; ++j) bb[j] = Bs[buf][kk + kh][bn + j * 32];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
     }
 
     // epilogue: bias + gathered term + activation; for a fixed accumulator register the 32 lanes

@@ -109,3 +109,39 @@ def test_batch_items_are_independent(device):
     for k in full:   # MIOpen may pick another algorithm per batch size: compare at range scale
         scale = float(full[k].abs().max())
         assert float((full[k][1:2] - single[k]).abs().max()) <= 1e-3 * scale, k
+
+
+def test_training_step_gradients_match_plain_torch(device):
+    """Config-3 path (DDP training) on one rank: gradients through the custom operators' backward
+    kernels (scatter-add / arg-max / softmax backward) inside the whole network must equal the
+    gradients plain torch autograd produces for the same forward (oracle/forward_ref.py)."""
+    from oracle import forward_ref
+    frames = synth.make_batch(7, 2, n_points=1024, height=120, width=160)
+    net = build(5, 1024, device)          # eval(): BatchNorm uses running statistics in both paths
+    inputs = pyramid.frames_to_device(frames, device)
+    names = ["rndla_ds_stages.0.lfa.mlp1.conv.weight", "rndla_ds_stages.2.lfa.att_pooling_1.fc.weight",
+             "ds_fuse_r2p_pre_layers.1.conv.weight", "ds_fuse_p2r_pre_layers.0.conv.weight",
+             "rndla_up_stages.1.conv.weight", "cnn_ds_stages.0.0.conv1.weight", "rndla_pre_stages.conv.weight"]
+    params = dict(net.named_parameters())
+
+    def loss_of(ep):
+        return sum((v.float() ** 2).mean() for v in ep.values())
+
+    net.zero_grad()
+    with torch.enable_grad():
+        loss = loss_of(net(inputs))
+    loss.backward()
+    ours = {n: params[n].grad.detach().clone() for n in names}
+
+    sd = {k: v.detach().clone().requires_grad_(k in params) for k, v in net.state_dict().items()}
+    with torch.enable_grad():
+        ref_loss = loss_of(forward_ref.ffb6d_forward(sd, inputs))
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss))
+    for n in names:
+        g, r = ours[n], sd[n].grad
+        scale = float(r.abs().max())
+        assert scale > 0, n
+        err = float((g - r).abs().max()) / scale
+        print(n, "grad max rel err", err)
+        assert err <= 1e-3, (n, err)
