@@ -215,6 +215,13 @@ def main():
         value = args.batch * world * args.steps / elapsed
         pyr_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["pyramid"]]))
         fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["forward"]]))
+        # split the shared-MLP launches by the kernel instantiation rocprofv3 lists them under:
+        # shared_mlp_kernel<BM, FLAT>, BM by Cout, FLAT for small per-frame P (csrc/shared_mlp.hip)
+        for rec in tracer.records.pop("shared_mlp", []):
+            k, cout, pcols = rec[3]
+            bm = 128 if cout > 64 else (64 if cout > 32 else 32)
+            flat = pcols < 2048 and pcols % 4 == 0
+            tracer.records.setdefault("shared_mlp<%d,%s>" % (bm, "flat" if flat else "frame"), []).append(rec)
         summary = tracer.summary()
         # dominant hand-written op of the timed steps.  KNN is latency/VALU bound (10.7 MB of
         # algorithmic bytes per frame) and is reported through hot_path_ops instead.
@@ -228,14 +235,15 @@ def main():
             pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc_file):      # HBM bytes per launch measured offline with rocprofv3 --pmc
                 with open(pmc_file) as fh:
-                    traffic = json.load(fh).get(roof_op, {}).get("hbm_bytes_per_launch")
+                    traffic = json.load(fh).get(roof_op.split("<")[0], {}).get("hbm_bytes_per_launch")
             sec = summ["total_ms"] * 1e-3
-            if roof_op == "shared_mlp":
+            if roof_op.startswith("shared_mlp"):
                 # fp32 MFMA GEMM: tag = (K, Cout, P) per frame
                 flops = sum(2.0 * args.batch * t[0] * t[1] * t[2] for _, _, _, t in tracer.records[roof_op])
                 ach = flops / sec / 1e12
                 roofline = {"bound": "mfma", "achieved": ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / VALU_PEAK_TFLOPS, "traffic": traffic, "kernel": "shared_mlp_kernel (fp32 MFMA 32x32x2)",
+                            "frac": ach / VALU_PEAK_TFLOPS, "traffic": traffic,
+                            "kernel": roof_op.replace("shared_mlp", "shared_mlp_kernel") + " (fp32 MFMA 32x32x2)",
                             "launches_per_step": summ["launches"] / args.steps, "avg_launch_us": summ["avg_us"],
                             "algorithmic_flops_per_step": flops / args.steps,
                             "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
