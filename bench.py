@@ -235,7 +235,8 @@ def main():
             pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc_file):      # HBM bytes per launch measured offline with rocprofv3 --pmc
                 with open(pmc_file) as fh:
-                    traffic = json.load(fh).get(roof_op.split("<")[0], {}).get("hbm_bytes_per_launch")
+                    table = json.load(fh)
+                    traffic = table.get(roof_op, table.get(roof_op.split("<")[0], {})).get("hbm_bytes_per_launch")
             sec = summ["total_ms"] * 1e-3
             if roof_op.startswith("shared_mlp"):
                 # fp32 MFMA GEMM: tag = (K, Cout, P) per frame
