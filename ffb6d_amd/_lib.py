@@ -37,6 +37,7 @@ SIGNATURES = {
     "ffb6d_att_pool_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_shared_mlp_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i64, _vp, _i64,
                                     _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
+    "ffb6d_att_score_pool_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_shared_mlp_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "ffb6d_bilinear_resize_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_affine_act_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _c.c_float, _vp]),

@@ -56,7 +56,36 @@ __device__ __forceinline__ float activate(float v, int act)
 }
 
 // WM x WN waves; each wave owns TM x TN MFMA tiles of 32x32
-template <int BM, bool FLAT>
+// all-reduce inside a DPP row of 16 lanes with row rotations (row_ror:8,4,2,1): VALU-rate, no
+// LDS-crossbar traffic; every lane ends up with the reduction over its row
+template <int ROR>
+__device__ __forceinline__ float row_ror(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + ROR, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v)
+{
+    v = fmaxf(v, row_ror<8>(v));
+    v = fmaxf(v, row_ror<4>(v));
+    v = fmaxf(v, row_ror<2>(v));
+    v = fmaxf(v, row_ror<1>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
+    return v;
+}
+
+// ATT: attentive-pooling epilogue (RandLANet.py:243-248).  The GEMM is the score matrix
+// A = W_fc * S over the feature set S = [x1 ; x2] ([d, N*16] per frame, 16 neighbours of a point in
+// 16 consecutive columns); instead of storing A the epilogue forms softmax over each 16-column
+// group, multiplies with S's own row m and writes the pooled [d, N] tensor.  A 16-column group is
+// one 16-lane DPP row of the accumulator layout, so both reductions are 4 row shuffles.
+template <int BM, bool FLAT, bool ATT = false>
 __global__ void __launch_bounds__(BLK)
 shared_mlp_kernel(const MlpParams p)
 {
@@ -205,6 +234,31 @@ shared_mlp_kernel(const MlpParams p)
 
     // epilogue: bias + gathered term + activation; for a fixed accumulator register the 32 lanes
     // of a half-wave hold 32 consecutive p of one output row -> 128-byte coalesced stores
+    if constexpr (ATT) {
+        // out = pooled [B, cout, P/16]; every 32-column MFMA tile holds two complete points
+        float* out = p.out + (size_t)b * p.out_bs;
+        const int npts = p.P >> 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = p0 + wn * (TN * 32) + j * 32 + l31;
+            const bool in = col < p.P;                       // P % 16 == 0: a row of 16 lanes is in or out together
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const bool ok = in && m < p.cout;
+                    const float a = ok ? acc[i][j][r] : 0.f;
+                    float f = 0.f;
+                    if (ok) f = (m < p.k1) ? x1[(size_t)m * p.P + col] : x2[(size_t)(m - p.k1) * p.P + col];
+                    const float e = expf(a - row16_max(a));
+                    const float pooled = row16_sum(f * (e / row16_sum(e)));
+                    if (ok && (l31 & 15) == 0) out[(size_t)m * npts + (col >> 4)] = pooled;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = p0 + wn * (TN * 32) + j * 32 + l31;
@@ -295,6 +349,33 @@ MlpPlan plan_mlp(int64_t B, int64_t cout, int64_t K, int64_t P)
 }  // namespace ffb6d
 
 using namespace ffb6d;
+
+extern "C" int ffb6d_att_score_pool_f32(const float* wt, const float* x1, int64_t k1, const float* x2, int64_t k2,
+                                        float* out, int64_t B, int64_t N, int K, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(K == 16, "att_score_pool: K must be 16 (got %d)", K);
+    FFB6D_REQUIRE(B >= 0 && N >= 0 && k1 >= 1 && k2 >= 0, "att_score_pool: bad shape");
+    if (B == 0 || N == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(wt && x1 && out && ((k2 == 0) == (x2 == nullptr)), "att_score_pool: null pointer");
+    const int64_t d = k1 + k2, P = N * 16;
+    FFB6D_REQUIRE(P < (1LL << 31) && d < (1 << 20) && B < 65536, "att_score_pool: too large");
+    MlpParams p;
+    p.wt = wt; p.bias = nullptr; p.x1 = x1; p.x2 = x2; p.yg = nullptr; p.gidx = nullptr; p.out = out;
+    p.x1_bs = k1 * P; p.x2_bs = k2 * P; p.yg_bs = 0; p.out_bs = d * N;
+    p.k1 = (int)k1; p.k2 = (int)k2; p.cout = (int)d; p.P = (int)P; p.py = 0; p.act = 0; p.idx64 = 0;
+    p.nb = (int)B; p.kchunk = (int)d; p.part = nullptr;
+    hipStream_t st = as_stream(stream);
+    const unsigned gx = (unsigned)ceil_div(P, BN);
+    if (d > 64) {
+        hipLaunchKernelGGL((shared_mlp_kernel<128, false, true>), dim3(gx, (unsigned)ceil_div(d, 128), (unsigned)B), dim3(BLK), 0, st, p);
+    } else if (d > 32) {
+        hipLaunchKernelGGL((shared_mlp_kernel<64, false, true>), dim3(gx, 1, (unsigned)B), dim3(BLK), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((shared_mlp_kernel<32, false, true>), dim3(gx, 1, (unsigned)B), dim3(BLK), 0, st, p);
+    }
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
 
 extern "C" size_t ffb6d_shared_mlp_workspace_bytes(int64_t B, int64_t cout, int64_t K, int64_t P)
 {

@@ -145,6 +145,8 @@ class AttPooling(nn.Module):
         w = self.fc.weight
         if getattr(self, "_fct", None) is None or self._fct[0] is not w:
             self._fct = (w, w.detach().reshape(w.shape[0], -1).t().contiguous())
+        if f_nei.shape[3] == 16:    # score GEMM with the softmax pooling in its epilogue
+            return self.mlp.fused(ops.att_score_pool(f_nei, f_xyz, self._fct[1]))
         att = ops.shared_mlp(f_nei, self._fct[1], None, ops.ACT_NONE, x2=f_xyz)
         return self.mlp.fused(ops.att_pool2(f_nei, f_xyz, att))
 

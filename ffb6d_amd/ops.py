@@ -343,6 +343,27 @@ def shared_mlp(x1, wt, bias=None, act=ACT_NONE, x2=None, gather=None):
     return out.view(B, Cout, *x1.shape[2:])
 
 
+def att_score_pool(f_nei, f_xyz, fc_wt):
+    """Att_pooling up to the pooled tensor with the score GEMM fused in (inference only):
+    scores = fc(cat(f_nei, f_xyz)); returns sum_k cat(f_nei, f_xyz) * softmax_k(scores) as [B,d,N,1].
+    f_nei [B,d1,N,16], f_xyz [B,d2,N,16], fc_wt = fc.weight^T [d1+d2, d1+d2]."""
+    _need_gpu(f_nei, f_xyz, fc_wt)
+    lib = _lib.load()
+    a, b = _f32(f_nei.detach()), _f32(f_xyz.detach())
+    B, d1, N, K = a.shape
+    d2 = b.shape[1]
+    if b.shape != (B, d2, N, K) or fc_wt.shape != (d1 + d2, d1 + d2) or not fc_wt.is_contiguous():
+        raise ValueError(f"bad shapes {tuple(a.shape)} / {tuple(b.shape)} / {tuple(fc_wt.shape)}")
+    out = torch.empty((B, d1 + d2, N), dtype=torch.float32, device=a.device)
+    d = d1 + d2
+    nbytes = 4 * (d * d + B * d * N * K + B * d * N)
+    with torch.cuda.device(a.device), _lib.traced("att_score_pool", nbytes, (d, N)):
+        rc = lib.ffb6d_att_score_pool_f32(fc_wt.data_ptr(), a.data_ptr(), d1, b.data_ptr(), d2, out.data_ptr(),
+                                          B, N, K, _stream(a))
+    _lib.check(rc, "ffb6d_att_score_pool_f32")
+    return out.unsqueeze(3)
+
+
 def bilinear_resize(x, size, align_corners):
     """x [B,C,IH,IW] float32 -> [B,C,OH,OW], bilinear, the two conventions of the colour branch
     (pspnet.py:24-28 align_corners=False; pspnet.py:37-42 align_corners=True).  Inference only

@@ -109,6 +109,13 @@ int ffb6d_shared_mlp_f32(const float* wt, const float* bias, const float* x1, in
  * K loop is split across workgroups and reduced by a second kernel). */
 size_t ffb6d_shared_mlp_workspace_bytes(int64_t B, int64_t cout, int64_t K, int64_t P);
 
+/* Attentive pooling with the score GEMM fused in (Att_pooling.forward, RandLANet.py:243-248, up to
+ * the pooled tensor): scores = W_fc * S over the feature set S = cat(x1 [B,k1,N,16], x2 [B,k2,N,16]),
+ * out[b,m,n] = sum_k S[b,m,n,k] * softmax_k(scores[b,m,n,:]).  wt = W_fc transposed [k1+k2, k1+k2];
+ * the [B,d,N,16] score tensor is never written.  K must be 16. */
+int ffb6d_att_score_pool_f32(const float* wt, const float* x1, int64_t k1, const float* x2, int64_t k2,
+                             float* out, int64_t B, int64_t N, int K, ffb6d_stream_t stream);
+
 /* Bilinear resize of `planes` = B*C independent [IH,IW] float32 images to [OH,OW], the two
  * flavours the colour branch uses: align_corners = 0 (F.upsample(size=...), pspnet.py:24-28) and
  * align_corners = 1 (nn.Upsample(scale_factor=2, align_corners=True), pspnet.py:37-42).

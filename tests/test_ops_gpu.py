@@ -255,3 +255,17 @@ def test_psp_pool_and_prior_sum_match_torch(device):
                                                       mode="bilinear", align_corners=False)
         off += s * s
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,d1,d2,N", [(2, 16, 16, 3072), (1, 32, 32, 300), (2, 64, 64, 48), (1, 128, 128, 192), (1, 8, 24, 7)])
+def test_att_score_pool_equals_unfused_attentive_pooling(device, B, d1, d2, N):
+    g = torch.Generator().manual_seed(d1 + N)
+    f1 = torch.randn(B, d1, N, 16, generator=g)
+    f2 = torch.randn(B, d2, N, 16, generator=g)
+    w = torch.randn(d1 + d2, d1 + d2, generator=g) / (d1 + d2) ** 0.5          # fc.weight [out, in]
+    fs = torch.cat([f1, f2], dim=1)
+    att = torch.einsum("oi,binx->bonx", w.double(), fs.double())
+    want = (fs.double() * torch.softmax(att, dim=3)).sum(dim=3, keepdim=True).float()
+    got = ops.att_score_pool(f1.to(device), f2.to(device), w.t().contiguous().to(device)).cpu()
+    assert got.shape == (B, d1 + d2, N, 1)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
