@@ -45,6 +45,7 @@ struct MlpParams {
     int k1, k2, cout, P, py, act, idx64;
     // flat mode (small P): tile columns run over all frames, c = b*P + p; blockIdx.z = K split
     int nb, kchunk;       // frames; k range per split (multiple of BK)
+    int col_tiles, nz;    // grid decode: blockIdx.x = col_tile + col_tiles * z, z = frame (or K split when flat)
     float* part;          // [nsplit, cout, nb*P] partial sums when nsplit > 1
 };
 
@@ -101,11 +102,18 @@ shared_mlp_kernel(const MlpParams p)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int b = FLAT ? 0 : blockIdx.z;
+    // XCD-aware tile order: hardware sends workgroup i to XCD i % 8 (MI355X: 8 XCDs, private L2s).
+    // gridDim.x is padded to a multiple of 8 and enumerates (column tile, frame / K-split) pairs,
+    // gridDim.y the row tiles, so all row tiles that read the SAME activation columns carry the
+    // same blockIdx.x and therefore share one XCD's L2 (the weight tiles are small and replicated).
+    const int ncol_tiles = p.col_tiles;
+    if ((int)blockIdx.x >= ncol_tiles * p.nz) return;
+    const int bz = blockIdx.x / ncol_tiles;
+    const int b = FLAT ? 0 : bz;
     const int m0 = blockIdx.y * BM;
-    const int p0 = blockIdx.x * BN;
+    const int p0 = (blockIdx.x - bz * ncol_tiles) * BN;
     const int K = p.k1 + p.k2;
-    const int kbeg = FLAT ? blockIdx.z * p.kchunk : 0;
+    const int kbeg = FLAT ? bz * p.kchunk : 0;
     const int kend = FLAT ? min(K, kbeg + p.kchunk) : K;
     const int ncols = FLAT ? p.nb * p.P : p.P;          // columns of this launch's N dimension
     const float* x1 = p.x1 + (size_t)b * p.x1_bs;
@@ -216,18 +224,28 @@ shared_mlp_kernel(const MlpParams p)
         // the global loads of stage k+2 stay in flight under this stage's MFMAs
         if (k0 + BK < kend) store_tiles(buf ^ 1);
         if (k0 + 2 * BK < kend) load_tiles(k0 + 2 * BK);
+        // fragment double buffering: the LDS reads of step kk+2 are in flight under the MFMAs of kk
+        float a[2][TM], bb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[buf][kh][am + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bb[0][j] = Bs[buf][kh][bn + j * 32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], bb[TN];
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + kh][am + i * 32];
+                for (int i = 0; i < TM; ++i) a[nxt][i] = As[buf][kk + 2 + kh][am + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bb[j] = Bs[buf][kk + kh][bn + j * 32];
+                for (int j = 0; j < TN; ++j) bb[nxt][j] = Bs[buf][kk + 2 + kh][bn + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -264,7 +282,7 @@ shared_mlp_kernel(const MlpParams p)
         const int col = p0 + wn * (TN * 32) + j * 32 + l31;
         if (col >= ncols) continue;
         if (FLAT && p.part) {       // K is split: raw partial sums, reduced by shared_mlp_reduce_kernel
-            float* dst = p.part + (size_t)blockIdx.z * p.cout * ncols + col;
+            float* dst = p.part + (size_t)bz * p.cout * ncols + col;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -366,12 +384,14 @@ extern "C" int ffb6d_att_score_pool_f32(const float* wt, const float* x1, int64_
     p.nb = (int)B; p.kchunk = (int)d; p.part = nullptr;
     hipStream_t st = as_stream(stream);
     const unsigned gx = (unsigned)ceil_div(P, BN);
+    p.col_tiles = (int)gx; p.nz = (int)B;
+    const unsigned gxz = (gx * (unsigned)B + 7u) / 8u * 8u;
     if (d > 64) {
-        hipLaunchKernelGGL((shared_mlp_kernel<128, false, true>), dim3(gx, (unsigned)ceil_div(d, 128), (unsigned)B), dim3(BLK), 0, st, p);
+        hipLaunchKernelGGL((shared_mlp_kernel<128, false, true>), dim3(gxz, (unsigned)ceil_div(d, 128), 1), dim3(BLK), 0, st, p);
     } else if (d > 32) {
-        hipLaunchKernelGGL((shared_mlp_kernel<64, false, true>), dim3(gx, 1, (unsigned)B), dim3(BLK), 0, st, p);
+        hipLaunchKernelGGL((shared_mlp_kernel<64, false, true>), dim3(gxz, 1, 1), dim3(BLK), 0, st, p);
     } else {
-        hipLaunchKernelGGL((shared_mlp_kernel<32, false, true>), dim3(gx, 1, (unsigned)B), dim3(BLK), 0, st, p);
+        hipLaunchKernelGGL((shared_mlp_kernel<32, false, true>), dim3(gxz, 1, 1), dim3(BLK), 0, st, p);
     }
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
@@ -419,9 +439,11 @@ extern "C" int ffb6d_shared_mlp_f32(const float* wt, const float* bias, const fl
     }
     const unsigned gx = (unsigned)ceil_div(pl.flat ? B * P : P, BN);
     const unsigned gz = pl.flat ? (unsigned)pl.nsplit : (unsigned)B;
+    p.col_tiles = (int)gx; p.nz = (int)gz;
+    const unsigned gxz = (gx * gz + 7u) / 8u * 8u;       // multiple of the XCD count
 #define FFB6D_LAUNCH_MLP(BMV)                                                                              \
     do {                                                                                                   \
-        const dim3 grid(gx, (unsigned)ceil_div(cout, BMV), gz);                                            \
+        const dim3 grid(gxz, (unsigned)ceil_div(cout, BMV), 1);                                            \
         if (pl.flat) hipLaunchKernelGGL((shared_mlp_kernel<BMV, true>), grid, dim3(BLK), 0, st, p);        \
         else hipLaunchKernelGGL((shared_mlp_kernel<BMV, false>), grid, dim3(BLK), 0, st, p);               \
     } while (0)
