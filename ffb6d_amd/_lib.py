@@ -44,6 +44,7 @@ SIGNATURES = {
     "ffb6d_channel_log_softmax_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "ffb6d_psp_pool_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "ffb6d_psp_prior_sum_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "ffb6d_depth_to_cloud_f32": (_i32, [_vp, _vp, _c.c_float, _vp, _i64, _i64, _i64, _vp]),
     "ffb6d_check_index_range": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
 }
 

@@ -145,6 +145,12 @@ int ffb6d_psp_pool_f32(const float* x, float* out, int64_t planes, int64_t H, in
 int ffb6d_psp_prior_sum_f32(const float* z, float* out, int64_t planes, int64_t H, int64_t W,
                             const int* sizes, int nsizes, ffb6d_stream_t stream);
 
+/* Depth image -> xyz image, the dataset's dpt_2_pcld (linemod_dataset.py:188-199,258-259) on the device:
+ * depth [B,H,W] f32 (raw units), K [B,3,3] f64 row-major intrinsics, out [B,3,H,W] f32 (x,y,z planes),
+ * invalid depth (<= 1e-8 after scaling) and NaN/Inf -> (0,0,0).  float32/float64 mix as numpy there. */
+int ffb6d_depth_to_cloud_f32(const float* depth, const double* K, float cam_scale, float* out,
+                             int64_t B, int64_t H, int64_t W, ffb6d_stream_t stream);
+
 /* Debug helper: number of entries of idx[0:count] outside [0, M) written to *bad (device int32). */
 int ffb6d_check_index_range(const void* idx, int idx_bits, int64_t count, int64_t M,
                             int32_t* bad, ffb6d_stream_t stream);

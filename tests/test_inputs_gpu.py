@@ -1,0 +1,61 @@
+"""GPU parity of the on-device input pipeline against the numpy
+restatement of the dataset code (oracle/inputs_ref.py)."""
+import numpy as np
+import pytest
+import torch
+
+from ffb6d_amd import inputs, synth
+from oracle import inputs_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _depth(seed, h=120, w=160):
+    rng = np.random.RandomState(seed)
+    d = (1000.0 * (1.0 + 0.3 * rng.rand(h, w))).astype(np.float32)     # millimetres
+    d[rng.rand(h, w) < 0.07] = 0.0
+    d[3, 5] = np.nan
+    d[4, 6] = np.inf
+    return d
+
+
+def test_depth_to_cloud_is_bit_exact(device):
+    K = synth.LINEMOD_K
+    deps = np.stack([_depth(1), _depth(2)])
+    want = np.stack([inputs_ref.dpt_2_pcld(d, 1000.0, K).astype(np.float32).transpose(2, 0, 1) for d in deps])
+    got = inputs.depth_to_cloud(torch.from_numpy(deps).to(device), K, cam_scale=1000.0).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert (got[:, :, 3, 5] == 0).all() and (got[:, :, 4, 6] == 0).all()
+
+
+def test_sample_choose_properties(device):
+    d = torch.from_numpy(np.stack([_depth(3), _depth(4)])).to(device)
+    g = torch.Generator(device=device).manual_seed(5)
+    ch = inputs.sample_choose(d, 2048, generator=g)
+    assert ch.shape == (2, 1, 2048) and ch.dtype == torch.int64
+    for b in range(2):
+        pix = ch[b, 0]
+        assert (d[b].reshape(-1)[pix] > 1e-6).all()            # only valid pixels
+        assert pix.unique().numel() == 2048                      # without replacement
+        assert not torch.equal(pix, pix.sort().values)           # shuffled
+    few = torch.zeros(1, 60, 80, device=device)
+    few.view(-1)[:500] = 1.0
+    ch = inputs.sample_choose(few, 1024)                          # wrap padding
+    assert set(ch.unique().tolist()) == set(range(500))
+    with pytest.raises(ValueError):
+        inputs.sample_choose(torch.zeros(1, 60, 80, device=device), 128)
+
+
+def test_assemble_inputs_feeds_the_model(device):
+    rng = np.random.RandomState(0)
+    deps = torch.from_numpy(np.stack([_depth(7), _depth(8)])).to(device)
+    deps = torch.nan_to_num(deps, nan=0.0, posinf=0.0)
+    rgb = torch.from_numpy(rng.randint(0, 256, (2, 3, 120, 160)).astype(np.uint8)).to(device)
+    nrm = torch.from_numpy(rng.randn(2, 3, 120, 160).astype(np.float32)).to(device)
+    d = inputs.assemble_inputs(rgb, deps, nrm, synth.LINEMOD_K, 1024, cam_scale=1000.0)
+    assert d['cld_rgb_nrm'].shape == (2, 9, 1024) and d['cld_xyz0'].shape == (2, 1024, 3)
+    flat = d['dpt_xyz'].reshape(2, 3, -1)
+    assert torch.equal(d['cld_rgb_nrm'][:, :3], torch.gather(flat, 2, d['choose'].expand(2, 3, 1024)))
+    assert torch.equal(d['cld_xyz0'], d['cld_rgb_nrm'][:, :3].transpose(1, 2))
+    for k in ('cld_nei_idx0', 'r2p_ds_nei_idx3', 'p2r_up_nei_idx2'):
+        assert k in d

@@ -142,3 +142,16 @@ def test_oracle_forward_matches_reference_small_golden():
         scale = float(np.abs(gold[k]).max())
         err = float(np.abs(ep[k].numpy() - gold[k]).max())
         assert err <= 1e-5 * max(scale, 1.0), (k, err, scale)
+
+
+def test_depth_backprojection_restatement_matches_the_frame_generator():
+    """oracle/inputs_ref.dpt_2_pcld (line-by-line restatement of linemod_dataset.py:188-199; the
+    dataset module itself cannot be imported here: cv2/normalSpeed are absent) must agree with the
+    back-projection inside ffb6d_amd.synth.make_frame, which every golden frame went through."""
+    from oracle import inputs_ref
+    f = synth.make_frame(2000, n_points=1024, height=120, width=160)
+    want = inputs_ref.dpt_2_pcld(f["dpt_xyz"][2], 1.0, synth.LINEMOD_K).astype(np.float32).transpose(2, 0, 1)
+    np.testing.assert_array_equal(want, f["dpt_xyz"])
+    z = f["dpt_xyz"][2].copy()
+    z[0, 0] = np.nan
+    assert (inputs_ref.dpt_2_pcld(z, 1.0, synth.LINEMOD_K)[0, 0] == 0).all()
