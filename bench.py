@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--trace-all", action="store_true", help="extra untimed pass: per-op table to stderr")
     ap.add_argument("--cudnn-benchmark", type=int, default=1,
                     help="torch.backends.cudnn.benchmark (MIOpen find mode for the colour branch's dense convs)")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer (default, the BASELINE metric): pyramid + forward, eval, no_grad.  train: BASELINE "
+                         "config 3 shape -- pyramid + forward + backward + Adam step in train() mode, wrapped in "
+                         "DistributedDataParallel (RCCL gradient all-reduce) when launched with more than one rank")
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
@@ -146,7 +150,15 @@ def main():
     sd = state_dict(args.n_classes)
     net = model.FFB6D(n_classes=args.n_classes, n_pts=args.n_points)
     net.load_state_dict(sd)
-    net = net.to(dev).eval()
+    net = net.to(dev)
+    train = args.mode == "train"
+    opt = None
+    if train:
+        net.train()
+        ddp = distributed.wrap_ddp(net, dev) if world > 1 else net     # RCCL all-reduce of 33.85 M fp32 grads
+        opt = torch.optim.Adam(net.parameters(), lr=1e-5)              # train_lm.py:596
+    else:
+        net.eval()
 
     # per-rank batch, resident in HBM before the timed region: rank r holds samples
     # [r*batch, (r+1)*batch) of the config-2 synthetic stream (seeds 1000*2 + sample)
@@ -169,7 +181,17 @@ def main():
         inputs.update(rgb=rgb, cld_rgb_nrm=cld_rgb_nrm, choose=choose)
         if record:
             e1.record()
-        out = net(inputs)
+        if train:
+            # proxy objective (the reference's focal + L1 offset losses need labels that synthetic
+            # frames do not have); it touches all three heads so every parameter gets a gradient
+            opt.zero_grad(set_to_none=True)
+            with torch.enable_grad():
+                out = ddp(inputs)
+                loss = sum((v.float() ** 2).mean() for v in out.values())
+            loss.backward()
+            opt.step()
+        else:
+            out = net(inputs)
         if record:
             e2.record()
             phase["pyramid"].append((e0, e1))
@@ -264,10 +286,13 @@ def main():
             sec = summary["knn"]["total_ms"] * 1e-3
             ops_table["knn"]["bruteforce_equivalent_Gpairs_per_s"] = pairs / sec / 1e9
         line = {
-            "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC if not train else "RGB-D frames/sec train step (fwd+bwd+Adam, 480x640, N=12288, bs=8/GPU)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "FFB6D forward incl. on-device 22-call KNN index pyramid; "
+            "config": {"workload": ("FFB6D forward" if not train else "FFB6D training step (forward + backward + Adam, "
+                                    "train-mode BatchNorm, DDP gradient all-reduce when n_gpus > 1)") +
+                                   " incl. on-device 22-call KNN index pyramid; "
                                    f"bs={args.batch}/GPU, N={args.n_points} pts, 480x640 RGB-D, "
                                    f"{args.n_classes} classes, fp32, eval",
                        "global_batch": args.batch * world, "n_points": args.n_points,
@@ -277,7 +302,7 @@ def main():
             "roofline": roofline,
             "hot_path_ops": ops_table,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not train:
             line["cpu_baseline"] = cpu_baseline(args, sd)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)

@@ -31,8 +31,20 @@ WORKER = textwrap.dedent("""
         time.sleep(0.02 * (1 + g.rank))          # rank 1 is the slow one
     elapsed = D.timed_steps(step, warmup=2, steps=3, group=g)
     total = g.sum_over_ranks(float(frames["cld"].sum()))
+    # DDP gradient all-reduce (BASELINE config 3 recipe, train_lm.py:625-628) through wrap_ddp
+    import torch
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(3, 2)
+    ddp = D.wrap_ddp(lin, torch.device("cpu"))
+    x = torch.from_numpy(frames["cld"][0][:16])
+    ddp(x).pow(2).mean().backward()
+    grad = lin.weight.grad.flatten().tolist()
+    local = torch.nn.Linear(3, 2)
+    local.load_state_dict({k: v.clone() for k, v in lin.state_dict().items()})
+    local(x).pow(2).mean().backward()
     out = dict(rank=g.rank, world=g.world, elapsed=elapsed, calls=calls,
-               first_seed_check=float(frames["cld"][0].sum()), total=total)
+               first_seed_check=float(frames["cld"][0].sum()), total=total, grad=grad,
+               local_grad=local.weight.grad.flatten().tolist())
     print("RESULT " + json.dumps(out), flush=True)
     g.close()
 """) % ROOT
@@ -64,6 +76,11 @@ def test_two_rank_gloo_harness(tmp_path):
         want = synth.make_frame(synth.frame_seed(3, 2 * r["rank"]), n_points=256, height=60, width=80)
         assert abs(r["first_seed_check"] - float(want["cld"].sum())) < 1e-3
     assert abs(res[0]["total"] - res[1]["total"]) < 1e-6   # SUM all-reduce agrees
+    # DDP: both ranks end up with the SAME gradient = mean of the two local gradients
+    np.testing.assert_allclose(res[0]["grad"], res[1]["grad"], rtol=1e-6, atol=1e-7)
+    mean = (np.array(res[0]["local_grad"]) + np.array(res[1]["local_grad"])) / 2
+    np.testing.assert_allclose(res[0]["grad"], mean, rtol=1e-5, atol=1e-6)
+    assert not np.allclose(res[0]["local_grad"], res[1]["local_grad"])   # ranks really saw different frames
 
 
 def test_single_process_group_is_a_noop():
