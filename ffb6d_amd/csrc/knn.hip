@@ -19,13 +19,16 @@
 //     blockIdx.y and the per-split sorted lists are merged by a second tiny kernel
 //     (splits are merged in index order, preserving the lowest-index tie rule).
 //
-// Roofline: VALU-bound (8 f32 ops + compare per pair; 926 M pairs per 480x640 frame),
-// algorithmic HBM traffic is ~10.7 MB/frame.
+// Since knn_pruned.hip exists this scan only serves SMALL support sets (< 2048 points; larger ones
+// are Morton-prepared and searched with tile pruning) and the host-pointer cpp_knn* entry points
+// route through ffb6d_knn_batch_device, i.e. through whichever kernel fits the shape.
+//
+// Roofline: VALU-bound (8 f32 ops + compare per pair), algorithmic HBM traffic is ~10.7 MB/frame
+// (SURVEY.md section 8d).
 #include "common.h"
 
 #include <cfloat>
 #include <cmath>
-#include <vector>
 
 namespace ffb6d {
 namespace {

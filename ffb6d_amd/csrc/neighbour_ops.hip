@@ -23,12 +23,6 @@ namespace {
 
 constexpr int BLK = 256;
 
-template <typename IdxT>
-__device__ __forceinline__ int ld_idx(const IdxT* __restrict__ p, size_t i)
-{
-    return (int)p[i];
-}
-
 // ------------------------------------------------------------------------------------
 // random_sample: out[b,c,n] = max_k feat[b,c,idx[b,n,k]]
 // lanes run over n (contiguous in out and in idx rows); each lane keeps its K indices in
