@@ -133,6 +133,13 @@ def main():
     args = parse()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env > 1:
+        # one MIOpen find-db / kernel cache per rank: N ranks tuning the same convolutions at the same
+        # time would otherwise contend for the lock of one sqlite user database
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", f"/tmp/ffb6d_miopen_db_rank{local_rank}")
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/ffb6d_miopen_cache_rank{local_rank}")
+        for d in (os.environ["MIOPEN_USER_DB_PATH"], os.environ["MIOPEN_CUSTOM_CACHE_DIR"]):
+            os.makedirs(d, exist_ok=True)
     if world_env != args.gpus and world_env > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     if not torch.cuda.is_available():

@@ -59,6 +59,49 @@ random_sample_kernel(const float* __restrict__ feat, const IdxT* __restrict__ id
     }
 }
 
+// K = 16, inference (no arg-max needed): a ROW of 16 lanes owns one output point, lane r gathers
+// neighbour r.  For the pixel->point fusion the 16 neighbours of a point are a ~4x4 pixel patch, so
+// the 16 addresses of a row fall into 4-5 cache lines instead of 16 different ones (one lane per
+// point makes every lane of a gather hit its own line); the max over the row is four row_ror DPP
+// steps.  Lane (c & 15) keeps the result of channel c, so results leave as one store per 16 channels.
+__device__ __forceinline__ float row16_max_dpp(float v)
+{
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));  // row_ror:8
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));  // row_ror:4
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)));  // row_ror:2
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)));  // row_ror:1
+    return v;
+}
+
+template <typename IdxT>
+__global__ void __launch_bounds__(BLK)
+random_sample_row16_kernel(const float* __restrict__ feat, const IdxT* __restrict__ idx,
+                           float* __restrict__ out, int C, int M, int Np, int cc)
+{
+    const int r = threadIdx.x & 15;
+    const int n = blockIdx.x * (BLK / 16) + (threadIdx.x >> 4);
+    const int b = blockIdx.z;
+    const bool valid = n < Np;
+    const int my = valid ? (int)idx[((size_t)b * Np + n) * 16 + r] : 0;
+    const int c0 = blockIdx.y * cc;
+    const int c1 = min(C, c0 + cc);
+    const float* base = feat + (size_t)b * C * M + my;
+    float* obase = out + (size_t)b * C * Np + n;
+    for (int cb = c0; cb < c1; cb += 16) {
+        float keep = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = cb + j;
+            float v = -INFINITY;
+            if (c < c1) v = base[(size_t)c * M];
+            const float m = row16_max_dpp(v);
+            if (j == r) keep = m;
+        }
+        const int c = cb + r;
+        if (valid && c < c1) obase[(size_t)c * Np] = keep;
+    }
+}
+
 // any K (indices re-read per channel; they stay L1/L2 resident)
 template <typename IdxT>
 __global__ void __launch_bounds__(BLK)
@@ -427,7 +470,17 @@ int ffb6d_random_sample_f32(const float* feat, const void* idx, int idx_bits, fl
     hipStream_t st = as_stream(stream);
     DISPATCH_IDX(idx_bits, IdxT, {
         const IdxT* ip = static_cast<const IdxT*>(idx);
-        if (K == 16)
+        // the row layout pays when the 16 neighbours of a point are close in memory (image sources:
+        // M = h*w >> Np); for the shuffled cloud (pooling a level onto its first quarter, M = 4*Np) every
+        // neighbour sits in its own line either way and one lane per point issues fewer reductions
+        if (K == 16 && arg == nullptr && M > 4 * Np) {
+            const int64_t rtiles = ceil_div(Np, BLK / 16);
+            int rcc = pick_cc(rtiles, B, C);
+            rcc = (rcc + 15) / 16 * 16;                        // whole groups of 16 channels
+            dim3 rgrid((unsigned)rtiles, (unsigned)ceil_div(C, rcc), (unsigned)B);
+            hipLaunchKernelGGL((random_sample_row16_kernel<IdxT>), rgrid, dim3(BLK), 0, st, feat, ip, out,
+                               (int)C, (int)M, (int)Np, rcc);
+        } else if (K == 16)
             hipLaunchKernelGGL((random_sample_kernel<IdxT, 16>), grid, dim3(BLK), 0, st, feat, ip,
                                out, arg, (int)C, (int)M, (int)Np, cc);
         else
