@@ -58,6 +58,9 @@ def parse():
                     help="infer (default, the BASELINE metric): pyramid + forward, eval, no_grad.  train: BASELINE "
                          "config 3 shape -- pyramid + forward + backward + Adam step in train() mode, wrapped in "
                          "DistributedDataParallel (RCCL gradient all-reduce) when launched with more than one rank")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL, one GPU per rank) for real runs; gloo lets several ranks share one GPU "
+                         "to exercise the multi-process path on a single-GPU box")
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
@@ -144,12 +147,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    if args.dist_backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
 
     from ffb6d_amd import _lib, distributed, model, ops, pyramid, synth
-    group = distributed.init_from_env(backend="nccl", device=dev)   # nccl == RCCL on ROCm
+    group = distributed.init_from_env(backend=args.dist_backend, device=dev)   # nccl == RCCL on ROCm
     rank, world = group.rank, group.world
     _lib.load()
     idt = torch.int64 if args.index_dtype == "int64" else torch.int32
