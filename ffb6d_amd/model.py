@@ -460,9 +460,112 @@ class FFB6D(nn.Module):
         y = ops.shared_mlp(p_emb, wb, None, ops.ACT_NONE)
         return ops.shared_mlp(skip, wa, bias, stage.act_code, gather=(y, interp_idx))
 
+    # ------------------------------------------------------------------------------------------
+    # Two-stream inference.  Within a stage the colour branch (MIOpen convolutions: few, large,
+    # MFMA-bound launches) and the point branch (many small gather / pooling / GEMM launches) are
+    # independent until the fusion step, and the two fusion directions read the pre-fusion tensors
+    # (ffb6d.py:245-262), so they are independent too.  Running the point side on a second HIP stream
+    # hides most of it under the convolutions:
+    #     main:  CNN_i ---------------> [join] p2r (pixel GEMM) ----------> CNN_i+1 ...
+    #     side:  LFA_i + pooling -----> [join] r2p (gather-max + GEMMs) --> LFA_i+1 ...
+    # Tensors crossing streams are handed over with events and record_stream().
+    # ------------------------------------------------------------------------------------------
+    two_streams = True
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._side = st
+        return st
+
+    def _forward_two_streams(self, inputs, end_points):
+        dev = inputs['rgb'].device
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev)
+        side.wait_stream(main)                      # inputs (and the index pyramid) come from `main`
+
+        def handover(t, producer, consumer):
+            """tensor produced on `producer`, about to be read on `consumer`"""
+            ev = torch.cuda.Event()
+            ev.record(producer)
+            consumer.wait_event(ev)
+            t.record_stream(consumer)
+            return t
+
+        def fuse(i, pre_p2r, fuse_p2r, pre_r2p, fuse_r2p, rgb_emb0, p_emb0, p2r_idx, r2p_idx):
+            bs, c, hr, wr = rgb_emb0.shape
+            handover(p_emb0, side, main)
+            handover(rgb_emb0, main, side)
+            p2r_idx.record_stream(main)
+            # p2r on main (see _fuse for the algebra)
+            e = pre_p2r[i].fused(p_emb0)
+            wa, wb, bias = fuse_p2r[i].split(c)
+            y = ops.shared_mlp(e, wb, None, ops.ACT_NONE)
+            rgb_emb = ops.shared_mlp(rgb_emb0, wa, bias, fuse_p2r[i].act_code, gather=(y, p2r_idx))
+            with torch.cuda.stream(side):
+                r2p = pre_r2p[i].fused(ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx))
+                p_emb = fuse_r2p[i].fused(p_emb0, x2=r2p)
+            return rgb_emb, p_emb
+
+        # stem
+        y = ops.affine_act_(self.cnn_pre_stages[0](inputs['rgb']), *ops.bn_fold(self.cnn_pre_stages[1]),
+                            act=ops.ACT_RELU)
+        rgb_emb = self.cnn_pre_stages[3](y)
+        with torch.cuda.stream(side):
+            p_emb = self.rndla_pre_stages(inputs['cld_rgb_nrm']).unsqueeze(3)
+
+        ds_emb = []
+        for i in range(4):
+            rgb_emb0 = self.cnn_ds_stages[i](rgb_emb)
+            with torch.cuda.stream(side):
+                f_enc = self.rndla_ds_stages[i](p_emb, inputs['cld_xyz%d' % i], inputs['cld_nei_idx%d' % i])
+                p_emb0 = ops.random_sample(f_enc, inputs['cld_sub_idx%d' % i])
+            if i == 0:
+                ds_emb.append(f_enc)
+            rgb_emb, p_emb = fuse(i, self.ds_fuse_p2r_pre_layers, self.ds_fuse_p2r_fuse_layers,
+                                  self.ds_fuse_r2p_pre_layers, self.ds_fuse_r2p_fuse_layers, rgb_emb0, p_emb0,
+                                  inputs['p2r_ds_nei_idx%d' % i], inputs['r2p_ds_nei_idx%d' % i])
+            ds_emb.append(p_emb)
+
+        n_up = len(self.rndla_up_stages)
+        for i in range(n_up - 1):
+            rgb_emb0 = self.cnn_up_stages[i](rgb_emb)
+            with torch.cuda.stream(side):
+                p_emb0 = self._decode(self.rndla_up_stages[i], ds_emb[-i - 2], p_emb,
+                                      inputs['cld_interp_idx%d' % (n_up - i - 1)])
+            rgb_emb, p_emb = fuse(i, self.up_fuse_p2r_pre_layers, self.up_fuse_p2r_fuse_layers,
+                                  self.up_fuse_r2p_pre_layers, self.up_fuse_r2p_fuse_layers, rgb_emb0, p_emb0,
+                                  inputs['p2r_up_nei_idx%d' % i], inputs['r2p_up_nei_idx%d' % i])
+
+        rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
+        with torch.cuda.stream(side):
+            p_emb = self._decode(self.rndla_up_stages[n_up - 1], ds_emb[0], p_emb,
+                                 inputs['cld_interp_idx0']).squeeze(-1)
+        handover(p_emb, side, main)                 # also the final join: main is behind all side work
+
+        bs = rgb_emb.shape[0]
+        rgb_emb_c = ops.choose_gather(rgb_emb, inputs['choose'])
+
+        def head(seq):
+            y = seq[0].fused(rgb_emb_c, x2=p_emb)
+            for layer in list(seq)[1:]:
+                y = layer.fused(y)
+            return y
+
+        end_points['pred_rgbd_segs'] = head(self.rgbd_seg_layer)
+        end_points['pred_kp_ofs'] = head(self.kp_ofst_layer).view(
+            bs, self.n_kps, 3, -1).permute(0, 1, 3, 2).contiguous()
+        end_points['pred_ctr_ofs'] = head(self.ctr_ofst_layer).view(
+            bs, 1, 3, -1).permute(0, 1, 3, 2).contiguous()
+        return end_points
+
     def forward(self, inputs, end_points=None, scale=1):
         if not end_points:
             end_points = {}
+        rgb = inputs['rgb']
+        if self.two_streams and not _autograd_path(rgb) and (rgb.shape[2] * rgb.shape[3]) % 16 == 0:
+            return self._forward_two_streams(inputs, end_points)
         if _autograd_path(inputs['rgb']) or (inputs['rgb'].shape[2] * inputs['rgb'].shape[3]) % 16:
             rgb_emb = self.cnn_pre_stages(inputs['rgb'])
         else:   # stem: conv7x7 -> [BN+ReLU in one pass] -> maxpool

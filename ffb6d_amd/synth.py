@@ -168,3 +168,62 @@ def synth_state_dict_from_shapes(shapes, seed=0, n_classes=None):
         a = synth_tensor(src, shape, seed)
         out[name] = torch.from_numpy(a)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# Pose-solver cases: what FFB6D.forward hands to
+# cal_frame_poses[_lm] (ffb6d/utils/pvn3d_eval_utils_kpls.py:65-158,220-285), synthesised:
+# objects = rigidly placed blobs of the cloud, votes = true offsets + noise + outliers.
+# --------------------------------------------------------------------------------------
+def random_rotation(rng):
+    q = rng.randn(4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def make_pose_case(seed, n_pts=2048, n_obj=2, n_kps=8, n_cls=None, noise=0.004, outliers=0.1,
+                   label_noise=0.02, bg_frac=0.3):
+    """Returns a dict of numpy arrays:
+      pcld f32[N,3], mask i64[N] (0 = background, 1..n_obj), ctr_of f32[1,N,3], kp_of f32[n_kps,N,3]
+      mesh_kps f32[n_cls,n_kps,3], mesh_ctr f32[n_cls,3] (row = class id, row 0 unused),
+      r_lst f32[n_cls-1] object radii, RT f64[n_cls,3,4] the true poses."""
+    rng = np.random.RandomState(seed)
+    n_cls = n_cls or n_obj + 1
+    mesh_kps = (rng.rand(n_cls, n_kps, 3).astype(np.float32) - 0.5) * 0.2
+    mesh_ctr = (rng.rand(n_cls, 3).astype(np.float32) - 0.5) * 0.02
+    r_lst = (0.08 + 0.05 * rng.rand(n_cls - 1)).astype(np.float32)
+    RT = np.zeros((n_cls, 3, 4))
+    pcld = np.zeros((n_pts, 3), np.float32)
+    mask = np.zeros((n_pts,), np.int64)
+    ctr_of = np.zeros((1, n_pts, 3), np.float32)
+    kp_of = np.zeros((n_kps, n_pts, 3), np.float32)
+    owner = rng.choice(n_obj + 1, size=n_pts, p=[bg_frac] + [(1 - bg_frac) / n_obj] * n_obj)
+    for c in range(1, n_obj + 1):
+        R = random_rotation(rng)
+        t = np.array([0.5 * (c - (n_obj + 1) / 2), 0.1 * rng.randn(), 1.0 + 0.2 * rng.rand()])
+        RT[c, :, :3], RT[c, :, 3] = R, t
+    for i in range(n_pts):
+        c = owner[i]
+        if c == 0:
+            pcld[i] = [rng.uniform(-1, 1), rng.uniform(-0.6, 0.6), rng.uniform(0.6, 1.6)]
+            ctr_of[0, i] = 0.2 * rng.randn(3)
+            kp_of[:, i] = 0.2 * rng.randn(n_kps, 3)
+            continue
+        R, t = RT[c, :, :3], RT[c, :, 3]
+        local = rng.randn(3)
+        local *= 0.07 * rng.rand() ** (1 / 3) / np.linalg.norm(local)
+        p = R @ local + t
+        pcld[i] = p
+        mask[i] = c
+        ctr_of[0, i] = p - (R @ mesh_ctr[c] + t) + noise * rng.randn(3)
+        kp_of[:, i] = p[None] - (mesh_kps[c] @ R.T + t) + noise * rng.randn(n_kps, 3)
+        if rng.rand() < outliers:
+            ctr_of[0, i] += 0.15 * rng.randn(3)
+            kp_of[:, i] += 0.15 * rng.randn(n_kps, 3)
+    flip = rng.rand(n_pts) < label_noise                      # segmentation mistakes
+    mask[flip] = rng.randint(0, n_obj + 1, size=int(flip.sum()))
+    return dict(pcld=pcld, mask=mask, ctr_of=ctr_of.astype(np.float32), kp_of=kp_of.astype(np.float32),
+                mesh_kps=mesh_kps, mesh_ctr=mesh_ctr, r_lst=r_lst, RT=RT)

@@ -147,3 +147,51 @@ def reference_modules():
     finally:
         os.chdir(cwd)
     return m_ffb6d, m_randla, helper_tool
+
+
+def reference_pose_modules(mesh_kps=None, mesh_ctr=None, r_lst=None):
+    """(utils.meanshift_pytorch, utils.pvn3d_eval_utils_kpls) of the reference, importable on this
+    CPU-only image through harness-side shims (nothing in the reference is edited):
+      4. `cv2`, `plyfile`, `normalSpeed` (meanshift_pytorch.py:3, basic_utils.py:8-9: display, mesh
+         files and normal estimation -- none is on the pose-solver path) -> empty stub modules;
+      5. `torch.Tensor.cuda` -> identity, so `torch.zeros(...).cuda()` (pvn3d_eval_utils_kpls.py:79,235)
+         stays on the CPU;
+      6. the module-level `bs_utils` / `bs_utils_lm` / `config.ycb_r_lst` (dataset-file readers,
+         pvn3d_eval_utils_kpls.py:18-25) -> objects serving the synthetic mesh keypoints handed in:
+         mesh_kps [n_cls,n_kps,3], mesh_ctr [n_cls,3] indexed by class id; r_lst[cls_id-1]."""
+    install()
+    import torch
+    for name in ("cv2", "plyfile", "normalSpeed"):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.imshow = mod.waitKey = lambda *a, **k: None
+            mod.PlyData = object
+            sys.modules[name] = mod
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    cwd = os.getcwd()
+    os.chdir(REF_FFB6D)
+    try:
+        import utils.meanshift_pytorch as ms_mod
+        import utils.pvn3d_eval_utils_kpls as pose_mod
+    finally:
+        os.chdir(cwd)
+
+    class _Mesh:
+        def __init__(self, by_name):
+            self.by_name = by_name
+
+        def _cls(self, key):
+            return pose_mod.cls_lst.index(key) + 1 if self.by_name else int(key)
+
+        def get_kps(self, key, **kw):
+            return np.asarray(mesh_kps[self._cls(key)], np.float32).copy()
+
+        def get_ctr(self, key, **kw):
+            return np.asarray(mesh_ctr[self._cls(key)], np.float32).copy()
+
+    if mesh_kps is not None:
+        pose_mod.bs_utils = _Mesh(by_name=True)          # YCB path looks objects up by name (:149-152)
+        pose_mod.bs_utils_lm = _Mesh(by_name=False)      # LineMOD path by obj_id (:277-280)
+    if r_lst is not None:
+        pose_mod.config.ycb_r_lst = list(np.asarray(r_lst, np.float64))
+    return ms_mod, pose_mod

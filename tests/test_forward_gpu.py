@@ -96,6 +96,25 @@ def test_forward_full_size_matches_reference_sample(device):
         assert err <= 2 * err_plain + HOT_TOL   # we add nothing on top of the MIOpen-vs-CPU gap
 
 
+def test_two_stream_forward_equals_single_stream(device):
+    """The point branch runs on a second HIP stream under the colour branch's convolutions
+    (model.FFB6D._forward_two_streams); same kernels, same order per tensor -> same bits.
+    Repeated so that a missing event / record_stream shows up as a race."""
+    frames = synth.make_batch(3, 2, n_points=12288, height=480, width=640)
+    net = build(22, 12288, device)
+    inputs = pyramid.frames_to_device(frames, device)
+    with torch.no_grad():
+        net.two_streams = False
+        want = {k: v.clone() for k, v in net(inputs).items()}
+        net.two_streams = True
+        for rep in range(4):
+            got = net(inputs)
+            junk = torch.empty(64 << 20, device=device).fill_(float("nan"))    # recycle freed blocks
+            del junk
+            for k in want:
+                assert torch.equal(got[k], want[k]), (rep, k, float((got[k] - want[k]).abs().max()))
+
+
 def test_batch_items_are_independent(device):
     """Every op on the path is per-sample in eval mode: a frame's
     result must not depend on its batch neighbours -- the property multi-GPU sharding relies on."""
