@@ -46,6 +46,14 @@ SIGNATURES = {
     "ffb6d_psp_prior_sum_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "ffb6d_depth_to_cloud_f32": (_i32, [_vp, _vp, _c.c_float, _vp, _i64, _i64, _i64, _vp]),
     "ffb6d_check_index_range": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
+    # include/ffb6d_pose.h
+    "ffb6d_vote_sets_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _vp]),
+    "ffb6d_mean_shift_workspace_bytes": (_sz, [_i32, _i64]),
+    "ffb6d_mean_shift_f32": (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _c.c_float, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+                                    _sz, _vp]),
+    "ffb6d_set_labels_to_points": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "ffb6d_refine_mask_by_center": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "ffb6d_best_fit_transform_f32": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
 }
 
 _LIB = None

@@ -1,0 +1,547 @@
+// ffb6d_amd/csrc/pose.hip -- gfx950 pose solver (include/ffb6d_pose.h).
+//
+// The reference runs MeanShiftTorch.fit (ffb6d/utils/meanshift_pytorch.py:27-58) once per object
+// centre and once per keypoint, each call materialising [M,M,3] / [M,M] temporaries per round and
+// synchronising with the host for the stopping test.  Here every (frame, object, keypoint) vote set
+// of a batch is one row of a [G, set_stride] float4 table and one launch advances all of them by one
+// round:
+//   * a 256-thread block owns 64 points of one set; 4 lanes share a point and each takes a quarter
+//     of the set, which is streamed through LDS in 512-point tiles (same-address LDS reads
+//     broadcast, 4 distinct addresses per wavefront -> conflict free);
+//   * the Gaussian weight is one v_exp_f32: exp(-0.5 (d/bw)^2) = 2^(d^2 * k), k = -0.5 log2(e)/bw^2;
+//     the normalising constant of the reference's kernel cancels in the weighted mean;
+//   * the stopping test stays on the device: round t publishes its largest move with atomicMax
+//     into slot t%3, reads slot (t-1)%3 to know whether its set already stopped (then the launch is
+//     a no-op for that set) and clears slot (t+1)%3.
+// fp32 throughout like the reference; results differ from it by summation order and exp rounding
+// only (tests/test_pose_gpu.py states the tolerance).
+#include <vector>
+
+#include "common.h"
+#include "ffb6d_pose.h"
+
+namespace {
+
+using ffb6d::ceil_div;
+
+constexpr int kBlock = 256;
+constexpr int kLanesPerPoint = 4;
+constexpr int kPointsPerBlock = kBlock / kLanesPerPoint;   // 64
+constexpr int kTile = 512;
+constexpr float kFar = 1.0e15f;                            // padding point: weight underflows to 0
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// workspace tail: shift [3][G] float bits of the largest move of round t in slot t%3; rounds [G]
+// rounds made; best [G] (ball size << 32) | (0xffffffff - point index)
+
+__device__ __forceinline__ void load_tile(float4* tile, const float4* src, int j0, int cnt) {
+    for (int x = threadIdx.x; x < kTile; x += kBlock) {
+        const int j = j0 + x;
+        tile[x] = j < cnt ? src[j] : make_float4(kFar, kFar, kFar, 0.f);
+    }
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// one mean-shift round for every set (meanshift_pytorch.py:38-46).  The pair loop is written on
+// 2-wide vectors so that it compiles to packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two pairs per
+// instruction); the tile is kept as three planes in LDS so a lane fetches two neighbours per b64 read.
+__global__ __launch_bounds__(kBlock) void mean_shift_round_kernel(
+    float4* __restrict__ buf0, float4* __restrict__ buf1, const int* __restrict__ counts, int sets_per_count,
+    int64_t stride, float k2, float thresh, unsigned* __restrict__ shift, int* __restrict__ rounds, int t, int G) {
+#pragma clang fp contract(fast)
+    __shared__ __attribute__((aligned(16))) float tx[kTile], ty[kTile], tz[kTile];
+    __shared__ float wmax[kBlock / 64];
+    const int g = blockIdx.y;
+    const int cnt = counts[g / sets_per_count];
+    bool done = false;
+    if (t > 0) done = __uint_as_float(shift[((t + 2) % 3) * G + g]) < thresh;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        shift[((t + 1) % 3) * G + g] = 0u;
+        if (!done && cnt > 0) rounds[g] = t + 1;
+    }
+    const int q0 = blockIdx.x * kPointsPerBlock;
+    if (done || q0 >= cnt) return;
+    const float4* src = ((t & 1) ? buf1 : buf0) + g * stride;
+    float4* dst = ((t & 1) ? buf0 : buf1) + g * stride;
+    const int sub = threadIdx.x & (kLanesPerPoint - 1);
+    const int q = q0 + (threadIdx.x >> 2);
+    const float4 c = src[min(q, cnt - 1)];
+    const v2f cx = {c.x, c.x}, cy = {c.y, c.y}, cz = {c.z, c.z}, kk = {k2, k2};
+    v2f sw = {0.f, 0.f}, sx = {0.f, 0.f}, sy = {0.f, 0.f}, sz = {0.f, 0.f};
+    for (int j0 = 0; j0 < cnt; j0 += kTile) {
+        __syncthreads();
+        for (int x = threadIdx.x; x < kTile; x += kBlock) {
+            const int j = j0 + x;
+            const float4 p = j < cnt ? src[j] : make_float4(kFar, kFar, kFar, 0.f);
+            tx[x] = p.x;
+            ty[x] = p.y;
+            tz[x] = p.z;
+        }
+        __syncthreads();
+        const int n = min(kTile, (cnt - j0 + 7) & ~7);
+#pragma unroll 2
+        for (int x = 2 * sub; x < n; x += 2 * kLanesPerPoint) {
+            const v2f px = *reinterpret_cast<const v2f*>(&tx[x]);
+            const v2f py = *reinterpret_cast<const v2f*>(&ty[x]);
+            const v2f pz = *reinterpret_cast<const v2f*>(&tz[x]);
+            const v2f dx = px - cx, dy = py - cy, dz = pz - cz;
+            const v2f e = (dx * dx + dy * dy + dz * dz) * kk;
+            v2f w;
+            w.x = __builtin_amdgcn_exp2f(e.x);
+            w.y = __builtin_amdgcn_exp2f(e.y);
+            sw += w;
+            sx += w * px;
+            sy += w * py;
+            sz += w * pz;
+        }
+    }
+    float aw = sw.x + sw.y, ax = sx.x + sx.y, ay = sy.x + sy.y, az = sz.x + sz.y;
+#pragma unroll
+    for (int o = 1; o < kLanesPerPoint; o <<= 1) {
+        aw += __shfl_xor(aw, o);
+        ax += __shfl_xor(ax, o);
+        ay += __shfl_xor(ay, o);
+        az += __shfl_xor(az, o);
+    }
+    float move = 0.f;
+    if (q < cnt) {
+        const float nx = ax / aw, ny = ay / aw, nz = az / aw;
+        if (sub == 0) dst[q] = make_float4(nx, ny, nz, c.w);
+        const float ex = nx - c.x, ey = ny - c.y, ez = nz - c.z;
+        move = sqrtf(ex * ex + ey * ey + ez * ez);
+        if (!(move == move)) move = __uint_as_float(0x7f800000u);   // NaN never counts as converged
+    }
+    move = wave_max(move);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = move;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = wmax[0];
+        for (int i = 1; i < kBlock / 64; ++i) m = fmaxf(m, wmax[i]);
+        atomicMax(&shift[(t % 3) * G + g], __float_as_uint(m));
+    }
+}
+
+// ball size of every converged point, arg-max with ties to the lowest index (:50-53)
+__global__ __launch_bounds__(kBlock) void ball_count_kernel(
+    const float4* __restrict__ buf0, const float4* __restrict__ buf1, const int* __restrict__ counts,
+    int sets_per_count, int64_t stride, float bandwidth, const int* __restrict__ rounds,
+    unsigned long long* __restrict__ best) {
+    __shared__ float4 tile[kTile];
+    __shared__ unsigned long long wbest[kBlock / 64];
+    const int g = blockIdx.y;
+    const int cnt = counts[g / sets_per_count];
+    const int q0 = blockIdx.x * kPointsPerBlock;
+    if (q0 >= cnt) return;
+    const float4* src = ((rounds[g] & 1) ? buf1 : buf0) + g * stride;
+    const int sub = threadIdx.x & (kLanesPerPoint - 1);
+    const int q = q0 + (threadIdx.x >> 2);
+    const float4 c = src[min(q, cnt - 1)];
+    int inside = 0;
+    for (int j0 = 0; j0 < cnt; j0 += kTile) {
+        __syncthreads();
+        load_tile(tile, src, j0, cnt);
+        __syncthreads();
+        const int n = min(kTile, (cnt - j0 + 7) & ~7);
+        for (int x = sub; x < n; x += kLanesPerPoint) {
+            const float4 p = tile[x];
+            const float dx = c.x - p.x, dy = c.y - p.y, dz = c.z - p.z;
+            inside += sqrtf(dx * dx + dy * dy + dz * dz) < bandwidth;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < kLanesPerPoint; o <<= 1) inside += __shfl_xor(inside, o);
+    unsigned long long key = 0ull;
+    if (q < cnt) key = (static_cast<unsigned long long>(inside) << 32) | (0xffffffffu - static_cast<unsigned>(q));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / 64; ++i) key = wbest[i] > key ? wbest[i] : key;
+        key = wbest[0] > key ? wbest[0] : key;
+        atomicMax(&best[g], key);
+    }
+}
+
+// centre = winning point, labels = membership of its ball (:54)
+__global__ __launch_bounds__(kBlock) void ball_labels_kernel(
+    const float4* __restrict__ buf0, const float4* __restrict__ buf1, const int* __restrict__ counts,
+    int sets_per_count, int64_t stride, float bandwidth, const int* __restrict__ rounds,
+    const unsigned long long* __restrict__ best, float* __restrict__ centers, unsigned char* __restrict__ labels,
+    int* __restrict__ n_inside, int* __restrict__ iters) {
+    const int g = blockIdx.y;
+    const int cnt = counts[g / sets_per_count];
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (lead && iters) iters[g] = rounds[g];
+    if (cnt <= 0) {
+        if (lead) {
+            centers[3 * g] = centers[3 * g + 1] = centers[3 * g + 2] = 0.f;
+            if (n_inside) n_inside[g] = 0;
+        }
+        return;
+    }
+    const float4* src = ((rounds[g] & 1) ? buf1 : buf0) + g * stride;
+    const unsigned long long key = best[g];
+    const int win = static_cast<int>(0xffffffffu - static_cast<unsigned>(key & 0xffffffffull));
+    const float4 c = src[win];
+    if (lead) {
+        centers[3 * g] = c.x;
+        centers[3 * g + 1] = c.y;
+        centers[3 * g + 2] = c.z;
+        if (n_inside) n_inside[g] = static_cast<int>(key >> 32);
+    }
+    if (labels && j < stride) {
+        unsigned char lab = 0;
+        if (j < cnt) {
+            const float4 p = src[j];
+            const float dx = c.x - p.x, dy = c.y - p.y, dz = c.z - p.z;
+            lab = sqrtf(dx * dx + dy * dy + dz * dz) < bandwidth;
+        }
+        labels[g * stride + j] = lab;
+    }
+}
+
+template <typename MaskT>
+__global__ __launch_bounds__(kBlock) void vote_sets_kernel(
+    const float* __restrict__ pcld, const float* __restrict__ offsets, const MaskT* __restrict__ mask,
+    const unsigned char* __restrict__ keep, const int* __restrict__ frame_of, const int* __restrict__ class_of,
+    int S, int N, int64_t stride, float4* __restrict__ sets, int* __restrict__ counts) {
+    __shared__ int wave_total[kBlock / 64];
+    const int p = blockIdx.x;
+    const int b = frame_of[p];
+    const MaskT cls = static_cast<MaskT>(class_of[p]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int i0 = 0; i0 < N; i0 += kBlock) {
+        const int i = i0 + threadIdx.x;
+        bool sel = false;
+        if (i < N) sel = mask[static_cast<int64_t>(b) * N + i] == cls && (!keep || keep[static_cast<int64_t>(b) * N + i]);
+        const unsigned long long bal = __ballot(sel);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wave_total[wave] = __popcll(bal);
+        __syncthreads();
+        int pos = base + before;
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            if (w < wave) pos += wave_total[w];
+            total += wave_total[w];
+        }
+        if (sel) {
+            const float* pt = pcld + (static_cast<int64_t>(b) * N + i) * 3;
+            const float px = pt[0], py = pt[1], pz = pt[2];
+            for (int s = 0; s < S; ++s) {
+                const float* of = offsets + ((static_cast<int64_t>(b) * S + s) * N + i) * 3;
+                sets[(static_cast<int64_t>(p) * S + s) * stride + pos] =
+                    make_float4(px - of[0], py - of[1], pz - of[2], __int_as_float(i));
+            }
+        }
+        base += total;
+    }
+    if (threadIdx.x == 0) counts[p] = base;
+}
+
+__global__ void labels_to_points_kernel(const float4* __restrict__ sets, const unsigned char* __restrict__ labels,
+                                        const int* __restrict__ counts, const int* __restrict__ frame_of,
+                                        int64_t stride, int N, unsigned char* __restrict__ keep) {
+    const int p = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= counts[p]) return;
+    const int i = __float_as_int(sets[p * stride + j].w);
+    keep[static_cast<int64_t>(frame_of[p]) * N + i] = labels[p * stride + j];
+}
+
+template <typename MaskT>
+__global__ void refine_mask_kernel(const float* __restrict__ pcld, const float* __restrict__ ctr_of,
+                                   const MaskT* __restrict__ mask, const float* __restrict__ centers,
+                                   const int* __restrict__ class_of, const int* __restrict__ pair_begin,
+                                   const float* __restrict__ max_dist, int N, MaskT* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int64_t at = static_cast<int64_t>(b) * N + i;
+    MaskT m = mask[at];
+    const int p0 = pair_begin[b], p1 = pair_begin[b + 1];
+    if (m > 0 && p1 > p0) {
+        const float vx = pcld[at * 3] - ctr_of[at * 3], vy = pcld[at * 3 + 1] - ctr_of[at * 3 + 1],
+                    vz = pcld[at * 3 + 2] - ctr_of[at * 3 + 2];
+        float dmin = __uint_as_float(0x7f800000u);
+        int pmin = p0;
+        for (int p = p0; p < p1; ++p) {
+            const float dx = vx - centers[3 * p], dy = vy - centers[3 * p + 1], dz = vz - centers[3 * p + 2];
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            if (d < dmin) {
+                dmin = d;
+                pmin = p;
+            }
+        }
+        if (dmin < max_dist[pmin]) m = static_cast<MaskT>(class_of[pmin]);
+    }
+    out[at] = m;
+}
+
+// ---- 3x3 Kabsch in double, one thread per problem --------------------------------------------
+__device__ void jacobi_eigen3(double a[3][3], double v[3][3]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) v[i][j] = i == j;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(a[p][q]) < 1e-300) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < 3; ++k) {      // A <- A J
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 3; ++k) {      // A <- J^T A
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = cs * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+}
+
+__device__ inline void cross3(const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__device__ inline double normalize3(double* a) {
+    const double n = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (n > 0) {
+        a[0] /= n;
+        a[1] /= n;
+        a[2] /= n;
+    }
+    return n;
+}
+
+// any unit vector orthogonal to u
+__device__ inline void any_orthogonal(const double* u, double* o) {
+    const int k = fabs(u[0]) <= fabs(u[1]) ? (fabs(u[0]) <= fabs(u[2]) ? 0 : 2) : (fabs(u[1]) <= fabs(u[2]) ? 1 : 2);
+    double e[3] = {0, 0, 0};
+    e[k] = 1;
+    cross3(u, e, o);
+    normalize3(o);
+}
+
+__global__ void best_fit_kernel(const float* __restrict__ model, const float* __restrict__ found, int P, int n,
+                                double* __restrict__ T) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float* A = model + static_cast<int64_t>(p) * n * 3;
+    const float* Bm = found + static_cast<int64_t>(p) * n * 3;
+    double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            ca[k] += A[3 * i + k];
+            cb[k] += Bm[3 * i + k];
+        }
+    for (int k = 0; k < 3; ++k) {
+        ca[k] /= n;
+        cb[k] /= n;
+    }
+    double H[3][3] = {};                       // H = AA^T BB (:49)
+    for (int i = 0; i < n; ++i)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) H[r][c] += (A[3 * i + r] - ca[r]) * (Bm[3 * i + c] - cb[c]);
+    // H = U S V^T: eigenvectors of H^T H give V; u_k = H v_k / s_k
+    double M[3][3], V[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[r][c] = H[0][r] * H[0][c] + H[1][r] * H[1][c] + H[2][r] * H[2][c];
+    jacobi_eigen3(M, V);
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (M[order[j]][order[j]] > M[order[i]][order[i]]) {
+                const int tmp = order[i];
+                order[i] = order[j];
+                order[j] = tmp;
+            }
+    double v[3][3], u[3][3];                   // rows = singular vectors, largest first
+    for (int k = 0; k < 3; ++k)
+        for (int r = 0; r < 3; ++r) v[k][r] = V[r][order[k]];
+    for (int k = 0; k < 2; ++k)
+        for (int r = 0; r < 3; ++r) u[k][r] = H[r][0] * v[k][0] + H[r][1] * v[k][1] + H[r][2] * v[k][2];
+    const double s1 = normalize3(u[0]);
+    if (!(s1 > 0)) {                           // H = 0: any rotation is optimal, return the identity
+        u[0][0] = v[0][0] = 1; u[0][1] = u[0][2] = v[0][1] = v[0][2] = 0;
+        u[1][1] = v[1][1] = 1; u[1][0] = u[1][2] = v[1][0] = v[1][2] = 0;
+    } else {
+        const double proj = u[1][0] * u[0][0] + u[1][1] * u[0][1] + u[1][2] * u[0][2];
+        for (int r = 0; r < 3; ++r) u[1][r] -= proj * u[0][r];
+        const double s2 = normalize3(u[1]);
+        if (!(s2 > 1e-12 * s1)) any_orthogonal(u[0], u[1]);   // rank 1: the plane is free
+    }
+    // third pair by right-handedness on both sides == the reference's det(R) < 0 correction (:53-56):
+    // R = V diag(1, 1, det(V U^T)) U^T does not depend on the sign choice of u3 / v3
+    cross3(u[0], u[1], u[2]);
+    cross3(v[0], v[1], v[2]);
+    double R[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R[r][c] = v[0][r] * u[0][c] + v[1][r] * u[1][c] + v[2][r] * u[2][c];
+    double* out = T + static_cast<int64_t>(p) * 12;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) out[4 * r + c] = R[r][c];
+        out[4 * r + 3] = cb[r] - (R[r][0] * ca[0] + R[r][1] * ca[1] + R[r][2] * ca[2]);
+    }
+}
+
+size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+}  // namespace
+
+extern "C" {
+
+int ffb6d_vote_sets_f32(const float* pcld, const float* offsets, const void* mask, int mask_bits,
+                        const unsigned char* keep, const int* frame_of, const int* class_of, int n_pairs, int B,
+                        int S, int N, int64_t set_stride, float* sets, int* counts, ffb6d_stream_t stream) {
+    FFB6D_REQUIRE(n_pairs >= 0 && B > 0 && S > 0 && N > 0, "vote_sets: bad sizes n_pairs=%d B=%d S=%d N=%d", n_pairs, B, S, N);
+    FFB6D_REQUIRE(mask_bits == 32 || mask_bits == 64, "vote_sets: mask_bits must be 32 or 64, got %d", mask_bits);
+    FFB6D_REQUIRE(set_stride >= N, "vote_sets: set_stride %lld < N %d", (long long)set_stride, N);
+    if (n_pairs == 0) return 0;
+    FFB6D_REQUIRE(pcld && offsets && mask && frame_of && class_of && sets && counts, "vote_sets: null pointer");
+    hipStream_t st = ffb6d::as_stream(stream);
+    if (mask_bits == 64)
+        vote_sets_kernel<int64_t><<<n_pairs, kBlock, 0, st>>>(pcld, offsets, static_cast<const int64_t*>(mask), keep,
+                                                               frame_of, class_of, S, N, set_stride,
+                                                               reinterpret_cast<float4*>(sets), counts);
+    else
+        vote_sets_kernel<int32_t><<<n_pairs, kBlock, 0, st>>>(pcld, offsets, static_cast<const int32_t*>(mask), keep,
+                                                               frame_of, class_of, S, N, set_stride,
+                                                               reinterpret_cast<float4*>(sets), counts);
+    FFB6D_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t ffb6d_mean_shift_workspace_bytes(int G, int64_t set_stride) {
+    if (G <= 0 || set_stride <= 0) return 0;
+    return 2 * align256(static_cast<size_t>(G) * set_stride * sizeof(float4)) + align256(3 * sizeof(unsigned) * G) +
+           align256(sizeof(int) * G) + align256(sizeof(unsigned long long) * G);
+}
+
+int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_count, int G, int64_t set_stride,
+                         int64_t max_count, float bandwidth, int max_iter, int check_every, float* centers,
+                         unsigned char* labels,
+                         int* n_inside, int* iters, void* workspace, size_t workspace_bytes, ffb6d_stream_t stream) {
+    FFB6D_REQUIRE(G >= 0 && set_stride > 0 && sets_per_count > 0, "mean_shift: bad sizes G=%d stride=%lld", G,
+                  (long long)set_stride);
+    FFB6D_REQUIRE(bandwidth > 0.f && max_iter >= 0 && check_every >= 0, "mean_shift: bad bandwidth/max_iter");
+    FFB6D_REQUIRE(max_count >= 0 && max_count <= set_stride, "mean_shift: max_count %lld outside [0, set_stride]",
+                  (long long)max_count);
+    if (G == 0) return 0;
+    FFB6D_REQUIRE(sets && counts && centers, "mean_shift: null pointer");
+    const size_t need = ffb6d_mean_shift_workspace_bytes(G, set_stride);
+    if (!workspace || workspace_bytes < need)
+        return ffb6d::set_error(FFB6D_ERR_WORKSPACE, "mean_shift: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = ffb6d::as_stream(stream);
+    char* w = static_cast<char*>(workspace);
+    const size_t buf_bytes = align256(static_cast<size_t>(G) * set_stride * sizeof(float4));
+    float4* buf0 = reinterpret_cast<float4*>(w);
+    float4* buf1 = reinterpret_cast<float4*>(w + buf_bytes);
+    char* tail = w + 2 * buf_bytes;
+    unsigned* shift = reinterpret_cast<unsigned*>(tail);
+    int* rounds = reinterpret_cast<int*>(tail + align256(3 * sizeof(unsigned) * G));
+    unsigned long long* best =
+        reinterpret_cast<unsigned long long*>(tail + align256(3 * sizeof(unsigned) * G) + align256(sizeof(int) * G));
+    FFB6D_HIP_TRY(hipMemsetAsync(tail, 0, need - 2 * buf_bytes, st));
+    FFB6D_HIP_TRY(hipMemcpyAsync(buf0, sets, static_cast<size_t>(G) * set_stride * sizeof(float4),
+                                 hipMemcpyDeviceToDevice, st));
+
+    const double inv_bw2 = 1.0 / (static_cast<double>(bandwidth) * static_cast<double>(bandwidth));
+    const float k2 = static_cast<float>(-0.5 * 1.4426950408889634 * inv_bw2);
+    const float thresh = static_cast<float>(static_cast<double>(bandwidth) * 1e-3);   // stop_thresh (:30)
+    // blocks beyond a set's count exit at once, but 12288-wide grids over 1700-point sets are mostly
+    // such blocks: the caller's bound on the counts sizes the grid
+    const int64_t span = max_count > 0 ? max_count : set_stride;
+    const dim3 grid(static_cast<unsigned>(ceil_div(span, kPointsPerBlock)), static_cast<unsigned>(G));
+    std::vector<float> host_shift;
+    if (check_every > 0) host_shift.resize(G);
+    for (int t = 0; t <= max_iter; ++t) {       // `it > max_iter` stops after max_iter+1 rounds (:47)
+        mean_shift_round_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, k2, thresh,
+                                                         shift, rounds, t, G);
+        FFB6D_LAUNCH_CHECK();
+        if (check_every > 0 && (t + 1) % check_every == 0 && t < max_iter) {
+            FFB6D_HIP_TRY(hipMemcpyAsync(host_shift.data(), shift + (t % 3) * G, sizeof(float) * G,
+                                         hipMemcpyDeviceToHost, st));
+            FFB6D_HIP_TRY(hipStreamSynchronize(st));
+            bool all_done = true;
+            for (int g = 0; g < G && all_done; ++g) all_done = host_shift[g] < thresh;
+            if (all_done) break;
+        }
+    }
+    ball_count_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best);
+    FFB6D_LAUNCH_CHECK();
+    const dim3 lgrid(static_cast<unsigned>(labels ? ceil_div(set_stride, kBlock) : 1), static_cast<unsigned>(G));
+    ball_labels_kernel<<<lgrid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best,
+                                                 centers, labels, n_inside, iters);
+    FFB6D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ffb6d_set_labels_to_points(const float* sets, const unsigned char* labels, const int* counts, const int* frame_of,
+                               int n_pairs, int64_t set_stride, int N, unsigned char* keep, ffb6d_stream_t stream) {
+    FFB6D_REQUIRE(n_pairs >= 0 && set_stride > 0 && N > 0, "set_labels_to_points: bad sizes");
+    if (n_pairs == 0) return 0;
+    FFB6D_REQUIRE(sets && labels && counts && frame_of && keep, "set_labels_to_points: null pointer");
+    const dim3 grid(static_cast<unsigned>(ceil_div(set_stride, kBlock)), static_cast<unsigned>(n_pairs));
+    labels_to_points_kernel<<<grid, kBlock, 0, ffb6d::as_stream(stream)>>>(reinterpret_cast<const float4*>(sets), labels,
+                                                                          counts, frame_of, set_stride, N, keep);
+    FFB6D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ffb6d_refine_mask_by_center(const float* pcld, const float* ctr_offsets, const void* mask, int mask_bits,
+                                const float* centers, const int* class_of, const int* pair_begin,
+                                const float* max_dist, int B, int N, void* mask_out, ffb6d_stream_t stream) {
+    FFB6D_REQUIRE(B > 0 && N > 0, "refine_mask: bad sizes B=%d N=%d", B, N);
+    FFB6D_REQUIRE(mask_bits == 32 || mask_bits == 64, "refine_mask: mask_bits must be 32 or 64, got %d", mask_bits);
+    FFB6D_REQUIRE(pcld && ctr_offsets && mask && pair_begin && mask_out, "refine_mask: null pointer");
+    const dim3 grid(static_cast<unsigned>(ceil_div(N, kBlock)), static_cast<unsigned>(B));
+    hipStream_t st = ffb6d::as_stream(stream);
+    if (mask_bits == 64)
+        refine_mask_kernel<int64_t><<<grid, kBlock, 0, st>>>(pcld, ctr_offsets, static_cast<const int64_t*>(mask), centers,
+                                                              class_of, pair_begin, max_dist, N,
+                                                              static_cast<int64_t*>(mask_out));
+    else
+        refine_mask_kernel<int32_t><<<grid, kBlock, 0, st>>>(pcld, ctr_offsets, static_cast<const int32_t*>(mask), centers,
+                                                              class_of, pair_begin, max_dist, N,
+                                                              static_cast<int32_t*>(mask_out));
+    FFB6D_LAUNCH_CHECK();
+    return 0;
+}
+
+int ffb6d_best_fit_transform_f32(const float* model, const float* found, int P, int n, double* T,
+                                 ffb6d_stream_t stream) {
+    FFB6D_REQUIRE(P >= 0 && n > 0, "best_fit_transform: bad sizes P=%d n=%d", P, n);
+    if (P == 0) return 0;
+    FFB6D_REQUIRE(model && found && T, "best_fit_transform: null pointer");
+    best_fit_kernel<<<static_cast<unsigned>(ceil_div(P, 64)), 64, 0, ffb6d::as_stream(stream)>>>(model, found, P, n, T);
+    FFB6D_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -185,16 +185,17 @@ def random_rotation(rng):
 
 
 def make_pose_case(seed, n_pts=2048, n_obj=2, n_kps=8, n_cls=None, noise=0.004, outliers=0.1,
-                   label_noise=0.02, bg_frac=0.3):
+                   label_noise=0.02, bg_frac=0.3, mesh_seed=None):
     """Returns a dict of numpy arrays:
       pcld f32[N,3], mask i64[N] (0 = background, 1..n_obj), ctr_of f32[1,N,3], kp_of f32[n_kps,N,3]
       mesh_kps f32[n_cls,n_kps,3], mesh_ctr f32[n_cls,3] (row = class id, row 0 unused),
       r_lst f32[n_cls-1] object radii, RT f64[n_cls,3,4] the true poses."""
     rng = np.random.RandomState(seed)
     n_cls = n_cls or n_obj + 1
-    mesh_kps = (rng.rand(n_cls, n_kps, 3).astype(np.float32) - 0.5) * 0.2
-    mesh_ctr = (rng.rand(n_cls, 3).astype(np.float32) - 0.5) * 0.02
-    r_lst = (0.08 + 0.05 * rng.rand(n_cls - 1)).astype(np.float32)
+    mrng = rng if mesh_seed is None else np.random.RandomState(mesh_seed)   # frames of one batch share the meshes
+    mesh_kps = (mrng.rand(n_cls, n_kps, 3).astype(np.float32) - 0.5) * 0.2
+    mesh_ctr = (mrng.rand(n_cls, 3).astype(np.float32) - 0.5) * 0.02
+    r_lst = (0.08 + 0.05 * mrng.rand(n_cls - 1)).astype(np.float32)
     RT = np.zeros((n_cls, 3, 4))
     pcld = np.zeros((n_pts, 3), np.float32)
     mask = np.zeros((n_pts,), np.int64)

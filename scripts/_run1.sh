@@ -1,8 +1,3 @@
 cd /root/repo
-python -m pytest tests/test_forward_gpu.py -x -q 2>&1 | tail -5
-python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/two_stream.json
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/two_stream.json'))
-print(d['value'], d['ms_per_step'], d.get('breakdown_ms'))
-PY
+python -m pytest tests/test_pose_gpu.py -x -q -s 2>&1 | grep -v Warning | tail -25
+timeout 300 python scripts/bench_pose.py --steps 5 > gpurun_out/pose_bench.json 2> gpurun_out/pose_bench.err; tail -3 gpurun_out/pose_bench.err; cat gpurun_out/pose_bench.json

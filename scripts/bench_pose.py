@@ -1,0 +1,59 @@
+"""Pose-solver timing on the GPU box: ffb6d_amd.pose.solve_poses on a batch of full-size frames
+(HIP events), rounds made, and the oracle (reference algorithm, torch CPU) on one frame beside it."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ffb6d_amd import _lib, pose, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--n-points", type=int, default=12288)
+ap.add_argument("--objects", type=int, default=5)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--cpu", type=int, default=1, help="time the oracle on one frame too")
+args = ap.parse_args()
+
+dev = torch.device("cuda:0")
+cases = [synth.make_pose_case(900 + b, n_pts=args.n_points, n_obj=args.objects, mesh_seed=9) for b in range(args.batch)]
+stack = lambda key: torch.from_numpy(np.stack([c[key] for c in cases])).to(dev)
+pcld, mask, ctr_of, kp_of = stack("pcld"), stack("mask"), stack("ctr_of"), stack("kp_of")
+mk, mc, rl = cases[0]["mesh_kps"], cases[0]["mesh_ctr"], cases[0]["r_lst"]
+
+for _ in range(2):
+    res = pose.solve_poses(pcld, mask, ctr_of, kp_of, mk, mc, r_lst=rl)
+torch.cuda.synchronize()
+tracer = _lib.Tracer()
+t0 = time.perf_counter()
+_lib.TRACER = tracer
+for _ in range(args.steps):
+    res = pose.solve_poses(pcld, mask, ctr_of, kp_of, mk, mc, r_lst=rl)
+torch.cuda.synchronize()
+_lib.TRACER = None
+stats = {}
+pose.solve_poses(pcld, mask, ctr_of, kp_of, mk, mc, r_lst=rl, stats=stats)
+wall = (time.perf_counter() - t0) / args.steps
+err = max(np.abs(T - cases[b]["RT"][c]).max() for b, (ids, poses, _) in enumerate(res) for c, T in zip(ids, poses))
+out = {"batch": args.batch, "n_points": args.n_points, "objects_per_frame": args.objects,
+       "wall_ms_per_batch": 1e3 * wall, "frames_per_s": args.batch / wall, "max_pose_err_vs_truth": float(err),
+       "kernels_ms_per_batch": {k: v["total_ms"] / args.steps for k, v in tracer.summary().items()}}
+for k in ("refine", "ctr", "kps"):
+    r, c = stats["rounds_" + k].cpu().numpy(), stats["counts_" + k].cpu().numpy()
+    out["rounds_" + k] = {"sets": int(r.size), "min": int(r.min()), "mean": float(r.mean()), "max": int(r.max()),
+                          "mean_points": float(c.mean())}
+if args.cpu:
+    from oracle import pose_ref
+    c = cases[0]
+    t = [torch.from_numpy(c[k]) for k in ("pcld", "mask", "ctr_of", "kp_of")]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    pose_ref.frame_poses_ycb(*t, True, True, mk, mc, rl)
+    out["oracle_cpu_s_per_frame"] = time.perf_counter() - t0
+    out["oracle_cpu_threads"] = torch.get_num_threads()
+print(json.dumps(out))

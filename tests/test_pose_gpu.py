@@ -1,0 +1,173 @@
+"""GPU parity of the pose solver (ffb6d_amd/pose.py over include/ffb6d_pose.h) against
+  * outputs of the reference itself (tests/golden/pose_small.npz), and
+  * the oracle restatement (oracle/pose_ref.py) on further seeded cases.
+
+Tolerances.  Mean shift is an fp32 fixed-point iteration; the kernel sums the Gaussian-weighted
+mean in another order than torch's CPU reduction and uses the hardware exp2, so converged points
+differ by rounding noise and a set may stop one round earlier or later.  The loop stops when no
+point moved more than stop_thresh = bandwidth*1e-3 (4e-5 m) in a round -- the points of a cluster
+are then still a few stop_thresh apart -- and the answer is ONE of them, picked by arg-max ball
+size, where neighbouring points differ by a handful of counts: rounding may pick another point of
+the same cluster.  Hence:
+    centres / keypoints   |diff| <= 5e-4 m   (12 stop_thresh; the synthetic vote noise is 4e-3 m)
+    labels                <= 0.5 % of a set's points may flip (points on the ball's surface)
+    poses [R|t]           <= 5e-3 (9-point Kabsch of keypoints that each carry <= 5e-4 m over a
+                          0.2 m model)
+best_fit_transform alone (same keypoints in): the reference runs LAPACK in float32, the kernel
+Jacobi in float64 -> |diff| <= 2e-5.
+"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from ffb6d_amd import pose, synth
+
+pytestmark = pytest.mark.gpu
+
+spec = importlib.util.spec_from_file_location("make_golden_pose", os.path.join(GOLDEN, "make_golden_pose.py"))
+gen = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(gen)
+
+CTR_TOL = 5e-4
+LABEL_FLIP = 0.005
+POSE_TOL = 5e-3
+BFT_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "pose_small.npz"))
+
+
+def dev_case(case, device):
+    return (torch.from_numpy(case["pcld"]).to(device), torch.from_numpy(case["mask"]).to(device),
+            torch.from_numpy(case["ctr_of"]).to(device), torch.from_numpy(case["kp_of"]).to(device))
+
+
+@pytest.mark.parametrize("i", range(len(gen.MS_CASES)))
+def test_mean_shift_matches_reference(device, gold, i):
+    seed, n, bw = gen.MS_CASES[i]
+    votes = torch.from_numpy(gen.ms_votes(seed, n)).to(device)
+    ctr, lab = pose.MeanShiftTorch(bandwidth=bw).fit(votes)
+    assert lab.dtype == torch.bool and lab.shape == (n,)
+    assert np.abs(ctr.cpu().numpy() - gold[f"ms{i}_ctr"]).max() <= CTR_TOL
+    flips = int((lab.cpu().numpy() != gold[f"ms{i}_labels"]).sum())
+    assert flips <= max(1, int(LABEL_FLIP * n)), flips
+
+
+def test_mean_shift_batch_equals_single_fits(device):
+    """Sets of different sizes in one launch: each must equal its own single-set run bit for bit
+    (no cross-talk through padding, shared tiles or the per-set stopping flags)."""
+    clouds = [torch.from_numpy(gen.ms_votes(500 + k, n)).to(device) for k, n in enumerate((40, 513, 1, 2000, 64, 700))]
+    ms = pose.MeanShiftTorch(bandwidth=0.04)
+    centers, labels = ms.fit_batch(clouds)
+    for g, c in enumerate(clouds):
+        ctr, lab = ms.fit(c)
+        assert torch.equal(ctr, centers[g]) and torch.equal(lab, labels[g])
+
+
+def test_mean_shift_round_limit_and_polling(device):
+    """max_iter bounds the rounds (it > max_iter after max_iter+1 rounds, meanshift_pytorch.py:47);
+    polling the stop flag every k rounds must not change the result."""
+    votes = torch.from_numpy(gen.ms_votes(600, 1200)).to(device)
+    sets = torch.zeros((1, 1200, 4), device=device)
+    sets[0, :, :3] = votes
+    counts = torch.tensor([1200], dtype=torch.int32, device=device)
+    c0, l0, n0, r0 = pose.mean_shift(sets, counts, 0.04, 300, check_every=0)
+    c1, l1, n1, r1 = pose.mean_shift(sets, counts, 0.04, 300, check_every=1)
+    c8, l8, n8, r8 = pose.mean_shift(sets, counts, 0.04, 300, check_every=8)
+    assert torch.equal(c0, c1) and torch.equal(c0, c8) and torch.equal(l0, l8) and int(r0) == int(r1) == int(r8)
+    assert 1 <= int(r0) <= 301 and int(n0) == int(l0.sum())
+    _, _, _, r = pose.mean_shift(sets, counts, 0.04, 2, check_every=0)
+    assert int(r) == 3
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_best_fit_transform_matches_reference(device, gold, i):
+    A, B = gen.bft_case(400 + i)
+    T = pose.best_fit_transform(A, B)
+    assert T.shape == (3, 4) and T.dtype == np.float64
+    assert np.abs(T - gold[f"bft{i}_T"]).max() <= BFT_TOL
+    assert abs(np.linalg.det(T[:, :3]) - 1) < 1e-9
+
+
+def test_best_fit_transform_degenerate_inputs(device):
+    rng = np.random.RandomState(0)
+    A = rng.rand(9, 3).astype(np.float32)
+    T = pose.best_fit_transform(A, A)                                  # identity
+    assert np.abs(T - np.eye(4)[:3]).max() < 1e-6
+    line = np.outer(np.linspace(-1, 1, 9), [1, 2, 3]).astype(np.float32)   # rank-1 model
+    T = pose.best_fit_transform(line, line + np.float32(0.5))
+    assert abs(np.linalg.det(T[:, :3]) - 1) < 1e-9
+    assert np.abs(line @ T[:, :3].T + T[:, 3] - (line + 0.5)).max() < 1e-5
+    T = pose.best_fit_transform(np.zeros((4, 3), np.float32), np.ones((4, 3), np.float32))   # H = 0
+    assert np.abs(T[:, :3] - np.eye(3)).max() == 0 and np.abs(T[:, 3] - 1).max() < 1e-12
+
+
+@pytest.mark.parametrize("i", range(len(gen.LM_CASES)))
+def test_linemod_flow_matches_reference(device, gold, i):
+    seed, n, n_obj, flt = gen.LM_CASES[i]
+    case = synth.make_pose_case(seed, n_pts=n, n_obj=n_obj)
+    poses = pose.cal_frame_poses_lm(*dev_case(case, device), True, n_obj + 1, flt, 1,
+                                    mesh_kps=case["mesh_kps"][1], mesh_ctr=case["mesh_ctr"][1])
+    assert len(poses) == 1
+    err = np.abs(poses[0] - gold[f"lm{i}_pose"][0]).max()
+    print("lm", i, "pose err", err)
+    assert err <= POSE_TOL
+
+
+@pytest.mark.parametrize("i", range(len(gen.YCB_CASES)))
+def test_ycb_flow_matches_reference(device, gold, i):
+    seed, n, n_obj, flt = gen.YCB_CASES[i]
+    case = synth.make_pose_case(seed, n_pts=n, n_obj=n_obj)
+    ids, poses, kps = pose.cal_frame_poses(*dev_case(case, device), True, n_obj + 1, flt,
+                                           mesh_kps=case["mesh_kps"], mesh_ctr=case["mesh_ctr"], r_lst=case["r_lst"])
+    assert np.array_equal(ids, gold[f"ycb{i}_ids"])
+    kerr = np.abs(np.stack(kps) - gold[f"ycb{i}_kps"]).max()
+    perr = np.abs(np.stack(poses) - gold[f"ycb{i}_pose"]).max()
+    print("ycb", i, "kps err", kerr, "pose err", perr)
+    assert kerr <= CTR_TOL and perr <= POSE_TOL
+
+
+def test_batched_solver_equals_per_frame_and_oracle(device):
+    """Frames of different content in one batch (int32 mask, one frame without foreground, one class
+    that loses all its points) against per-frame oracle runs."""
+    from oracle import pose_ref
+    cases = [synth.make_pose_case(700 + k, n_pts=1500, n_obj=3, n_cls=5, mesh_seed=7) for k in range(3)]
+    cases[1]["mask"][:] = 0                                              # nothing to solve in frame 1
+    cases[2]["mask"][cases[2]["mask"] == 2] = 0                          # class 2 absent in frame 2
+    stack = lambda key: torch.from_numpy(np.stack([c[key] for c in cases])).to(device)
+    mesh_kps, mesh_ctr, r_lst = cases[0]["mesh_kps"], cases[0]["mesh_ctr"], cases[0]["r_lst"]
+    res = pose.solve_poses(stack("pcld"), stack("mask").int(), stack("ctr_of"), stack("kp_of"),
+                           mesh_kps, mesh_ctr, r_lst=r_lst)
+    assert len(res) == 3 and len(res[1][0]) == 0
+    for b, case in enumerate(cases):
+        ids, poses, kps = pose_ref.frame_poses_ycb(*gen.tensors(case), True, True, mesh_kps, mesh_ctr, r_lst)
+        assert np.array_equal(res[b][0], ids)
+        if len(ids):
+            assert np.abs(res[b][2] - np.stack(kps)).max() <= CTR_TOL
+            assert np.abs(res[b][1] - np.stack(poses)).max() <= POSE_TOL
+            for c, T in zip(ids, res[b][1]):
+                if (case["mask"] == c).sum() > 50:
+                    assert np.abs(T - case["RT"][c]).max() < 0.03
+
+
+def test_full_size_cloud_recovers_the_pose(device):
+    """N = 12288 points, 5 objects: size-independent property -- the solver returns the pose the
+    votes were synthesised from."""
+    case = synth.make_pose_case(800, n_pts=12288, n_obj=5)
+    ids, poses, _ = pose.cal_frame_poses(*dev_case(case, device), True, 6, True, mesh_kps=case["mesh_kps"],
+                                         mesh_ctr=case["mesh_ctr"], r_lst=case["r_lst"])
+    assert list(ids) == [1, 2, 3, 4, 5]
+    for c, T in zip(ids, poses):
+        assert np.abs(T - case["RT"][c]).max() < 0.01
+
+
+def test_cpu_tensors_are_rejected():
+    from ffb6d_amd import _lib
+    with pytest.raises(_lib.FFB6DNativeError):
+        pose.MeanShiftTorch(0.04).fit(torch.zeros(10, 3))
