@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, one GPU per rank) for real runs; gloo lets several ranks share one GPU "
                          "to exercise the multi-process path on a single-GPU box")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
+                    help="2: point branch + index pyramid on a second HIP stream under the colour branch "
+                         "(inference); 1: everything on one stream")
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
@@ -185,14 +188,28 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     phase = {"pyramid": [], "forward": []}
 
+    # streams: the point branch of the forward runs on a second HIP stream under the colour branch's
+    # convolutions (model.FFB6D._forward_two_streams); the index pyramid is enqueued on that stream
+    # too, so it runs under the colour stem of the same step (nothing in the stem needs an index)
+    overlap = bool(args.streams == 2) and not train
+    net.two_streams = overlap
+    side = net._side_stream(dev) if overlap else None
+
     def step(record=False):
         e0, e1, e2 = (ev(), ev(), ev()) if record else (None, None, None)
         if record:
             e0.record()
-        inputs = pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                inputs = pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
+                if record:
+                    e1.record()
+        else:
+            inputs = pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
+            if record:
+                e1.record()
         inputs.update(rgb=rgb, cld_rgb_nrm=cld_rgb_nrm, choose=choose)
-        if record:
-            e1.record()
         if train:
             # proxy objective (the reference's focal + L1 offset losses need labels that synthetic
             # frames do not have); it touches all three heads so every parameter gets a gradient
@@ -207,7 +224,7 @@ def main():
         if record:
             e2.record()
             phase["pyramid"].append((e0, e1))
-            phase["forward"].append((e1, e2))
+            phase["forward"].append((e0 if overlap else e1, e2))
         return out
 
     with torch.no_grad():
@@ -227,6 +244,21 @@ def main():
         _lib.TRACER = None
         if args.mark_region:
             ops.check_index_range(marker, 1)
+
+        # after the timed region: the same steps on ONE stream, to time every kernel without a
+        # neighbour from the other stream sharing its CUs (reported as roofline.isolated)
+        serial = None
+        if overlap and rank == 0:
+            net.two_streams, keep_side, side = False, side, None
+            serial = _lib.Tracer(None if args.roofline_op == "auto" else [args.roofline_op])
+            step()
+            torch.cuda.synchronize()
+            _lib.TRACER = serial
+            for _ in range(max(2, min(args.steps, 5))):
+                step()
+            torch.cuda.synchronize()
+            _lib.TRACER = None
+            net.two_streams, side = True, keep_side
 
         if args.trace_all and rank == 0:
             full = _lib.Tracer(None)
@@ -251,11 +283,14 @@ def main():
         fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["forward"]]))
         # split the shared-MLP launches by the kernel instantiation rocprofv3 lists them under:
         # shared_mlp_kernel<BM, FLAT>, BM by Cout, FLAT for small per-frame P (csrc/shared_mlp.hip)
-        for rec in tracer.records.pop("shared_mlp", []):
-            k, cout, pcols = rec[3]
-            bm = 128 if cout > 64 else (64 if cout > 32 else 32)
-            flat = pcols < 2048 and pcols % 4 == 0
-            tracer.records.setdefault("shared_mlp<%d,%s>" % (bm, "flat" if flat else "frame"), []).append(rec)
+        def split_mlp(tr):
+            for rec in tr.records.pop("shared_mlp", []):
+                k, cout, pcols = rec[3]
+                bm = 128 if cout > 64 else (64 if cout > 32 else 32)
+                flat = pcols < 2048 and pcols % 4 == 0
+                tr.records.setdefault("shared_mlp<%d,%s>" % (bm, "flat" if flat else "frame"), []).append(rec)
+
+        split_mlp(tracer)
         summary = tracer.summary()
         # dominant hand-written op of the timed steps.  KNN is latency/VALU bound (10.7 MB of
         # algorithmic bytes per frame) and is reported through hot_path_ops instead.
@@ -290,6 +325,19 @@ def main():
                             "avg_launch_us": summ["avg_us"],
                             "algorithmic_bytes_per_launch": summ["bytes"] / summ["launches"],
                             "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
+        if roofline and serial is not None:
+            split_mlp(serial)
+            iso = serial.summary().get(roof_op)
+            if iso and iso["launches"]:
+                if roofline["bound"] == "mfma":
+                    iso_ach = sum(2.0 * args.batch * t[0] * t[1] * t[2] for _, _, _, t in serial.records[roof_op]) \
+                        / (iso["total_ms"] * 1e-3) / 1e12
+                else:
+                    iso_ach = iso["gbps"]
+                roofline["isolated"] = {"achieved": iso_ach, "frac": iso_ach / roofline["peak"],
+                                        "avg_launch_us": iso["avg_us"],
+                                        "note": "same kernel, same steps on one stream after the timed region: "
+                                                "no kernel of the other stream shares the CUs"}
         ops_table = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["total_ms"] / args.steps,
                          "algorithmic_GBps": v["gbps"]} for k, v in summary.items()}
         if "knn" in summary:
@@ -309,8 +357,12 @@ def main():
                                    f"{args.n_classes} classes, fp32, eval",
                        "global_batch": args.batch * world, "n_points": args.n_points,
                        "index_dtype": args.index_dtype, "parallelism": f"dp{world} (independent batches)"},
-            "breakdown_ms": {"knn_pyramid": pyr_ms, "forward": fwd_ms},
-            "forward_only_fps": args.batch * world / (fwd_ms * 1e-3),
+            "breakdown_ms": ({"knn_pyramid_on_side_stream": pyr_ms, "step_on_main_stream": fwd_ms,
+                              "note": "two HIP streams: pyramid + point branch run under the colour branch; "
+                                      "both intervals start at the step's first event and overlap"}
+                             if overlap else {"knn_pyramid": pyr_ms, "forward": fwd_ms}),
+            "streams": 2 if overlap else 1,
+            **({} if overlap else {"forward_only_fps": args.batch * world / (fwd_ms * 1e-3)}),
             "roofline": roofline,
             "hot_path_ops": ops_table,
         }

@@ -21,6 +21,8 @@
 // B[k = l>>5][j = l&31]; accumulator element r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 // Block = 256 threads = 4 waves, tile BM x 128 x 16; LDS tiles are k-major so a fragment read is
 // 32 consecutive floats per half-wave (conflict free: lanes l and l+32 may share a bank).
+#include <cstdlib>
+
 #include "common.h"
 #include "ffb6d_ops.h"
 
@@ -317,6 +319,168 @@ shared_mlp_kernel(const MlpParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pipelined variant for the MFMA-bound launches (per-frame tiles, 16-byte aligned rows).
+//
+// PMC of shared_mlp_kernel<128> on the 1024->1024 layer showed the MFMA pipe only ~60 % busy with
+// three workgroups per CU: the tile refill (bounds-checked loads + LDS stores, full of exec-mask
+// branches) is a separate phase of the loop that the compiler cannot mix into the MFMA stream, and
+// co-resident workgroups run in lock-step, so their refill phases coincide.
+// (measured alternatives that did not help: BK = 32 with two workgroups per CU, s_setprio around the
+// MFMA groups -- scripts/bench_mlp_ab.py.)  Here the k-loop body
+// is ONE basic block: operands come through buffer loads (hardware range check returns 0 outside
+// [0, num_records) -> no branches for the K tail or the end of a source), the refill is issued
+// unconditionally (the surplus loads of the last steps are out of range = free zeros) and is
+// spread over the k-steps of the MFMA stream.
+// Out-of-tile columns/rows (m >= cout, p >= P) read neighbouring in-range data instead of zeros;
+// they only feed accumulator elements that are never stored.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buffer_load_f4(__amdgpu_buffer_rsrc_t rs, int byte_offset)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_offset, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+template <int BM>
+__global__ void __launch_bounds__(BLK)
+shared_mlp_pipe_kernel(const MlpParams p)
+{
+    constexpr int WM = BM == 128 ? 2 : 1;
+    constexpr int WN = 4 / WM;
+    constexpr int TM = BM / (32 * WM);
+    constexpr int TN = BN / (32 * WN);
+    constexpr int A_F4 = BK * BM / 4 / BLK;          // 128: 2, 64: 1
+    constexpr int B_F4 = BK * BN / 4 / BLK;          // 2
+    static_assert(A_F4 >= 1, "BM >= 64");
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ncol_tiles = p.col_tiles;
+    if ((int)blockIdx.x >= ncol_tiles * p.nz) return;
+    const int b = blockIdx.x / ncol_tiles;
+    const int m0 = blockIdx.y * BM;
+    const int p0 = (blockIdx.x - b * ncol_tiles) * BN;
+    const int K = p.k1 + p.k2;
+
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, K * p.cout * 4, 0x00020000);
+    const float* x1 = p.x1 + (size_t)b * p.x1_bs;
+    const float* x2 = p.x2 ? p.x2 + (size_t)b * p.x2_bs : p.x1;
+    const int rec1 = p.k1 * p.P * 4, rec2 = p.x2 ? p.k2 * p.P * 4 : 0;
+
+    int a_vo[A_F4], b_vo[B_F4], a_lds[A_F4], b_lds[B_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int f = tid + i * BLK;
+        const int kr = f / (BM / 4), mc = (f % (BM / 4)) * 4;
+        a_vo[i] = (kr * p.cout + m0 + mc) * 4;
+        a_lds[i] = kr * BM + mc;
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int f = tid + i * BLK;
+        const int kr = f / (BN / 4), nc = (f % (BN / 4)) * 4;
+        b_vo[i] = (kr * p.P + p0 + nc) * 4;
+        b_lds[i] = kr * BN + nc;
+    }
+    float4 ra[A_F4], rb[B_F4];
+    auto load_tiles = [&](int k0) {                  // k0 is a multiple of BK; k1 % BK == 0 when there is an x2
+        const bool second = k0 >= p.k1;
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(second ? x2 : x1), 0, second ? rec2 : rec1, 0x00020000);
+        const int a_so = k0 * p.cout * 4;
+        const int b_so = (second ? k0 - p.k1 : k0) * p.P * 4;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) ra[i] = buffer_load_f4(rs_w, a_vo[i] + a_so);
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) rb[i] = buffer_load_f4(rs_x, b_vo[i] + b_so);
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(&As[buf][0][0] + a_lds[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) *reinterpret_cast<float4*>(&Bs[buf][0][0] + b_lds[i]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kh = lane >> 5;
+    const int l31 = lane & 31;
+    const int am = wm * (TM * 32) + l31;
+    const int bn = wn * (TN * 32) + l31;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    load_tiles(BK);
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
+        float a[2][TM], bb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[buf][kh][am + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bb[0][j] = Bs[buf][kh][bn + j * 32];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = As[buf][kk + 2 + kh][am + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bb[nxt][j] = Bs[buf][kk + 2 + kh][bn + j * 32];
+            }
+            if (kk == 2) store_tiles(buf ^ 1);       // stage k+1 (loaded one iteration ago) -> other LDS buffer
+            if (kk == 4) load_tiles(k0 + 2 * BK);     // stage k+2 -> the staging registers just freed
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    const float* yg = p.yg ? p.yg + (size_t)b * p.yg_bs : nullptr;
+    float* out = p.out + (size_t)b * p.out_bs;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = p0 + wn * (TN * 32) + j * 32 + l31;
+        if (col >= p.P) continue;
+        long long gi = 0;
+        if (yg) {
+            gi = p.idx64 ? static_cast<const long long*>(p.gidx)[(size_t)b * p.P + col]
+                         : (long long)static_cast<const int*>(p.gidx)[(size_t)b * p.P + col];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (m < p.cout) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[m];
+                    if (yg) v += yg[(size_t)m * p.py + gi];
+                    out[(size_t)m * p.P + col] = activate(v, p.act);
+                }
+            }
+        }
+    }
+}
+
 // sums the K-split partial slabs and applies the epilogue; one lane per output element
 __global__ void __launch_bounds__(BLK)
 shared_mlp_reduce_kernel(const MlpParams p, int nsplit)
@@ -343,6 +507,17 @@ struct MlpPlan {
     bool flat;
     int nsplit, kchunk;
 };
+
+// FFB6D_MLP_PIPE=0 in the environment routes everything through the first-generation kernel
+// (A/B measurements, scripts/bench_mlp.py)
+int mlp_pipe_enabled()
+{
+    static const int v = [] {
+        const char* e = getenv("FFB6D_MLP_PIPE");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
 
 MlpPlan plan_mlp(int64_t B, int64_t cout, int64_t K, int64_t P)
 {
@@ -441,6 +616,23 @@ extern "C" int ffb6d_shared_mlp_f32(const float* wt, const float* bias, const fl
     const unsigned gz = pl.flat ? (unsigned)pl.nsplit : (unsigned)B;
     p.col_tiles = (int)gx; p.nz = (int)gz;
     const unsigned gxz = (gx * gz + 7u) / 8u * 8u;       // multiple of the XCD count
+    // pipelined kernel: per-frame tiles, 16-byte aligned rows, sources switching on a BK boundary,
+    // byte offsets that fit the 32-bit buffer addressing
+    const int64_t K = k1 + k2;
+    const bool pipe = !pl.flat && cout > 32 && mlp_pipe_enabled() && (P & 3) == 0 && (cout & 3) == 0 &&
+                      ((x1_batch_stride | x2_batch_stride) & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2) |
+                        reinterpret_cast<uintptr_t>(wt)) & 15) == 0 &&
+                      (k2 == 0 || k1 % BK == 0) && (K + 2 * BK) * P * 4 < (1LL << 31) &&
+                      (K + 2 * BK) * cout * 4 < (1LL << 31);
+    if (pipe) {
+        if (cout > 64)
+            hipLaunchKernelGGL((shared_mlp_pipe_kernel<128>), dim3(gxz, (unsigned)ceil_div(cout, 128), 1), dim3(BLK), 0, st, p);
+        else
+            hipLaunchKernelGGL((shared_mlp_pipe_kernel<64>), dim3(gxz, 1, 1), dim3(BLK), 0, st, p);
+        FFB6D_LAUNCH_CHECK();
+        return FFB6D_OK;
+    }
 #define FFB6D_LAUNCH_MLP(BMV)                                                                              \
     do {                                                                                                   \
         const dim3 grid(gxz, (unsigned)ceil_div(cout, BMV), 1);                                            \
