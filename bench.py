@@ -62,12 +62,22 @@ def parse():
                     help="nccl (= RCCL, one GPU per rank) for real runs; gloo lets several ranks share one GPU "
                          "to exercise the multi-process path on a single-GPU box")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
-                    help="2: point branch + index pyramid on a second HIP stream under the colour branch "
-                         "(inference); 1: everything on one stream")
+                    help="2: point branch on a second HIP stream under the colour branch (inference); "
+                         "1: everything on one stream")
+    ap.add_argument("--overlap-pyramid", type=int, default=0,
+                    help="1: enqueue the index pyramid on the second stream too (under the colour stem); "
+                         "measured neutral on MI355X, the GPU is throughput-bound (DESIGN.md section 4b)")
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
     return ap.parse_args()
+
+
+# hot_path_ops key -> kernel instantiation as rocprofv3 lists it (csrc/shared_mlp.hip: per-frame tiles with
+# Cout > 32 take the buffer-load pipelined loop, small per-frame P the flat split-K kernel)
+MLP_KERNEL_NAMES = {"shared_mlp<128,frame>": "shared_mlp_pipe_kernel<128>", "shared_mlp<64,frame>": "shared_mlp_pipe_kernel<64>",
+                    "shared_mlp<32,frame>": "shared_mlp_kernel<32, false>", "shared_mlp<128,flat>": "shared_mlp_kernel<128, true>",
+                    "shared_mlp<64,flat>": "shared_mlp_kernel<64, true>", "shared_mlp<32,flat>": "shared_mlp_kernel<32, true>"}
 
 
 def state_dict(n_classes):
@@ -189,11 +199,11 @@ def main():
     phase = {"pyramid": [], "forward": []}
 
     # streams: the point branch of the forward runs on a second HIP stream under the colour branch's
-    # convolutions (model.FFB6D._forward_two_streams); the index pyramid is enqueued on that stream
-    # too, so it runs under the colour stem of the same step (nothing in the stem needs an index)
+    # convolutions (model.FFB6D._forward_two_streams); with --overlap-pyramid the index pyramid is
+    # enqueued on that stream too (nothing in the colour stem needs an index)
     overlap = bool(args.streams == 2) and not train
     net.two_streams = overlap
-    side = net._side_stream(dev) if overlap else None
+    side = net._side_stream(dev) if (overlap and args.overlap_pyramid) else None
 
     def step(record=False):
         e0, e1, e2 = (ev(), ev(), ev()) if record else (None, None, None)
@@ -224,7 +234,7 @@ def main():
         if record:
             e2.record()
             phase["pyramid"].append((e0, e1))
-            phase["forward"].append((e0 if overlap else e1, e2))
+            phase["forward"].append((e0 if side is not None else e1, e2))
         return out
 
     with torch.no_grad():
@@ -248,6 +258,7 @@ def main():
         # after the timed region: the same steps on ONE stream, to time every kernel without a
         # neighbour from the other stream sharing its CUs (reported as roofline.isolated)
         serial = None
+        pyramid_on_side = side is not None
         if overlap and rank == 0:
             net.two_streams, keep_side, side = False, side, None
             serial = _lib.Tracer(None if args.roofline_op == "auto" else [args.roofline_op])
@@ -313,7 +324,7 @@ def main():
                 ach = flops / sec / 1e12
                 roofline = {"bound": "mfma", "achieved": ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / VALU_PEAK_TFLOPS, "traffic": traffic,
-                            "kernel": roof_op.replace("shared_mlp", "shared_mlp_kernel") + " (fp32 MFMA 32x32x2)",
+                            "kernel": MLP_KERNEL_NAMES.get(roof_op, roof_op) + " (fp32 MFMA 32x32x2)",
                             "launches_per_step": summ["launches"] / args.steps, "avg_launch_us": summ["avg_us"],
                             "algorithmic_flops_per_step": flops / args.steps,
                             "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
@@ -358,11 +369,11 @@ def main():
                        "global_batch": args.batch * world, "n_points": args.n_points,
                        "index_dtype": args.index_dtype, "parallelism": f"dp{world} (independent batches)"},
             "breakdown_ms": ({"knn_pyramid_on_side_stream": pyr_ms, "step_on_main_stream": fwd_ms,
-                              "note": "two HIP streams: pyramid + point branch run under the colour branch; "
-                                      "both intervals start at the step's first event and overlap"}
-                             if overlap else {"knn_pyramid": pyr_ms, "forward": fwd_ms}),
+                              "note": "pyramid + point branch run under the colour branch; both intervals "
+                                      "start at the step's first event and overlap"}
+                             if pyramid_on_side else {"knn_pyramid": pyr_ms, "forward": fwd_ms}),
             "streams": 2 if overlap else 1,
-            **({} if overlap else {"forward_only_fps": args.batch * world / (fwd_ms * 1e-3)}),
+            **({} if pyramid_on_side else {"forward_only_fps": args.batch * world / (fwd_ms * 1e-3)}),
             "roofline": roofline,
             "hot_path_ops": ops_table,
         }
