@@ -307,6 +307,16 @@ def shared_mlp(x1, wt, bias=None, act=ACT_NONE, x2=None, gather=None):
     lib = _lib.load()
     if x1.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
         raise TypeError("float32 expected")
+    cols = x1[0, 0].numel() if x1.numel() else 0
+    if gather is None and 0 < cols < 2048 and cols % 4:
+        # a handful of columns per frame (e.g. the 1x1 and 3x3 levels of the pyramid pooling): pad to a
+        # multiple of 4 so the launch takes the flat split-K kernel (all frames in one column range, K
+        # spread over workgroups) instead of one under-filled tile per frame walking the whole K
+        pad = (-cols) % 4
+        p1 = torch.nn.functional.pad(x1.detach().reshape(x1.shape[0], x1.shape[1], cols), (0, pad))
+        p2 = None if x2 is None else torch.nn.functional.pad(x2.detach().reshape(x2.shape[0], x2.shape[1], cols), (0, pad))
+        out = shared_mlp(p1, wt, bias, act, x2=p2)[:, :, :cols]
+        return out.reshape(out.shape[0], out.shape[1], *x1.shape[2:])
     a, a_bs = _rows(x1.detach())
     B, K1, P = a.shape
     K2 = 0

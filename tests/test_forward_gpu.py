@@ -98,21 +98,30 @@ def test_forward_full_size_matches_reference_sample(device):
 
 def test_two_stream_forward_equals_single_stream(device):
     """The point branch runs on a second HIP stream under the colour branch's convolutions
-    (model.FFB6D._forward_two_streams); same kernels, same order per tensor -> same bits.
-    Repeated so that a missing event / record_stream shows up as a race."""
+    (model.FFB6D._forward_two_streams); same kernels, same order per tensor -> same bits, unless
+    MIOpen picked a split-K convolution that accumulates with atomics (then even two single-stream
+    runs differ in the last bits and the comparison falls back to HOT_TOL of the output range).
+    Repeated, with a NaN-filled block recycled through the allocator in between, so that a missing
+    event / record_stream shows up as a race."""
     frames = synth.make_batch(3, 2, n_points=12288, height=480, width=640)
     net = build(22, 12288, device)
     inputs = pyramid.frames_to_device(frames, device)
     with torch.no_grad():
         net.two_streams = False
         want = {k: v.clone() for k, v in net(inputs).items()}
+        again = net(inputs)
+        reproducible = all(torch.equal(again[k], want[k]) for k in want)
         net.two_streams = True
         for rep in range(4):
             got = net(inputs)
             junk = torch.empty(64 << 20, device=device).fill_(float("nan"))    # recycle freed blocks
             del junk
             for k in want:
-                assert torch.equal(got[k], want[k]), (rep, k, float((got[k] - want[k]).abs().max()))
+                if reproducible:
+                    assert torch.equal(got[k], want[k]), (rep, k, float((got[k] - want[k]).abs().max()))
+                else:
+                    scale = max(float(want[k].abs().max()), 1.0)
+                    assert float((got[k] - want[k]).abs().max()) <= HOT_TOL * scale, (rep, k)
 
 
 def test_batch_items_are_independent(device):

@@ -171,6 +171,8 @@ def _mlp_ref(x1, w, bias, act, x2=None, gather=None):
     # small per-frame P: flat columns over frames + split-K partial slabs
     (8, 1024, 0, 512, 48, 1, 0), (8, 512, 512, 256, 192, 2, 0), (8, 256, 0, 256, 192, 1, 48),
     (4, 128, 0, 22, 768, 0, 0), (2, 48, 16, 40, 1024, 1, 100),
+    # a few ragged columns per frame (pyramid-pooling levels 1x1 and 3x3): padded into the flat kernel
+    (8, 512, 0, 1024, 1, 0, 0), (8, 512, 0, 1024, 9, 0, 0), (2, 64, 32, 128, 7, 1, 0),
 ])
 def test_shared_mlp_matches_fp64_reference(device, B, K1, K2, Cout, P, act, py):
     g = torch.Generator().manual_seed(K1 + Cout + P)
