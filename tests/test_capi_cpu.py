@@ -13,7 +13,7 @@ from conftest import ROOT
 
 def declared_functions():
     names = []
-    for hdr in ("ffb6d_knn.h", "ffb6d_ops.h"):
+    for hdr in sorted(f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")):
         src = open(os.path.join(ROOT, "include", hdr)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         for m in re.finditer(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(\w+)\s*\(", src, flags=re.M):
@@ -28,7 +28,9 @@ def test_headers_declare_the_expected_entry_points():
     for must in ("cpp_knn", "cpp_knn_omp", "cpp_knn_batch", "cpp_knn_batch_omp",
                  "ffb6d_knn_batch_device", "ffb6d_random_sample_f32",
                  "ffb6d_nearest_interpolation_f32", "ffb6d_gather_neighbour_f32",
-                 "ffb6d_relative_pos_encoding_f32", "ffb6d_att_pool_f32"):
+                 "ffb6d_relative_pos_encoding_f32", "ffb6d_att_pool_f32", "ffb6d_shared_mlp_f32",
+                 "ffb6d_vote_sets_f32", "ffb6d_mean_shift_f32", "ffb6d_mean_shift_workspace_bytes",
+                 "ffb6d_set_labels_to_points", "ffb6d_refine_mask_by_center", "ffb6d_best_fit_transform_f32"):
         assert must in names
 
 
@@ -38,6 +40,22 @@ def test_library_exports_every_declared_symbol(native_lib):
         assert hasattr(native_lib, name), f"{name} declared in include/ but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
     assert native_lib.ffb6d_abi_version() >= 1000
+
+
+def test_pose_entry_points_validate_arguments_without_a_gpu(native_lib):
+    """Argument checks run before any HIP call: bad sizes come back as FFB6D_ERR_ARG with a message."""
+    from ffb6d_amd import _lib
+    assert native_lib.ffb6d_mean_shift_workspace_bytes(0, 128) == 0
+    need = native_lib.ffb6d_mean_shift_workspace_bytes(9, 1024)
+    assert need >= 2 * 9 * 1024 * 16
+    rc = native_lib.ffb6d_mean_shift_f32(None, None, 1, 4, 64, 0, -1.0, 300, 8, None, None, None, None, None, 0, None)
+    assert rc == -1 and "bandwidth" in _lib.last_error()
+    rc = native_lib.ffb6d_vote_sets_f32(None, None, None, 16, None, None, None, 1, 1, 1, 8, 8, None, None, None)
+    assert rc == -1 and "mask_bits" in _lib.last_error()
+    rc = native_lib.ffb6d_vote_sets_f32(None, None, None, 64, None, None, None, 1, 1, 1, 8, 4, None, None, None)
+    assert rc == -1 and "set_stride" in _lib.last_error()
+    assert native_lib.ffb6d_best_fit_transform_f32(None, None, 0, 9, None, None) == 0      # nothing to do
+    assert native_lib.ffb6d_best_fit_transform_f32(None, None, 2, 0, None, None) == -1
 
 
 def test_workspace_query_is_pure_host_logic(native_lib):
