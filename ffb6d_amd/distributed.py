@@ -87,6 +87,7 @@ def timed_steps(step, warmup, steps, group, sync=lambda: None):
         step(True)
     sync()
     group.barrier()
+    sync()
     elapsed = time.perf_counter() - t0
     return group.max_over_ranks(elapsed)
 
