@@ -171,6 +171,10 @@ def _mlp_ref(x1, w, bias, act, x2=None, gather=None):
     # small per-frame P: flat columns over frames + split-K partial slabs
     (8, 1024, 0, 512, 48, 1, 0), (8, 512, 512, 256, 192, 2, 0), (8, 256, 0, 256, 192, 1, 48),
     (4, 128, 0, 22, 768, 0, 0), (2, 48, 16, 40, 1024, 1, 100),
+    # pipelined kernel (per-frame tiles, Cout > 32): K tail (rows past K come back as zeros from the buffer range
+    # check), second source shorter than a k-tile, Cout that is no multiple of the row tile, ragged last column tile
+    (1, 32, 8, 64, 4096, 1, 0), (1, 48, 0, 72, 2052, 2, 50), (2, 16, 16, 128, 2048, 0, 0),
+    (1, 1000, 0, 136, 2048, 1, 0), (2, 64, 24, 132, 2304, 2, 7),
     # a few ragged columns per frame (pyramid-pooling levels 1x1 and 3x3): padded into the flat kernel
     (8, 512, 0, 1024, 1, 0, 0), (8, 512, 0, 1024, 9, 0, 0), (2, 64, 32, 128, 7, 1, 0),
 ])
@@ -187,6 +191,25 @@ def test_shared_mlp_matches_fp64_reference(device, B, K1, K2, Cout, P, act, py):
                          gather=None if gather is None else (d(gather[0]), d(gather[1]))).cpu()
     assert got.shape == want.shape
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_shared_mlp_ignores_non_finite_neighbours_of_its_operands(device):
+    """The pipelined kernel lets out-of-tile loads wrap into neighbouring rows; what it reads there may only
+    reach accumulator elements that are never stored.  Operands embedded in NaN-filled storage (batch stride
+    larger than K*P, weights inside a larger buffer) must give the same result as clean ones."""
+    g = torch.Generator().manual_seed(9)
+    B, K, C, P = 2, 40, 72, 2052
+    x = torch.randn(B, K, P, generator=g).to(device)
+    w = (torch.randn(K, C, generator=g) / K ** 0.5).to(device)
+    bias = torch.randn(C, generator=g).to(device)
+    want = ops.shared_mlp(x, w, bias, ops.ACT_RELU)
+    big = torch.full((B, K + 24, P), float("nan"), device=device)
+    big[:, :K] = x
+    wbuf = torch.full((K + 16, C), float("nan"), device=device)
+    wbuf[:K] = w
+    got = ops.shared_mlp(big[:, :K], wbuf[:K], bias, ops.ACT_RELU)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want)
 
 
 def test_shared_mlp_4d_views_and_channel_slices(device):

@@ -167,6 +167,36 @@ def test_full_size_cloud_recovers_the_pose(device):
         assert np.abs(T - case["RT"][c]).max() < 0.01
 
 
+def test_mean_shift_edge_sets(device):
+    """Empty set, one point, all votes identical, two points further apart than the bandwidth."""
+    ms = pose.MeanShiftTorch(bandwidth=0.04)
+    one = torch.tensor([[0.1, 0.2, 0.3]], device=device)
+    ctr, lab = ms.fit(one)
+    assert torch.equal(ctr, one[0]) and lab.tolist() == [True]
+    same = one.repeat(50, 1)
+    ctr, lab = ms.fit(same)
+    assert torch.allclose(ctr, one[0], atol=1e-7) and bool(lab.all())
+    far = torch.tensor([[0.0, 0.0, 1.0], [0.0, 0.5, 1.0], [0.0, 0.5, 1.0]], device=device)
+    ctr, lab = ms.fit(far)                                   # the doubled point wins, the lone one is outside
+    assert torch.allclose(ctr, far[1], atol=1e-6) and lab.tolist() == [False, True, True]
+    sets = torch.zeros((3, 8, 4), device=device)
+    sets[1, :3, :3] = far
+    counts = torch.tensor([0, 3, 0], dtype=torch.int32, device=device)
+    centers, labels, n_in, rounds = pose.mean_shift(sets, counts, 0.04)
+    assert centers[0].abs().max() == 0 and centers[2].abs().max() == 0 and n_in.tolist() == [0, 2, 0]
+    assert not bool(labels[0].any()) and labels[1].tolist()[:3] == [False, True, True] and int(rounds[0]) == 0
+    with pytest.raises(ValueError):
+        ms.fit(torch.zeros((0, 3), device=device))
+
+
+def test_linemod_flow_without_object_points_returns_identity(device):
+    case = synth.make_pose_case(55, n_pts=500, n_obj=1)
+    case["mask"][:] = 0
+    poses = pose.cal_frame_poses_lm(*dev_case(case, device), True, 2, False, 1,
+                                    mesh_kps=case["mesh_kps"][1], mesh_ctr=case["mesh_ctr"][1])
+    assert np.array_equal(poses[0], np.identity(4)[:3])     # pvn3d_eval_utils_kpls.py:239-240
+
+
 def test_cpu_tensors_are_rejected():
     from ffb6d_amd import _lib
     with pytest.raises(_lib.FFB6DNativeError):
