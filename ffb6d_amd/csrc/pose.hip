@@ -188,6 +188,7 @@ __global__ __launch_bounds__(kBlock) void ball_labels_kernel(
             centers[3 * g] = centers[3 * g + 1] = centers[3 * g + 2] = 0.f;
             if (n_inside) n_inside[g] = 0;
         }
+        if (labels && j < stride) labels[g * stride + j] = 0;
         return;
     }
     const float4* src = ((rounds[g] & 1) ? buf1 : buf0) + g * stride;
