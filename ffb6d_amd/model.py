@@ -119,8 +119,11 @@ class SharedMLP(nn.Module):
 
 
 def _autograd_path(x):
-    """True when the differentiable stock-torch path must be used instead of the fused
-    inference kernels (gradients enabled or not on a GPU)."""
+    """True when the differentiable stock-torch layers (conv -> BN -> activation as separate modules)
+    must be used instead of the fused inference kernels: gradients enabled, or tensors not on a GPU.
+    This is no CPU forward: the neighbour operators (ops.random_sample, gather_neighbour, ...) have no
+    CPU implementation and raise FFB6DNativeError on the first CPU tensor they see
+    (tests/test_model_cpu.py::test_forward_on_cpu_tensors_fails_loudly)."""
     return torch.is_grad_enabled() or not x.is_cuda
 
 

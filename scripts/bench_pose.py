@@ -17,7 +17,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--n-points", type=int, default=12288)
 ap.add_argument("--objects", type=int, default=5)
 ap.add_argument("--steps", type=int, default=10)
-ap.add_argument("--cpu", type=int, default=1, help="time the oracle on one frame too")
+ap.add_argument("--cpu", type=int, default=0, help="1: also time the reference algorithm (oracle/pose_ref.py, the CPU checker) on one frame as the CPU baseline leg")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")

@@ -87,3 +87,21 @@ def test_patcher_swaps_reference_operators():
     assert FakeAtt().forward.__func__ is patch._att_pooling_forward
     undo()
     assert FakeFFB6D.random_sample(None, None) == "ref" and FakeAtt().forward(None) == "ref"
+
+
+def test_forward_on_cpu_tensors_fails_loudly():
+    """There is no CPU fallback of the hot path: a forward on CPU tensors stops at the first hand-written
+    operator with FFB6DNativeError instead of silently computing something with stock torch."""
+    import numpy as np
+    from ffb6d_amd import _lib, synth
+    from oracle import knn as oknn
+    from oracle import pyramid as opyr
+    frames = synth.make_batch(7, 1, n_points=1024, height=120, width=160)
+    idx = opyr.build_batch(frames, oknn.knn_search)
+    inputs = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in idx.items()}
+    inputs = {k: (v.long() if v.dtype == torch.int32 else v) for k, v in inputs.items()}
+    inputs.update(rgb=torch.from_numpy(frames["rgb"]).float(), cld_rgb_nrm=torch.from_numpy(frames["cld_rgb_nrm"]),
+                  choose=torch.from_numpy(frames["choose"]).long())
+    net = M.FFB6D(n_classes=5, n_pts=1024).eval()
+    with torch.no_grad(), pytest.raises(_lib.FFB6DNativeError):
+        net(inputs)
