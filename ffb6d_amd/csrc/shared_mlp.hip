@@ -66,12 +66,17 @@ __device__ __forceinline__ float row_ror(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + ROR, 0xf, 0xf, false));
 }
+// max over a DPP row: v_max_f32 with the rotated operand folded in (the compiler folds row_ror into v_add_f32 for
+// the sums below, but for fmaxf it emits mov_dpp + two canonicalising v_max per step -- 22 instructions instead
+// of 8).  s_nop 1: a DPP operand written by the previous VALU instruction needs two wait states, and the
+// hazard recogniser does not look inside inline assembly.
 __device__ __forceinline__ float row16_max(float v)
 {
-    v = fmaxf(v, row_ror<8>(v));
-    v = fmaxf(v, row_ror<4>(v));
-    v = fmaxf(v, row_ror<2>(v));
-    v = fmaxf(v, row_ror<1>(v));
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(v));
     return v;
 }
 __device__ __forceinline__ float row16_sum(float v)
@@ -255,7 +260,10 @@ shared_mlp_kernel(const MlpParams p)
     // epilogue: bias + gathered term + activation; for a fixed accumulator register the 32 lanes
     // of a half-wave hold 32 consecutive p of one output row -> 128-byte coalesced stores
     if constexpr (ATT) {
-        // out = pooled [B, cout, P/16]; every 32-column MFMA tile holds two complete points
+        // out = pooled [B, cout, P/16]; every 32-column MFMA tile holds two complete points.
+        // softmax_k(a) . f = sum_k f_k 2^((a_k - max) log2 e) / sum_k 2^((a_k - max) log2 e): one v_exp_f32 and
+        // one v_rcp_f32 per element (both ~1 ulp) instead of the libm expf and an IEEE division; 32-bit
+        // element offsets (the entry point bounds d * P).
         float* out = p.out + (size_t)b * p.out_bs;
         const int npts = p.P >> 4;
 #pragma unroll
@@ -270,10 +278,14 @@ shared_mlp_kernel(const MlpParams p)
                     const bool ok = in && m < p.cout;
                     const float a = ok ? acc[i][j][r] : 0.f;
                     float f = 0.f;
-                    if (ok) f = (m < p.k1) ? x1[(size_t)m * p.P + col] : x2[(size_t)(m - p.k1) * p.P + col];
-                    const float e = expf(a - row16_max(a));
-                    const float pooled = row16_sum(f * (e / row16_sum(e)));
-                    if (ok && (l31 & 15) == 0) out[(size_t)m * npts + (col >> 4)] = pooled;
+                    if (ok) {
+                        const bool first = m < p.k1;
+                        const float* src = first ? x1 : x2;
+                        f = src[(unsigned)((first ? m : m - p.k1) * p.P + col)];
+                    }
+                    const float e = __builtin_amdgcn_exp2f((a - row16_max(a)) * 1.44269504088896341f);
+                    const float pooled = row16_sum(f * e) * __builtin_amdgcn_rcpf(row16_sum(e));
+                    if (ok && (l31 & 15) == 0) out[(unsigned)(m * npts + (col >> 4))] = pooled;
                 }
             }
         }
@@ -551,7 +563,7 @@ extern "C" int ffb6d_att_score_pool_f32(const float* wt, const float* x1, int64_
     if (B == 0 || N == 0) return FFB6D_OK;
     FFB6D_REQUIRE(wt && x1 && out && ((k2 == 0) == (x2 == nullptr)), "att_score_pool: null pointer");
     const int64_t d = k1 + k2, P = N * 16;
-    FFB6D_REQUIRE(P < (1LL << 31) && d < (1 << 20) && B < 65536, "att_score_pool: too large");
+    FFB6D_REQUIRE(P < (1LL << 31) && d < (1 << 20) && B < 65536 && d * P < (1LL << 31), "att_score_pool: too large");
     MlpParams p;
     p.wt = wt; p.bias = nullptr; p.x1 = x1; p.x2 = x2; p.yg = nullptr; p.gidx = nullptr; p.out = out;
     p.x1_bs = k1 * P; p.x2_bs = k2 * P; p.yg_bs = 0; p.out_bs = d * N;
