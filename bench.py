@@ -375,6 +375,11 @@ def main():
             "streams": 2 if overlap else 1,
             **({} if pyramid_on_side else {"forward_only_fps": args.batch * world / (fwd_ms * 1e-3)}),
             "roofline": roofline,
+            # hot-path-only time, i.e. without the MIOpen convolutions of the colour branch = sum of
+            # the HIP-event durations of every hand-written launch of a step (with two streams these intervals
+            # overlap the convolutions and each other, so the sum is GPU time, not a share of ms_per_step)
+            "hot_path_only": {"kernel_ms_per_step": sum(v["ms_per_step"] for v in ops_table.values()),
+                              "launches_per_step": sum(v["launches_per_step"] for v in ops_table.values())},
             "hot_path_ops": ops_table,
         }
         if not args.no_cpu_baseline and world == 1 and not train:
