@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B of the two shared-MLP GEMM kernels on the per-frame (MFMA-bound) layer shapes of one FFB6D
-forward (bs=8, N=12288): FFB6D_MLP_PIPE=0 (first generation) vs 1 (buffer-load pipelined loop).
-Each variant runs in its own process (the switch is read once)."""
+forward (bs=8, N=12288): FFB6D_MLP_PIPE=0 (first generation) vs 1 (buffer-load pipelined loop, the default);
+`python scripts/bench_mlp_ab.py 1 2` adds the experimental LDS-direct variant (2, Cout > 64 only).
+Each variant runs in its own process (the switch is read once).  The max|err| column is against a torch
+baddbmm reference, the `sum` column must be identical between variants (same tiles, same summation order)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (name, K1, K2, Cout, P, gather rows or 0)
