@@ -1,5 +1,5 @@
 """Probe: MIOpen fp32 convolutions of the colour branch, NCHW vs channels_last (planning data)."""
-import torch, time
+import torch
 torch.backends.cudnn.benchmark = True
 dev = torch.device("cuda:0")
 cases = [("up1 1024->256 3x3 @120x160", 1024, 256, 120, 160, 1), ("layer3 256->256 3x3 d2 @60x80", 256, 256, 60, 80, 2),

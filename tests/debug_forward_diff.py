@@ -1,11 +1,11 @@
-"""Debug aid (GPU box): run ffb6d_amd.model.FFB6D at full size with (a) HIP ops + folded GEMMs,
+"""Debug aid, not a test (GPU box; lives under tests/ because it mixes oracle operators into the model): run ffb6d_amd.model.FFB6D at full size with (a) HIP ops + folded GEMMs,
 (b) plain-torch ops (oracle/ops_ref) + folded GEMMs, (c) HIP ops + unfused conv/BN, and print the
 per-module max deviation relative to the module's output range, to localise a mismatch."""
 import json, os, sys, types
-import numpy as np, torch
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ffb6d_amd import model as M, ops, pyramid, synth
+from ffb6d_amd import model as M, pyramid, synth
 from oracle import ops_ref
 
 dev = torch.device("cuda:0")
