@@ -17,6 +17,8 @@ SIGNATURES = {
     "cpp_knn_omp": (None, [_vp, _sz, _sz, _vp, _sz, _sz, _vp]),
     "cpp_knn_batch": (None, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
     "cpp_knn_batch_omp": (None, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
+    "cpp_knn_batch_distance_pick": (None, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
+    "cpp_knn_batch_distance_pick_omp": (None, [_vp, _sz, _sz, _sz, _vp, _sz, _sz, _vp]),
     "ffb6d_knn_workspace_bytes": (_sz, [_i64, _i64, _i64, _i32]),
     "ffb6d_knn_batch_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ffb6d_knn_prepared_bytes": (_sz, [_i64, _i64]),

@@ -8,7 +8,8 @@ argument meaning, dtypes and output layout, backed by the gfx950 library.
 numpy arrays go through the host-pointer C entry points `cpp_knn*` (same names and
 signatures as knn_.h:4-19); `knn_batch_device` is the additional device-tensor entry the
 reference lacks (torch tensors in/out, stream-ordered, no host round trip).
-`knn_batch_distance_pick` is deliberately absent (unused by FFB6D, time-seeded)."""
+`knn_batch_distance_pick(pts, nqueries, K, omp=False)` mirrors knn.pyx:110-148 (unused by FFB6D; seeded
+from time(0) like upstream unless FFB6D_KNN_PICK_SEED is set)."""
 import numpy as np
 
 from . import _lib
@@ -54,6 +55,25 @@ def knn_batch(pts, queries, K, omp=False):
     if indices.size and indices.min() < 0:
         raise _lib.FFB6DNativeError("cpp_knn_batch failed: " + _lib.last_error())
     return indices
+
+
+def knn_batch_distance_pick(pts, nqueries, K, omp=False):
+    """knn.pyx:110-148: per frame draw `nqueries` query points (least-used first) and return
+    (indices int64 [B,nqueries,K], queries float32 [B,nqueries,3])."""
+    lib = _lib.load()
+    pts_c = np.ascontiguousarray(pts, dtype=np.float32)
+    if pts_c.ndim != 3 or pts_c.shape[2] != 3:
+        raise ValueError(f"expected [B,N,3] points, got {pts_c.shape}")
+    K, nqueries = int(K), int(nqueries)
+    if not 1 <= K <= 32 or pts_c.shape[1] < K:
+        raise ValueError(f"need 1 <= K <= 32 and npts >= K (K={K}, npts={pts_c.shape[1]})")
+    indices = np.full((pts_c.shape[0], nqueries, K), -1, dtype=np.int64)
+    queries = np.zeros((pts_c.shape[0], nqueries, 3), dtype=np.float32)
+    fn = lib.cpp_knn_batch_distance_pick_omp if omp else lib.cpp_knn_batch_distance_pick
+    fn(pts_c.ctypes.data, pts_c.shape[0], pts_c.shape[1], 3, queries.ctypes.data, nqueries, K, indices.ctypes.data)
+    if indices.size and indices.min() < 0:
+        raise _lib.FFB6DNativeError("cpp_knn_batch_distance_pick failed: " + _lib.last_error())
+    return indices, queries
 
 
 class PreparedPoints:

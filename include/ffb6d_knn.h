@@ -5,9 +5,12 @@
  *     ffb6d/models/RandLA/utils/nearest_neighbors/knn_.h:4-27   (declarations)
  *     ffb6d/models/RandLA/utils/nearest_neighbors/knn_.cxx:22-135 (definitions)
  * which the reference binds from Cython (knn.pyx:7-30 `cdef extern from "knn_.h"`).
- * The four host-pointer entry points below keep the reference's names, argument order
- * and meaning, so knn.pyx can bind this library instead of knn_.cxx unchanged
- * (see INTEGRATION.md).  The result is the exact K-NN set in ascending distance order;
+ * The six host-pointer entry points below keep the reference's names, argument order
+ * and meaning (all six symbols knn.pyx declares, knn.pyx:7-30), exported with C linkage.
+ * knn.pyx is compiled as C++ against the reference's knn_.h, whose declarations are
+ * C++-mangled: to bind this library the maintainer points the `cdef extern from` at this
+ * header instead (one-line change); tests/test_capi_cpu.py
+ * compiles the reference's knn.pyx that way and links it against libffb6d_amd.so.  The result is the exact K-NN set in ascending distance order;
  * squared distances are evaluated in float32 as ((dx*dx + dy*dy) + dz*dz) with no FMA
  * contraction (nanoflann.hpp:323-348); equal distances resolve to the LOWEST support
  * index (the reference's kd-tree keeps the first-visited member of a tie,
@@ -18,8 +21,10 @@
  *     for npts < K, knn_.cxx:121-131); violations are reported through
  *     ffb6d_last_error() and the output is left untouched.
  *   - `_omp` and non-`_omp` variants are the same GPU launch (there is no host loop).
- *   - cpp_knn_batch_distance_pick[_omp] (knn_.cxx:138-271) are NOT provided: they are
- *     unused by FFB6D and seeded from time(0), i.e. not reproducible by construction.
+ *   - cpp_knn_batch_distance_pick[_omp] (knn_.cxx:138-271; unused by FFB6D) seed their
+ *     std::mt19937 from time(0) like upstream unless FFB6D_KNN_PICK_SEED is set in the
+ *     environment (tests); the _omp variant, which races on one generator upstream, returns
+ *     the same result as the serial variant here.
  *
  * All pointers are plain host pointers for the cpp_* functions (the library stages them
  * through device memory itself) and plain device pointers for the ffb6d_*_device
@@ -65,6 +70,16 @@ void cpp_knn_batch(const float* batch_data, const size_t batch_size, const size_
 void cpp_knn_batch_omp(const float* batch_data, const size_t batch_size, const size_t npts,
                        const size_t dim, const float* queries, const size_t nqueries,
                        const size_t K, long* batch_indices);
+
+/* knn_.h:21-27 / knn_.cxx:138-271: draws nqueries query points per frame (least-used points first, see
+ * csrc/knn_pick.hip) and returns them with their K-NN.  batch_data [B,npts,dim] in; queries [B,nqueries,dim]
+ * and batch_indices [B,nqueries,K] out (caller allocated, knn.pyx:133-134). */
+void cpp_knn_batch_distance_pick(const float* batch_data, const size_t batch_size, const size_t npts,
+                                 const size_t dim, float* queries, const size_t nqueries,
+                                 const size_t K, long* batch_indices);
+void cpp_knn_batch_distance_pick_omp(const float* batch_data, const size_t batch_size, const size_t npts,
+                                     const size_t dim, float* batch_queries, const size_t nqueries,
+                                     const size_t K, long* batch_indices);
 
 /* ---- device-pointer entry points ------------------------------------------------ */
 /* Scratch bytes ffb6d_knn_batch_device needs for this shape (0 is possible). */

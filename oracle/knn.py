@@ -28,6 +28,8 @@ def lib():
         l.oracle_knn_batch.restype = None
         l.oracle_knn_batch_dist.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp, vp]
         l.oracle_knn_batch_dist.restype = None
+        l.oracle_knn_batch_distance_pick.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp, ctypes.c_uint32]
+        l.oracle_knn_batch_distance_pick.restype = None
         _lib = l
     return _lib
 
@@ -46,6 +48,18 @@ def knn_batch(pts, queries, K, omp=False, return_dist=False):
         return idx, dist
     lib().oracle_knn_batch(p.ctypes.data, B, npts, dim, q.ctypes.data, nq, K, idx.ctypes.data)
     return idx
+
+
+def knn_batch_distance_pick(pts, nqueries, K, seed, omp=False):
+    """knn.pyx:110-148 around the restatement of cpp_knn_batch_distance_pick (knn_.cxx:138-203), with the
+    std::mt19937 seed passed in instead of time(0).  Returns (indices int64 [B,nq,K], queries f32 [B,nq,3])."""
+    p = np.ascontiguousarray(pts, dtype=np.float32)
+    B, npts, dim = p.shape
+    idx = np.zeros((B, nqueries, K), dtype=np.int64)
+    queries = np.zeros((B, nqueries, dim), dtype=np.float32)
+    lib().oracle_knn_batch_distance_pick(p.ctypes.data, B, npts, dim, queries.ctypes.data, nqueries, K,
+                                         idx.ctypes.data, int(seed) & 0xffffffff)
+    return idx, queries
 
 
 def knn(pts, queries, K, omp=False):

@@ -21,7 +21,7 @@
  *   output     long[B][Q][K], caller allocated (knn.pyx:93), row-major.
  *
  * Pinned against the real reference (oracle/_ref/libknn_ref.so built from the
- * reference's own knn_.cxx) in tests/test_oracle_vs_ref.py and through the hashes
+ * reference's own knn_.cxx) in tests/test_oracle_cpu.py and through the hashes
  * in tests/golden/knn_pyramid_hashes.json.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
@@ -132,4 +132,78 @@ void oracle_knn_batch_dist(const float *batch_data, size_t batch_size, size_t np
         free(ids);
         free(dists);
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cpp_knn_batch_distance_pick (knn_.cxx:138-203): per frame `nqueries` sequential draws
+ *   candidates = { i : used[i] == current_id }  (ascending i; if empty current_id = min(used))
+ *   index      = candidates[mt_rand() % candidates.size()]
+ *   ids        = K-NN of points[index];  used[ids[k]]++ ;  used[index] += 100
+ * std::mt19937 (seeded with time(0) upstream) is restated below; ONE generator is shared by the
+ * frames of a batch, consumed frame after frame.  Pinned against the reference's own function
+ * compiled with a fixed clock (oracle/ref_shim.cpp, oracle/_ref/libknn_ref.so) in
+ * tests/test_oracle_cpu.py. */
+typedef struct { uint32_t mt[624]; int mti; } oracle_mt19937;
+
+static void mt_seed(oracle_mt19937 *g, uint32_t seed)
+{
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; ++i)
+        g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->mti = 624;
+}
+
+static uint32_t mt_next(oracle_mt19937 *g)
+{
+    if (g->mti >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->mti = 0;
+    }
+    uint32_t y = g->mt[g->mti++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+void oracle_knn_batch_distance_pick(const float *batch_data, size_t batch_size, size_t npts, size_t dim,
+                                    float *batch_queries, size_t nqueries, size_t K, long *batch_indices,
+                                    uint32_t seed)
+{
+    if (K == 0 || npts == 0) return;
+    oracle_mt19937 g;
+    mt_seed(&g, seed);
+    int64_t *ids = (int64_t *)malloc(sizeof(int64_t) * K);
+    float *dists = (float *)malloc(sizeof(float) * K);
+    int *used = (int *)malloc(sizeof(int) * npts);
+    size_t *cand = (size_t *)malloc(sizeof(size_t) * npts);
+    for (size_t b = 0; b < batch_size; ++b) {
+        const float *pts = batch_data + b * npts * dim;
+        for (size_t i = 0; i < npts; ++i) used[i] = 0;
+        int current_id = 0;
+        for (size_t q = 0; q < nqueries; ++q) {
+            size_t nc = 0;
+            while (nc == 0) {
+                for (size_t i = 0; i < npts; ++i)
+                    if (used[i] == current_id) cand[nc++] = i;
+                if (nc == 0) {
+                    int m = used[0];
+                    for (size_t i = 1; i < npts; ++i) if (used[i] < m) m = used[i];
+                    current_id = m;
+                }
+            }
+            size_t index = cand[(size_t)mt_next(&g) % nc];
+            const float *query = pts + index * dim;
+            knn_one(pts, npts, dim, query, K, ids, dists);
+            for (size_t k = 0; k < K; ++k) used[ids[k]]++;
+            used[index] += 100;
+            for (size_t k = 0; k < K; ++k) batch_indices[(b * nqueries + q) * K + k] = (long)ids[k];
+            for (size_t i = 0; i < dim; ++i) batch_queries[(b * nqueries + q) * dim + i] = query[i];
+        }
+    }
+    free(ids); free(dists); free(used); free(cand);
 }

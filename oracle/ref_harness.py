@@ -49,8 +49,29 @@ def ref_knn_lib():
         for name in ("ref_cpp_knn_batch", "ref_cpp_knn_batch_omp"):
             getattr(lib, name).argtypes = [vp, sz, sz, sz, vp, sz, sz, vp]
             getattr(lib, name).restype = None
+        lib.ref_cpp_knn_batch_distance_pick.argtypes = [vp, sz, sz, sz, vp, sz, sz, vp]
+        lib.ref_cpp_knn_batch_distance_pick.restype = None
+        lib.ref_set_fixed_time.argtypes = [ctypes.c_long]
+        lib.ref_set_fixed_time.restype = None
         _ref_knn_lib = lib
     return _ref_knn_lib
+
+
+def ref_knn_batch_distance_pick(pts, nqueries, K, seed):
+    """knn.pyx:110-148 marshalling around the reference's cpp_knn_batch_distance_pick, with the clock the
+    reference seeds its std::mt19937 from (time(0), knn_.cxx:143) pinned to `seed` by oracle/ref_shim.cpp."""
+    lib = ref_knn_lib()
+    pts_c = np.ascontiguousarray(pts, dtype=np.float32)
+    B, npts, dim = pts_c.shape
+    idx = np.zeros((B, nqueries, K), dtype=np.int64)
+    queries = np.zeros((B, nqueries, dim), dtype=np.float32)
+    lib.ref_set_fixed_time(int(seed))
+    try:
+        lib.ref_cpp_knn_batch_distance_pick(pts_c.ctypes.data, B, npts, dim, queries.ctypes.data, nqueries, K,
+                                            idx.ctypes.data)
+    finally:
+        lib.ref_set_fixed_time(-1)
+    return idx, queries
 
 
 def ref_knn_batch(pts, queries, K, omp=False):

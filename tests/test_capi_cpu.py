@@ -26,6 +26,7 @@ def declared_functions():
 def test_headers_declare_the_expected_entry_points():
     names = declared_functions()
     for must in ("cpp_knn", "cpp_knn_omp", "cpp_knn_batch", "cpp_knn_batch_omp",
+                 "cpp_knn_batch_distance_pick", "cpp_knn_batch_distance_pick_omp",
                  "ffb6d_knn_batch_device", "ffb6d_random_sample_f32",
                  "ffb6d_nearest_interpolation_f32", "ffb6d_gather_neighbour_f32",
                  "ffb6d_relative_pos_encoding_f32", "ffb6d_att_pool_f32", "ffb6d_shared_mlp_f32",
@@ -40,6 +41,34 @@ def test_library_exports_every_declared_symbol(native_lib):
         assert hasattr(native_lib, name), f"{name} declared in include/ but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
     assert native_lib.ffb6d_abi_version() >= 1000
+
+
+@pytest.mark.reference
+def test_reference_cython_binding_builds_and_links_against_this_library(native_lib, tmp_path):
+    """The reference's own knn.pyx (knn.pyx:7-148: `cdef extern from "knn_.h"`, all six cpp_knn* symbols), taken
+    verbatim except for its stale line 2 (`# distutils: sources = knn.cxx` names a file that does not exist
+    upstream either), compiles against include/knn_.h and links against libffb6d_amd.so -- no knn_.cxx, no
+    nanoflann.  Import succeeds, i.e. every symbol the binding declares resolves in this library."""
+    import subprocess
+    import sys
+    import sysconfig
+    from ffb6d_amd import build
+    ref = "/root/reference/ffb6d/models/RandLA/utils/nearest_neighbors/knn.pyx"
+    lines = open(ref).read().split("\n")
+    assert lines[1].startswith("# distutils: sources")
+    (tmp_path / "nearest_neighbors.pyx").write_text("\n".join(lines[:1] + lines[2:]))
+    subprocess.run([sys.executable, "-m", "cython", "--cplus", "-3", "nearest_neighbors.pyx"], cwd=tmp_path, check=True)
+    so = tmp_path / ("nearest_neighbors" + sysconfig.get_config_var("EXT_SUFFIX"))
+    lib_dir = os.path.dirname(build.LIB_PATH)
+    subprocess.run(["g++", "-O1", "-shared", "-fPIC", "-w", "-std=c++11", "nearest_neighbors.cpp", "-o", str(so),
+                    "-I" + os.path.join(ROOT, "include"), "-I" + sysconfig.get_paths()["include"],
+                    "-I" + np.get_include(), "-L" + lib_dir, "-lffb6d_amd", "-Wl,-rpath," + lib_dir,
+                    "-Wl,--no-undefined", "-L" + sysconfig.get_config_var("LIBDIR"),
+                    "-lpython" + sysconfig.get_config_var("LDVERSION")], cwd=tmp_path, check=True)
+    code = ("import sys; sys.path.insert(0, %r); import nearest_neighbors as m; "
+            "print(all(hasattr(m, n) for n in ('knn', 'knn_batch', 'knn_batch_distance_pick')))" % str(tmp_path))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True)
+    assert res.stdout.strip() == "True", res.stdout + res.stderr
 
 
 def test_pose_entry_points_validate_arguments_without_a_gpu(native_lib):

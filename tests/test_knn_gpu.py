@@ -171,3 +171,25 @@ def test_prepared_sets_and_raw_queries_agree_with_the_oracle(device):
     np.testing.assert_array_equal(got_1.cpu().numpy(), oknn.knn_batch(sup, qry, 1))
     with pytest.raises(ValueError):
         nn.knn_prepared(ps, q_dev, 1)                                                     # raw needs 2 <= K <= 16
+
+
+def test_distance_pick_matches_reference_goldens_and_oracle(device, monkeypatch):
+    """cpp_knn_batch_distance_pick[_omp] (knn_.h:21-27) through the C ABI: bit-exact against the reference's own
+    output (knn_pick_small.npz, clock pinned) and against the oracle on a bigger frame."""
+    z = np.load(os.path.join(GOLDEN, "knn_pick_small.npz"))
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        pts, K, seed = z[name + "/pts"], int(z[name + "/K"]), int(z[name + "/seed"])
+        monkeypatch.setenv("FFB6D_KNN_PICK_SEED", str(seed))
+        for omp in (False, True):
+            idx, q = nn.knn_batch_distance_pick(pts, z[name + "/idx"].shape[1], K, omp=omp)
+            np.testing.assert_array_equal(idx, z[name + "/idx"], err_msg=name)
+            np.testing.assert_array_equal(q, z[name + "/queries"], err_msg=name)
+    pts = np.random.RandomState(11).rand(2, 3072, 3).astype(np.float32)
+    monkeypatch.setenv("FFB6D_KNN_PICK_SEED", "4242")
+    idx, q = nn.knn_batch_distance_pick(pts, 1000, 16)
+    want_i, want_q = oknn.knn_batch_distance_pick(pts, 1000, 16, 4242)
+    np.testing.assert_array_equal(idx, want_i)
+    np.testing.assert_array_equal(q, want_q)
+    # every query is one of the frame's points and its own nearest neighbour
+    assert (idx[..., 0] == np.array([[np.flatnonzero((pts[b] == q[b, i]).all(1))[0] for i in range(1000)]
+                                     for b in range(2)])).all()

@@ -87,7 +87,29 @@ def test_ops_ref_matches_reference_goldens():
     np.testing.assert_allclose(ops_ref.att_pool(t(z["fs"]), t(z["act"])).numpy(), z["att_pool"], rtol=1e-6, atol=1e-6)
 
 
+def test_oracle_distance_pick_matches_reference_goldens():
+    """knn_pick_small.npz = output of the reference's cpp_knn_batch_distance_pick with a pinned clock
+    (tests/golden/make_golden_pick.py): the restated std::mt19937, candidate order, counters and K-NN agree."""
+    z = np.load(os.path.join(GOLDEN, "knn_pick_small.npz"))
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        pts, K, seed = z[name + "/pts"], int(z[name + "/K"]), int(z[name + "/seed"])
+        idx, q = oknn.knn_batch_distance_pick(pts, z[name + "/idx"].shape[1], K, seed)
+        np.testing.assert_array_equal(idx, z[name + "/idx"], err_msg=name)
+        np.testing.assert_array_equal(q, z[name + "/queries"], err_msg=name)
+
+
 # ---- direct comparisons with the reference's own code (build container only) ------------
+@pytest.mark.reference
+def test_oracle_distance_pick_equals_reference():
+    from oracle import ref_harness as rh
+    pts = np.random.RandomState(5).rand(2, 700, 3).astype(np.float32)
+    for seed in (1, 99991):
+        a = oknn.knn_batch_distance_pick(pts, 300, 16, seed)
+        b = rh.ref_knn_batch_distance_pick(pts, 300, 16, seed)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+
+
 @pytest.mark.reference
 @pytest.mark.parametrize("B,S,Q,K", [(1, 3000, 3000, 16), (2, 777, 1500, 1), (1, 4800, 48, 16), (1, 48, 4800, 1)])
 def test_oracle_knn_equals_reference_kdtree(B, S, Q, K):
