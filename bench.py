@@ -35,7 +35,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3     # fp32 peak, vector FMA = f32-input MFMA (MI355X_MICROARCH.md)
-METRIC = "RGB-D frames/sec fwd (480x640, N=12288, bs=8)"
+METRIC = "RGB-D frames/sec fwd (480x640, N=12288, bs=8)"      # BASELINE.json; --config 4 reports N=24576 in its line
 
 
 def parse():
@@ -43,8 +43,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
-    ap.add_argument("--n-points", type=int, default=12288)
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: 8)")
+    ap.add_argument("--n-points", type=int, default=None, help="points per frame (default: by --config)")
     ap.add_argument("--n-classes", type=int, default=22)
     ap.add_argument("--index-dtype", choices=["int64", "int32"], default="int64")
     ap.add_argument("--roofline-op", default="auto", help="op whose launches are event-timed in the timed region")
@@ -67,17 +67,59 @@ def parse():
     ap.add_argument("--overlap-pyramid", type=int, default=0,
                     help="1: enqueue the index pyramid on the second stream too (under the colour stem); "
                          "measured neutral on MI355X, the GPU is throughput-bound (DESIGN.md section 4b)")
+    ap.add_argument("--layout", choices=["pm", "cm"], default="pm",
+                    help="activation layout of the fused forward: pm = point-major / pixel-major rows (default), "
+                         "cm = the reference's channel-major layout on the first-generation kernels (A/B)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4),
+                    help="BASELINE.json workload: 2 = bs=8, N=12288, 22 classes (the headline metric, default); "
+                         "4 = YCB-shaped bs=8, N=24576, 22 classes.  Explicit --batch / --n-points override it")
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 8
+    if args.n_points is None:
+        args.n_points = 24576 if args.config == 4 else 12288
+    return args
 
 
 # hot_path_ops key -> kernel instantiation as rocprofv3 lists it (csrc/shared_mlp.hip: per-frame tiles with
-# Cout > 32 take the buffer-load pipelined loop, small per-frame P the flat split-K kernel)
+# Cout > 32 take the buffer-load pipelined loop, small per-frame P the flat split-K kernel; csrc/mlp_pm.hip: tile id
+# from ffb6d_mlp_pm_tile)
 MLP_KERNEL_NAMES = {"shared_mlp<128,frame>": "shared_mlp_pipe_kernel<128>", "shared_mlp<64,frame>": "shared_mlp_pipe_kernel<64>",
                     "shared_mlp<32,frame>": "shared_mlp_kernel<32, false>", "shared_mlp<128,flat>": "shared_mlp_kernel<128, true>",
-                    "shared_mlp<64,flat>": "shared_mlp_kernel<64, true>", "shared_mlp<32,flat>": "shared_mlp_kernel<32, true>"}
+                    "shared_mlp<64,flat>": "shared_mlp_kernel<64, true>", "shared_mlp<32,flat>": "shared_mlp_kernel<32, true>",
+                    "mlp_pm<128x128>": "mlp_pm_kernel<2, 2, 2, 2, false>", "mlp_pm<64x256>": "mlp_pm_kernel<2, 2, 1, 4, false>",
+                    "mlp_pm<32x256>": "mlp_pm_kernel<1, 2, 1, 4, false>", "mlp_pm<64x64>": "mlp_pm_kernel<1, 1, 2, 2, false>",
+                    "mlp_pm<64x32,ksplit>": "mlp_pm_kernel<2, 1, 2, 2, true>", "att_pool_pm": "att_pool_pm_kernel<TM, TN>"}
+PM_TILES = {1: "128x128", 2: "64x256", 3: "32x256", 4: "64x64", 5: "64x32,ksplit"}
+
+
+def gemm_flops(name, rec_tag, batch):
+    """algorithmic flops of one traced GEMM launch (tags: see ffb6d_amd/ops.py / ops_pm.py)"""
+    if name.startswith("shared_mlp"):
+        return 2.0 * batch * rec_tag[0] * rec_tag[1] * rec_tag[2]          # (K, Cout, P per frame)
+    if name.startswith("mlp_pm"):
+        return 2.0 * rec_tag[0] * rec_tag[1] * rec_tag[2]                  # (K, Cout, rows of all frames, tile)
+    if name.startswith("att_pool_pm"):
+        return 2.0 * rec_tag[0] * rec_tag[0] * 16 * rec_tag[1] * batch     # (d, N): score GEMM d x d over 16 N pairs
+    if name.startswith("att_score_pool"):
+        return 2.0 * rec_tag[0] * rec_tag[0] * 16 * rec_tag[1] * batch
+    return 0.0
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and args.dist_backend == "nccl":
+        raise SystemExit(f"--gpus {args.gpus} requested but only {have} GPU(s) are visible")
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
 
 
 def state_dict(n_classes):
@@ -156,7 +198,9 @@ def main():
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/ffb6d_miopen_cache_rank{local_rank}")
         for d in (os.environ["MIOPEN_USER_DB_PATH"], os.environ["MIOPEN_CUSTOM_CACHE_DIR"]):
             os.makedirs(d, exist_ok=True)
-    if world_env != args.gpus and world_env > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)            # never returns: a multi-GPU request is never silently run on one rank
+    if world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
@@ -187,7 +231,7 @@ def main():
 
     # per-rank batch, resident in HBM before the timed region: rank r holds samples
     # [r*batch, (r+1)*batch) of the config-2 synthetic stream (seeds 1000*2 + sample)
-    frames = distributed.shard_frames(2, args.batch, rank, None, n_points=args.n_points)
+    frames = distributed.shard_frames(args.config, args.batch, rank, None, n_points=args.n_points)
     cpu_baseline.frames = frames
     rgb = torch.from_numpy(frames["rgb"]).to(dev).float()
     cld_rgb_nrm = torch.from_numpy(frames["cld_rgb_nrm"]).to(dev)
@@ -203,6 +247,7 @@ def main():
     # enqueued on that stream too (nothing in the colour stem needs an index)
     overlap = bool(args.streams == 2) and not train
     net.two_streams = overlap
+    net.layout = args.layout
     side = net._side_stream(dev) if (overlap and args.overlap_pyramid) else None
 
     def step(record=False):
@@ -293,13 +338,33 @@ def main():
         pyr_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["pyramid"]]))
         fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["forward"]]))
         # split the shared-MLP launches by the kernel instantiation rocprofv3 lists them under:
-        # shared_mlp_kernel<BM, FLAT>, BM by Cout, FLAT for small per-frame P (csrc/shared_mlp.hip)
+        # shared_mlp_kernel<BM, FLAT>, BM by Cout, FLAT for small per-frame P (csrc/shared_mlp.hip); mlp_pm_kernel by tile
         def split_mlp(tr):
             for rec in tr.records.pop("shared_mlp", []):
                 k, cout, pcols = rec[3]
                 bm = 128 if cout > 64 else (64 if cout > 32 else 32)
                 flat = pcols < 2048 and pcols % 4 == 0
                 tr.records.setdefault("shared_mlp<%d,%s>" % (bm, "flat" if flat else "frame"), []).append(rec)
+            for rec in tr.records.pop("mlp_pm", []):
+                tr.records.setdefault("mlp_pm<%s>" % PM_TILES.get(rec[3][3], "?"), []).append(rec)
+
+        def is_gemm(name):
+            return name.startswith(("shared_mlp", "mlp_pm", "att_pool_pm", "att_score_pool"))
+
+        def roofline_of(tr, op):
+            summ = tr.summary().get(op)
+            if not summ or not summ["launches"]:
+                return None
+            sec = summ["total_ms"] * 1e-3
+            if is_gemm(op):
+                flops = sum(gemm_flops(op, t, args.batch) for _, _, _, t in tr.records[op])
+                ach = flops / sec / 1e12
+                return {"bound": "mfma", "achieved": ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / VALU_PEAK_TFLOPS, "kernel": MLP_KERNEL_NAMES.get(op, op) + " (fp32 MFMA 32x32x2)",
+                        "launches": summ["launches"], "avg_launch_us": summ["avg_us"], "flops": flops, "bytes": summ["bytes"]}
+            return {"bound": "hbm", "achieved": summ["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": summ["gbps"] / HBM_PEAK_GBS, "kernel": op, "launches": summ["launches"],
+                    "avg_launch_us": summ["avg_us"], "flops": 0.0, "bytes": summ["bytes"]}
 
         split_mlp(tracer)
         summary = tracer.summary()
@@ -308,56 +373,44 @@ def main():
         cand = {k: v for k, v in summary.items() if not k.startswith("knn") and v["launches"]}
         roof_op = args.roofline_op if args.roofline_op != "auto" else \
             (max(cand, key=lambda k: cand[k]["total_ms"]) if cand else None)
-        summ = summary.get(roof_op)
         roofline = None
-        if summ and summ["launches"]:
+        r = roofline_of(tracer, roof_op) if roof_op else None
+        if r:
             traffic = None
             pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc_file):      # HBM bytes per launch measured offline with rocprofv3 --pmc
                 with open(pmc_file) as fh:
                     table = json.load(fh)
                     traffic = table.get(roof_op, table.get(roof_op.split("<")[0], {})).get("hbm_bytes_per_launch")
-            sec = summ["total_ms"] * 1e-3
-            if roof_op.startswith("shared_mlp"):
-                # fp32 MFMA GEMM: tag = (K, Cout, P) per frame
-                flops = sum(2.0 * args.batch * t[0] * t[1] * t[2] for _, _, _, t in tracer.records[roof_op])
-                ach = flops / sec / 1e12
-                roofline = {"bound": "mfma", "achieved": ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / VALU_PEAK_TFLOPS, "traffic": traffic,
-                            "kernel": MLP_KERNEL_NAMES.get(roof_op, roof_op) + " (fp32 MFMA 32x32x2)",
-                            "launches_per_step": summ["launches"] / args.steps, "avg_launch_us": summ["avg_us"],
-                            "algorithmic_flops_per_step": flops / args.steps,
-                            "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
+            roofline = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+                        "frac": r["frac"], "traffic": traffic, "kernel": r["kernel"],
+                        "launches_per_step": r["launches"] / args.steps, "avg_launch_us": r["avg_launch_us"],
+                        "algorithmic_bytes_per_step": r["bytes"] / args.steps}
+            if r["bound"] == "mfma":
+                roofline["algorithmic_flops_per_step"] = r["flops"] / args.steps
             else:
-                ach = summ["gbps"]
-                roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": roof_op,
-                            "launches_per_step": summ["launches"] / args.steps,
-                            "avg_launch_us": summ["avg_us"],
-                            "algorithmic_bytes_per_launch": summ["bytes"] / summ["launches"],
-                            "algorithmic_bytes_per_step": summ["bytes"] / args.steps}
+                roofline["algorithmic_bytes_per_launch"] = r["bytes"] / r["launches"]
         if roofline and serial is not None:
             split_mlp(serial)
-            iso = serial.summary().get(roof_op)
-            if iso and iso["launches"]:
-                if roofline["bound"] == "mfma":
-                    iso_ach = sum(2.0 * args.batch * t[0] * t[1] * t[2] for _, _, _, t in serial.records[roof_op]) \
-                        / (iso["total_ms"] * 1e-3) / 1e12
-                else:
-                    iso_ach = iso["gbps"]
-                roofline["isolated"] = {"achieved": iso_ach, "frac": iso_ach / roofline["peak"],
-                                        "avg_launch_us": iso["avg_us"],
+            iso = roofline_of(serial, roof_op)
+            if iso:
+                roofline["isolated"] = {"achieved": iso["achieved"], "frac": iso["frac"], "avg_launch_us": iso["avg_launch_us"],
                                         "note": "same kernel, same steps on one stream after the timed region: "
                                                 "no kernel of the other stream shares the CUs"}
         ops_table = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["total_ms"] / args.steps,
                          "algorithmic_GBps": v["gbps"]} for k, v in summary.items()}
+        for k in ops_table:
+            if is_gemm(k):      # GEMM-shaped ops: MFMA rate next to the byte rate
+                fl = sum(gemm_flops(k, t, args.batch) for _, _, _, t in tracer.records[k])
+                ops_table[k]["algorithmic_TFLOPs"] = fl / (summary[k]["total_ms"] * 1e-3) / 1e12
         if "knn" in summary:
             # exact KNN is VALU/latency bound, not HBM bound: report brute-force-equivalent pairs/s
             pairs = sum(tag[0] * tag[1] for _, _, _, tag in tracer.records["knn"]) * args.batch
             sec = summary["knn"]["total_ms"] * 1e-3
             ops_table["knn"]["bruteforce_equivalent_Gpairs_per_s"] = pairs / sec / 1e9
         line = {
-            "metric": METRIC if not train else "RGB-D frames/sec train step (fwd+bwd+Adam, 480x640, N=12288, bs=8/GPU)",
+            "metric": (METRIC.replace("12288", str(args.n_points)).replace("bs=8", "bs=%d" % args.batch)) if not train else
+                      f"RGB-D frames/sec train step (fwd+bwd+Adam, 480x640, N={args.n_points}, bs={args.batch}/GPU)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -366,8 +419,10 @@ def main():
                                    " incl. on-device 22-call KNN index pyramid; "
                                    f"bs={args.batch}/GPU, N={args.n_points} pts, 480x640 RGB-D, "
                                    f"{args.n_classes} classes, fp32, eval",
-                       "global_batch": args.batch * world, "n_points": args.n_points,
-                       "index_dtype": args.index_dtype, "parallelism": f"dp{world} (independent batches)"},
+                       "baseline_config": args.config, "global_batch": args.batch * world, "n_points": args.n_points,
+                       "index_dtype": args.index_dtype, "layout": args.layout,
+                       "parallelism": f"dp{world} (independent batches, one process per GPU, "
+                                      f"{args.dist_backend if world > 1 else 'no'} process group)"},
             "breakdown_ms": ({"knn_pyramid_on_side_stream": pyr_ms, "step_on_main_stream": fwd_ms,
                               "note": "pyramid + point branch run under the colour branch; both intervals "
                                       "start at the step's first event and overlap"}

@@ -79,7 +79,7 @@ distance_pick_kernel(const float* __restrict__ pts_all, float* __restrict__ quer
     __shared__ Mt19937 gen;
     __shared__ int s_wave[PICK_WAVES];          // per-wave totals of the candidate scan / minima
     __shared__ unsigned long long s_key[PICK_WAVES];
-    __shared__ int s_total, s_index, s_min;
+    __shared__ int s_index, s_min;
     __shared__ unsigned int s_draw;
     __shared__ unsigned long long s_last;
 

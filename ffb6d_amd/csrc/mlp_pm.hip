@@ -1,0 +1,554 @@
+// ffb6d_amd/csrc/mlp_pm.hip -- shared MLP on POINT-MAJOR / PIXEL-MAJOR activations ("channels last") for gfx950.
+//
+// Reference: the same 1x1 Conv + BatchNorm + activation wrappers as csrc/shared_mlp.hip
+//   ffb6d/models/pytorch_utils.py:75-129, ffb6d/models/RandLA/pytorch_utils.py:35-111
+// and the cat / interpolate / residual plumbing around them (ffb6d.py:245-263,273-298,302-312,
+// RandLANet.py:179-184).  Same mathematics, different data layout:
+//
+//   out[r, m] = act( sum_k W[m, k] * X[r, k]  + bias[m]  + Y[yrow(r), m] ),      X = [X1 | X2] along k
+//
+// with activations stored one ROW per point / pixel (r runs over all points of all frames, the
+// C channels of a row are contiguous) and the weight in the layout nn.Conv stores it, [Cout, Cin].
+// Why this layout on MI355X: every gather of the hot path (neighbour features, pixel->point max pooling,
+// point->pixel interpolation, `choose`) then moves whole contiguous rows of C*4 bytes instead of one 4-byte
+// element per 64-byte sector, and BOTH GEMM operands are K-contiguous, which is exactly the register image
+// v_mfma_f32_32x32x2_f32 wants:
+//
+//   lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].  A lane loads ONE float4 of its row at
+//   k0 + 4*(l>>5): the two half-waves hold k0..k0+3 and k0+4..k0+7, and the MFMA of step t (t = 0..3)
+//   multiplies the pairs (k0+t, k0+4+t).  The sum over k is the same set of products in a different order
+//   (fp32 GEMM parity bar: 1e-5, tests/test_ops_gpu.py), and it makes a lane's operand 16 contiguous bytes.
+//
+// So there is NO LDS staging and NO barrier in the k-loop: both operands stream global -> VGPR -> MFMA through
+// buffer loads (hardware range check = zero fill past the last row, no exec-mask branches), three register
+// stages deep, and the waves of a workgroup share rows only through the L1/L2.  A = weight rows (i = output
+// channel), B = activation rows (j = point): accumulator register r of lane l is channel (r&3)+8*(r>>2)+4*(l>>5)
+// of point l&31, i.e. a lane owns 4 x 4 consecutive channels of ONE point and the epilogue (bias, gathered row of
+// Y, activation) is four 16-byte loads and four 16-byte stores per 32 x 32 tile.
+#include "common.h"
+#include "ffb6d_ops.h"
+
+namespace ffb6d {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BLK = 256;
+
+struct PmParams {
+    const float* w;       // [cout, k1 + k2]  (nn.Conv weight layout, BatchNorm folded)
+    const float* bias;    // [cout] or null
+    const float* x1;      // [rows, ld1] (or [B * px, ld1] when xidx), first k1 floats of a row are used
+    const void* xidx;     // [rows] int32/int64 or null: x1 row of output row r = (r / P) * px + xidx[r]  (operand gather)
+    const float* x2;      // [rows, ld2] or null
+    const float* y;       // [B * py, ldy] rows added in the epilogue, or null
+    const void* gidx;     // [rows] int32/int64: row of the frame's py rows to add; null with y != null: row r itself
+    float* out;           // [rows, ldo]
+    int rows, cout, k1, k2, ld1, ld2, ldy, ldo;
+    int P, py, px;        // output rows per frame (for the gathers), rows of Y / of X1 per frame
+    int act, idx64;
+    int n_pt, n_ct;       // point tiles, channel tiles
+};
+
+// act(v) = max(v, slope * v): slope 1 = identity, 0 = ReLU, 0.2 = LeakyReLU(0.2) -- no branch on the activation code
+__device__ __forceinline__ float activate(float v, float slope) { return fmaxf(v, slope * v); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// TM x TN MFMA tiles of 32 (channels) x 32 (points) per wave; WM x WN waves per workgroup.
+// KSPLIT: the four waves of the workgroup share ONE TM x TN tile and each take a quarter of K (partial sums meet
+// in LDS) -- for the deep layers, where a frame has a few hundred points and K up to 1024: without it a handful of
+// workgroups would each walk the whole K.
+template <int TM, int TN, int WM, int WN, bool KSPLIT>
+__global__ void __launch_bounds__(BLK)
+mlp_pm_kernel(const PmParams p)
+{
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BC = 32 * TM * (KSPLIT ? 1 : WM);     // channels per workgroup
+    constexpr int BP = 32 * TN * (KSPLIT ? 1 : WN);     // points per workgroup
+
+    // XCD-aware tile order: workgroup t runs on XCD t % 8 (observed dispatch rule; speed only).  All channel tiles of
+    // one point tile get consecutive slots of ONE XCD, so the activation rows are fetched into that XCD's L2 once.
+    const int t = blockIdx.x;
+    const int xcd = t & 7, s = t >> 3;
+    const int pt = (s / p.n_ct) * 8 + xcd;
+    const int ct = s % p.n_ct;
+    if (pt >= p.n_pt) return;
+    const int c0 = ct * BC, r0 = pt * BP;
+
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = KSPLIT ? 0 : wave / WN, wn = KSPLIT ? 0 : wave % WN;
+
+    const int K = p.k1 + p.k2;
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)K * 4u);
+    const unsigned x1_rows = p.xidx ? (unsigned)(p.rows / p.P) * (unsigned)p.px : (unsigned)p.rows;
+    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, x1_rows * (unsigned)p.ld1 * 4u);
+    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? (unsigned)p.rows * (unsigned)p.ld2 * 4u : 0u);
+
+    // per-lane byte offsets of this lane's rows (k = 0); rows past the end are out of range -> zeros
+    int w_vo[TM], x1_vo[TN], x2_vo[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) w_vo[i] = ((c0 + (wm * TM + i) * 32 + l31) * K + 4 * kh) * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = r0 + (wn * TN + j) * 32 + l31;
+        int xr = r;
+        if (p.xidx) {           // gathered operand rows: the gather IS the operand load
+            xr = 0x1fffffff / p.ld1;                            // out of range -> zeros
+            if (r < p.rows)
+                xr = (r / p.P) * p.px + (p.idx64 ? (int)static_cast<const long long*>(p.xidx)[r]
+                                                 : static_cast<const int*>(p.xidx)[r]);
+        }
+        x1_vo[j] = (xr * p.ld1 + 4 * kh) * 4;
+        x2_vo[j] = (r * p.ld2 + 4 * kh) * 4;
+    }
+
+    const int n1 = p.k1 >> 3, nsteps = K >> 3;            // k-steps of 8 (k1, k2 multiples of 8)
+    // this wave's step range
+    int s_beg = 0, s_end = nsteps;
+    if (KSPLIT) {
+        const int per = (nsteps + 3) >> 2;
+        s_beg = wave * per;
+        s_end = min(nsteps, s_beg + per);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // three register stages; a stage = 8 k of every row of the wave's tile.  The k offset travels in the per-lane
+    // offset (the scalar offset of a buffer load is not range checked): a surplus prefetch past the last step reads
+    // the following floats of the row buffer or, past its end, zeros -- never used either way.
+    u32x4 wa0[TM], wa1[TM], wa2[TM], xb0[TN], xb1[TN], xb2[TN];
+    auto load = [&](int step, u32x4 (&wa)[TM], u32x4 (&xb)[TN]) {
+        const bool second = step >= n1;
+        const __amdgpu_buffer_rsrc_t rx = second ? rs_x2 : rs_x1;
+        const int wko = step * 32;                                  // bytes: 8 floats per step
+        const int xko = (second ? step - n1 : step) * 32;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) wa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[i] + wko, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (second ? x2_vo[j] : x1_vo[j]) + xko, 0, 0);
+    };
+    auto compute = [&](const u32x4 (&wa)[TM], const u32x4 (&xb)[TN]) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wa[i][tt]), __uint_as_float(xb[j][tt]),
+                                                                     acc[i][j], 0, 0, 0);
+    };
+
+    int st = s_beg;
+    load(st, wa0, xb0);
+    load(st + 1, wa1, xb1);
+    // one basic block per iteration: the loads of step s+2 fly under the MFMAs of steps s and s+1.  sched_barrier pins
+    // the issue order (hipcc otherwise sinks the loads below the MFMA groups and every iteration starts by draining them).
+#define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
+    for (; st + 3 <= s_end; st += 3) {
+        load(st + 2, wa2, xb2); FFB6D_PIN();
+        compute(wa0, xb0);      FFB6D_PIN();
+        load(st + 3, wa0, xb0); FFB6D_PIN();
+        compute(wa1, xb1);      FFB6D_PIN();
+        load(st + 4, wa1, xb1); FFB6D_PIN();
+        compute(wa2, xb2);      FFB6D_PIN();
+    }
+#undef FFB6D_PIN
+    if (st < s_end) compute(wa0, xb0);
+    if (st + 1 < s_end) compute(wa1, xb1);
+
+    if constexpr (KSPLIT) {
+        // partial sums of waves 1..3 -> LDS (lane-contiguous), wave 0 adds them and runs the epilogue
+        __shared__ float part[3][TM * TN * 16][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[wave - 1][(i * TN + j) * 16 + r][lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += part[w][(i * TN + j) * 16 + r][lane];
+    }
+
+    // epilogue: lane = one point, 4 groups of 4 consecutive channels per 32 x 32 tile
+    const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
+    const bool vec = (p.cout & 3) == 0 && (p.ldo & 3) == 0 && (p.ldy & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.y) |
+                       reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = r0 + (wn * TN + j) * 32 + l31;
+        const bool live = r < p.rows;
+        const float* yrow = nullptr;
+        if (p.y && live) {
+            long long yr = r;
+            if (p.gidx) {
+                const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[r]
+                                             : (long long)static_cast<const int*>(p.gidx)[r];
+                yr = (long long)(r / p.P) * p.py + gi;
+            }
+            yrow = p.y + yr * p.ldy;
+        }
+        float* orow = p.out + (size_t)r * p.ldo;
+        if (vec) {
+            float4 v[TM][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
+                    v[i][g] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    if (ch >= p.cout || !live) continue;
+                    if (p.bias) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
+                        v[i][g].x += b4.x; v[i][g].y += b4.y; v[i][g].z += b4.z; v[i][g].w += b4.w;
+                    }
+                    if (yrow) {
+                        const float4 y4 = *reinterpret_cast<const float4*>(yrow + ch);
+                        v[i][g].x += y4.x; v[i][g].y += y4.y; v[i][g].z += y4.z; v[i][g].w += y4.w;
+                    }
+                }
+            }
+            if (p.act == 3) {
+                // log_softmax over the channels of a point (pspnet.py:108-112 `final`): the launcher guarantees that the
+                // wave's tile spans all cout channels; a point's channels sit in lanes l and l ^ 32
+                float m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (i * 32 + 8 * g + 4 * kh < p.cout)
+                            m = fmaxf(fmaxf(fmaxf(m, v[i][g].x), fmaxf(v[i][g].y, v[i][g].z)), v[i][g].w);
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (i * 32 + 8 * g + 4 * kh < p.cout)
+                            sum += (expf(v[i][g].x - m) + expf(v[i][g].y - m)) + (expf(v[i][g].z - m) + expf(v[i][g].w - m));
+                sum += __shfl_xor(sum, 32, 64);
+                const float lse = m + logf(sum);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
+                        if (ch < p.cout && live)
+                            *reinterpret_cast<float4*>(orow + ch) =
+                                make_float4(v[i][g].x - lse, v[i][g].y - lse, v[i][g].z - lse, v[i][g].w - lse);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
+                        if (ch < p.cout && live)
+                            *reinterpret_cast<float4*>(orow + ch) =
+                                make_float4(activate(v[i][g].x, slope), activate(v[i][g].y, slope), activate(v[i][g].z, slope),
+                                            activate(v[i][g].w, slope));
+                    }
+            }
+        } else if (live) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int ch = c0 + (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                    if (ch >= p.cout) continue;
+                    float u = acc[i][j][q];
+                    if (p.bias) u += p.bias[ch];
+                    if (yrow) u += yrow[ch];
+                    orow[ch] = activate(u, slope);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attentive pooling with the score GEMM fused in (Att_pooling.forward up to the pooled tensor, RandLANet.py:243-248):
+//     S[(n,k), :] = [ F[nei[n,k], :] | G[(n,k), :] ]           feature set: gathered point rows | per-pair rows
+//     A = S * W_fc^T                                           scores, never written
+//     out[n, m] = sum_k S[(n,k), m] * softmax_k(A[(n,k), m])
+// Operand roles are swapped with respect to mlp_pm_kernel: the (n,k) PAIRS are the MFMA's i index, the output channels its
+// j index, and the 32 row slots of a tile are two points x 16 neighbours in the order
+//     slot rho  ->  point (rho >> 2) & 1, neighbour (rho & 3) + 4 * (rho >> 3)
+// so that accumulator register r of lane l is neighbour r of point (l >> 5) for channel (l & 31): a lane holds all 16 scores
+// of one (point, channel) and the softmax / weighted sum over the neighbourhood is pure in-lane arithmetic -- no shuffles, no
+// LDS.  The gather of the neighbour rows IS the operand load (lane rho loads 16 bytes of row nei[n,k]); the feature values
+// the scores are multiplied with are re-read channel-contiguous (128-byte segments, L1-resident after the operand loads).
+// ---------------------------------------------------------------------------------------------------------------
+struct AttParams {
+    const float* w;       // [d, d] fc weight, nn.Conv layout
+    const float* f;       // [B * N, ldf] point rows, first c1 floats used
+    const void* nei;      // [B * N * 16] int32/int64 neighbour indices inside the frame
+    const float* g;       // [B * N * 16, ldg] pair rows, first c2 floats used
+    float* out;           // [B * N, ldo]
+    int npts, N, c1, c2, ldf, ldg, ldo, idx64;
+    int n_pt, n_ct;
+};
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(BLK)
+att_pool_pm_kernel(const AttParams p)
+{
+    constexpr int PTS = 2 * TM * 4;                 // points per workgroup (4 waves along the points)
+    constexpr int BC = 32 * TN;                     // channels per workgroup
+    const int t = blockIdx.x;
+    const int xcd = t & 7, s = t >> 3;
+    const int pt = (s / p.n_ct) * 8 + xcd;
+    const int ct = s % p.n_ct;
+    if (pt >= p.n_pt) return;
+    const int c0 = ct * BC;
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pbase = pt * PTS + wave * (2 * TM);   // first point of this wave
+    const int d = p.c1 + p.c2;
+
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)d * (unsigned)d * 4u);
+    const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.f, (unsigned)p.npts * (unsigned)p.ldf * 4u);
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(p.g, (unsigned)p.npts * 16u * (unsigned)p.ldg * 4u);
+
+    // A operand: this lane's pair of every row tile
+    const int a_pp = (l31 >> 2) & 1, a_nb = (l31 & 3) + 4 * (l31 >> 3);
+    int f_vo[TM], g_vo[TM], w_vo[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int n = pbase + 2 * i + a_pp;
+        int frow = 0x1fffffff / p.ldf, grow = 0x1fffffff / p.ldg;       // out of range -> zeros
+        if (n < p.npts) {
+            const size_t pair = (size_t)n * 16 + a_nb;
+            const int nb = p.idx64 ? (int)static_cast<const long long*>(p.nei)[pair] : static_cast<const int*>(p.nei)[pair];
+            frow = (n / p.N) * p.N + nb;
+            grow = (int)pair;
+        }
+        f_vo[i] = (frow * p.ldf + 4 * kh) * 4;
+        g_vo[i] = (grow * p.ldg + 4 * kh) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) w_vo[j] = ((c0 + j * 32 + l31) * d + 4 * kh) * 4;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int n1 = p.c1 >> 3, nsteps = d >> 3;
+    u32x4 xa0[TM], xa1[TM], xa2[TM], wb0[TN], wb1[TN], wb2[TN];
+    auto load = [&](int step, u32x4 (&xa)[TM], u32x4 (&wb)[TN]) {
+        const bool second = step >= n1;
+        const __amdgpu_buffer_rsrc_t rx = second ? rs_g : rs_f;
+        const int wko = step * 32, xko = (second ? step - n1 : step) * 32;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            xa[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (second ? g_vo[i] : f_vo[i]) + xko, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[j] + wko, 0, 0);
+    };
+    auto compute = [&](const u32x4 (&xa)[TM], const u32x4 (&wb)[TN]) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xa[i][tt]), __uint_as_float(wb[j][tt]),
+                                                                     acc[i][j], 0, 0, 0);
+    };
+    int st = 0;
+    load(0, xa0, wb0);
+    load(1, xa1, wb1);
+#define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
+    for (; st + 3 <= nsteps; st += 3) {
+        load(st + 2, xa2, wb2); FFB6D_PIN();
+        compute(xa0, wb0);      FFB6D_PIN();
+        load(st + 3, xa0, wb0); FFB6D_PIN();
+        compute(xa1, wb1);      FFB6D_PIN();
+        load(st + 4, xa1, wb1); FFB6D_PIN();
+        compute(xa2, wb2);      FFB6D_PIN();
+    }
+#undef FFB6D_PIN
+    if (st < nsteps) compute(xa0, wb0);
+    if (st + 1 < nsteps) compute(xa1, wb1);
+
+    // epilogue: lane (channel l31 of each column tile, point kh of each row tile) owns 16 scores = one neighbourhood
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int n = pbase + 2 * i + kh;
+        if (n >= p.npts) continue;
+        const int fb = (n / p.N) * p.N;
+        int nbr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            nbr[r] = p.idx64 ? (int)static_cast<const long long*>(p.nei)[(size_t)n * 16 + r]
+                             : static_cast<const int*>(p.nei)[(size_t)n * 16 + r];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ch = c0 + j * 32 + l31;
+            if (ch >= d) continue;
+            const bool from_f = ch < p.c1;
+            const float* src = from_f ? p.f + ch : p.g + (ch - p.c1);
+            float fv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t row = from_f ? (size_t)(fb + nbr[r]) * p.ldf : ((size_t)n * 16 + r) * p.ldg;
+                fv[r] = src[row];
+            }
+            float m = acc[i][j][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f((acc[i][j][r] - m) * 1.44269504088896341f);
+                den += e;
+                num = fmaf(fv[r], e, num);
+            }
+            p.out[(size_t)n * p.ldo + ch] = num * __builtin_amdgcn_rcpf(den);
+        }
+    }
+}
+
+template <int TM, int TN>
+void launch_att(AttParams& p, hipStream_t st)
+{
+    p.n_ct = (int)ceil_div(p.c1 + p.c2, 32 * TN);
+    p.n_pt = (int)ceil_div(p.npts, 2 * TM * 4);
+    hipLaunchKernelGGL((att_pool_pm_kernel<TM, TN>), dim3((unsigned)(ceil_div(p.n_pt, 8) * p.n_ct * 8)), dim3(BLK), 0, st, p);
+}
+
+template <int TM, int TN, int WM, int WN, bool KSPLIT>
+void launch_pm(PmParams& p, hipStream_t st)
+{
+    constexpr int BC = 32 * TM * (KSPLIT ? 1 : WM), BP = 32 * TN * (KSPLIT ? 1 : WN);
+    p.n_ct = (int)ceil_div(p.cout, BC);
+    p.n_pt = (int)ceil_div(p.rows, BP);
+    const unsigned grid = (unsigned)(ceil_div(p.n_pt, 8) * p.n_ct * 8);
+    hipLaunchKernelGGL((mlp_pm_kernel<TM, TN, WM, WN, KSPLIT>), dim3(grid), dim3(BLK), 0, st, p);
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+using namespace ffb6d;
+
+// tile choice: big tiles while they still give >= ~1.5 workgroups per CU, K split across the waves when even the
+// smallest tile leaves CUs idle (deep layers: a few hundred points per frame, K up to 1024)
+extern "C" int ffb6d_mlp_pm_tile(int64_t rows, int64_t cout, int64_t K, int act)
+{
+    if (act == 3) return cout > 32 ? 2 : 3;          // log_softmax: a wave's tile must span all channels
+    const int64_t big = ceil_div(rows, 128) * ceil_div(cout, 128);
+    const int64_t mid = ceil_div(rows, 256) * ceil_div(cout, 64);
+    const int64_t small = ceil_div(rows, 64) * ceil_div(cout, 64);
+    if (cout > 64 && big >= 384) return 1;
+    if (cout > 32 && cout <= 64 && mid >= 384) return 2;
+    if (cout <= 32) return ceil_div(rows, 256) >= 256 ? 3 : 5;
+    if (small >= 512 || K < 64) return 4;
+    return 5;
+}
+
+extern "C" int ffb6d_mlp_pm_f32(const float* w, const float* bias, const float* x1, int64_t k1, int64_t ld1, const void* x1_idx,
+                                int64_t x1_rows_per_frame, const float* x2, int64_t k2, int64_t ld2, const float* y, int64_t ldy,
+                                const void* y_idx, int64_t y_rows_per_frame, int idx_bits, int64_t rows_per_frame, float* out,
+                                int64_t ldo, int64_t rows, int64_t cout, int act, int tile_hint, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(rows >= 0 && cout >= 1 && k1 >= 8 && k2 >= 0, "mlp_pm: bad shape");
+    FFB6D_REQUIRE((k1 & 7) == 0 && (k2 & 7) == 0, "mlp_pm: k1 and k2 must be multiples of 8 (got %lld, %lld): pad the rows",
+                  (long long)k1, (long long)k2);
+    FFB6D_REQUIRE(act >= 0 && act <= 3, "mlp_pm: act must be 0 (none), 1 (relu), 2 (leaky 0.2) or 3 (log_softmax over channels)");
+    if (rows == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(w && x1 && out, "mlp_pm: null pointer");
+    FFB6D_REQUIRE((k2 == 0) == (x2 == nullptr), "mlp_pm: x2 and k2 must come together");
+    FFB6D_REQUIRE(ld1 >= k1 && (k2 == 0 || ld2 >= k2) && ldo >= cout, "mlp_pm: row stride smaller than the row");
+    FFB6D_REQUIRE((ld1 & 3) == 0 && (ld2 & 3) == 0 &&
+                  ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(w)) & 15) == 0,
+                  "mlp_pm: operand rows must be 16-byte aligned");
+    FFB6D_REQUIRE(!y_idx || y, "mlp_pm: gather indices without rows to gather");
+    const bool indexed = y_idx || x1_idx;
+    FFB6D_REQUIRE(!indexed || ((idx_bits == 32 || idx_bits == 64) && rows_per_frame >= 1 && rows % rows_per_frame == 0),
+                  "mlp_pm: index arrays need idx_bits 32/64 and rows_per_frame dividing rows");
+    FFB6D_REQUIRE((!y_idx || y_rows_per_frame >= 1) && (!x1_idx || x1_rows_per_frame >= 1), "mlp_pm: rows per frame of a gathered source");
+    FFB6D_REQUIRE(!y || ldy >= cout, "mlp_pm: ldy smaller than cout");
+    FFB6D_REQUIRE(act != 3 || (cout <= 64 && (cout & 3) == 0 && (ldo & 3) == 0 &&
+                               ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0),
+                  "mlp_pm: log_softmax epilogue needs cout <= 64, cout %% 4 == 0 and 16-byte aligned rows");
+    const int64_t K = k1 + k2;
+    const int64_t x1_rows = x1_idx ? rows / rows_per_frame * x1_rows_per_frame : rows;
+    FFB6D_REQUIRE((x1_rows + 256) * ld1 * 4 < (1LL << 31) && (rows + 256) * (ld2 > 0 ? ld2 : 1) * 4 < (1LL << 31) &&
+                  (cout + 128) * K * 4 < (1LL << 31), "mlp_pm: operand larger than the 2 GiB buffer addressing of one launch");
+    PmParams p;
+    p.w = w; p.bias = bias; p.x1 = x1; p.xidx = x1_idx; p.x2 = x2; p.y = y; p.gidx = y_idx; p.out = out;
+    p.rows = (int)rows; p.cout = (int)cout; p.k1 = (int)k1; p.k2 = (int)k2; p.ld1 = (int)ld1; p.ld2 = (int)(k2 ? ld2 : 4);
+    p.ldy = (int)ldy; p.ldo = (int)ldo; p.P = (int)(indexed ? rows_per_frame : rows); p.py = (int)y_rows_per_frame;
+    p.px = (int)x1_rows_per_frame; p.act = act;
+    p.idx64 = idx_bits == 64;
+    hipStream_t st = as_stream(stream);
+    const int choice = tile_hint > 0 ? tile_hint : ffb6d_mlp_pm_tile(rows, cout, K, act);
+    switch (choice) {
+        case 1: launch_pm<2, 2, 2, 2, false>(p, st); break;      // 128 ch x 128 pt
+        case 2: launch_pm<2, 2, 1, 4, false>(p, st); break;      // 64 ch x 256 pt
+        case 3: launch_pm<1, 2, 1, 4, false>(p, st); break;      // 32 ch x 256 pt
+        case 4: launch_pm<1, 1, 2, 2, false>(p, st); break;      // 64 ch x 64 pt
+        case 5: launch_pm<2, 1, 2, 2, true>(p, st); break;       // 64 ch x 32 pt, K over the 4 waves
+        default: return set_error(FFB6D_ERR_ARG, "mlp_pm: unknown tile_hint %d", tile_hint);
+    }
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+extern "C" int ffb6d_att_pool_pm_f32(const float* w_fc, const float* f, int64_t c1, int64_t ldf, const void* nei, int idx_bits,
+                                     const float* g, int64_t c2, int64_t ldg, float* out, int64_t ldo, int64_t B, int64_t N, int K,
+                                     ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(K == 16, "att_pool_pm: K must be 16 (got %d)", K);
+    FFB6D_REQUIRE(idx_bits == 32 || idx_bits == 64, "att_pool_pm: idx_bits must be 32 or 64");
+    FFB6D_REQUIRE(B >= 0 && N >= 0 && c1 >= 8 && c2 >= 8 && (c1 & 7) == 0 && (c2 & 7) == 0,
+                  "att_pool_pm: c1 and c2 must be positive multiples of 8");
+    if (B == 0 || N == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(w_fc && f && nei && g && out, "att_pool_pm: null pointer");
+    FFB6D_REQUIRE(ldf >= c1 && ldg >= c2 && ldo >= c1 + c2 && (ldf & 3) == 0 && (ldg & 3) == 0 &&
+                  ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(w_fc)) & 15) == 0,
+                  "att_pool_pm: rows must be 16-byte aligned and at least as long as their channel count");
+    const int64_t npts = B * N, d = c1 + c2;
+    FFB6D_REQUIRE((npts + 64) * ldf * 4 < (1LL << 31) && (npts + 64) * 16 * ldg * 4 < (1LL << 31) && (d + 128) * d * 4 < (1LL << 31),
+                  "att_pool_pm: operand larger than the 2 GiB buffer addressing of one launch");
+    AttParams p;
+    p.w = w_fc; p.f = f; p.nei = nei; p.g = g; p.out = out;
+    p.npts = (int)npts; p.N = (int)N; p.c1 = (int)c1; p.c2 = (int)c2; p.ldf = (int)ldf; p.ldg = (int)ldg; p.ldo = (int)ldo;
+    p.idx64 = idx_bits == 64;
+    hipStream_t st = as_stream(stream);
+    if (d <= 32) launch_att<4, 1>(p, st);
+    else if (d <= 64) launch_att<2, 2>(p, st);
+    else launch_att<1, 4>(p, st);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}

@@ -1,0 +1,321 @@
+"""Point-major / pixel-major ("channels last") inference forward of FFB6D on the gfx950 kernels.
+
+Same module tree, parameters and dataflow as `model.FFB6D` / the reference (ffb6d/models/ffb6d.py:203-337,
+RandLANet.py:170-250, cnn/pspnet.py, cnn/extractors.py); what changes is the memory layout of every activation:
+one row of C contiguous floats per point or pixel ([B,N,C], [B,H,W,C]) instead of the reference's [B,C,N,1] / [B,C,H,W].
+
+Why (MI355X): every gather of the hot path -- neighbour features of the local feature aggregation, the 16-pixel max
+pooling of the pixel->point fusion, the 1-NN interpolation of the point->pixel fusion and of the decoder, `choose` --
+moves whole contiguous rows instead of one 4-byte element per 64-byte sector; both operands of every shared-MLP GEMM
+are K-contiguous and stream straight into MFMA operand registers (csrc/mlp_pm.hip, no LDS, no barriers); MIOpen's
+fastest fp32 convolutions on this chip are its NHWC implicit-GEMM kernels, which then run without the NCHW<->NHWC
+transposes MIOpen otherwise inserts around them.
+
+Fusions (reference ops -> here), all inference only:
+    conv1x1 + BN + act                                    one GEMM, BN folded into W/b            (ops_pm.mlp)
+    cat(a, b) -> conv                                     two K ranges of one GEMM
+    conv(cat(a, interp(b)))                               W_a a + gather(W_b b) in the epilogue   (p2r fusion, decoder)
+    leaky(mlp2(f) + shortcut(x))                          one GEMM over K = [f | x]
+    gather_neighbour + cat + fc + softmax + mul + sum     ops_pm.att_pool: gather = operand load, softmax in-lane
+    choose gather + cat + head conv                       operand gather of the head GEMM
+    final conv1x1 + LogSoftmax                            log-softmax epilogue of the GEMM
+    pyramid pooling                                       W_x x + b + sum_i up_i((W_b,i W_i) pool_i(x))
+Dense 3x3 / 7x7 convolutions stay on MIOpen, fed channels_last tensors and weights.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops, ops_pm
+
+
+def cached(mod, name, sources, build):
+    """Per-module cache of inference-time derived tensors (folded / split / padded weights), keyed on the version
+    counter, storage and device of every source tensor: load_state_dict, optimizer steps, .to(device) and in-place
+    edits all invalidate it.  (Edits through `.data` bypass version counters; FFB6D.train() drops every cache.)"""
+    key = tuple((t._version, t.data_ptr(), t.device) for t in sources)
+    store = mod.__dict__.setdefault("_pm_cache", {})
+    hit = store.get(name)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, build())
+        store[name] = hit
+    return hit[1]
+
+
+def _pad_k(w, k_to):
+    if w.shape[1] == k_to:
+        return w.contiguous()
+    out = w.new_zeros(w.shape[0], k_to)
+    out[:, :w.shape[1]] = w
+    return out
+
+
+def mlp_sources(m):
+    src = [m.conv.weight]
+    if m.has_bn:
+        bn = m._bn_module()
+        src += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    else:
+        src.append(m.conv.bias)
+    return src
+
+
+def folded(m, pad_k=None):
+    """(W [Cout, Cin(padded)], b [Cout]) of a model.SharedMLP: conv weight layout, eval-mode BatchNorm absorbed."""
+    def build():
+        w = m.conv.weight.detach().reshape(m.conv.weight.shape[0], -1)
+        if m.has_bn:
+            bn = m._bn_module()
+            scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+            w = w * scale[:, None]
+            b = bn.bias.detach() - bn.running_mean * scale
+        else:
+            b = m.conv.bias.detach()
+        return _pad_k(w, pad_k or w.shape[1]), b.contiguous()
+    return cached(m, "folded%s" % (pad_k or ""), mlp_sources(m), build)
+
+
+def split(m, k1):
+    """(W_a [Cout,k1], W_b [Cout,Cin-k1], b) for conv(cat(a, gather(b))) == W_a a + gather(W_b b)."""
+    def build():
+        w, b = folded(m)
+        return w[:, :k1].contiguous(), w[:, k1:].contiguous(), b
+    return cached(m, "split%d" % k1, mlp_sources(m), build)
+
+
+def mlp(m, x1, x2=None, pad_k=None, **kw):
+    w, b = folded(m, pad_k)
+    return ops_pm.mlp(x1, w, b, m.act_code, x2=x2, **kw)
+
+
+def fc_weight(att):
+    w = att.fc.weight
+    return cached(att, "fc", [w], lambda: w.detach().reshape(w.shape[0], -1).contiguous())
+
+
+# ----------------------------------------------------------------------------------------------------
+# point branch
+# ----------------------------------------------------------------------------------------------------
+def building_block(bb, xyz, f_pc, nei):
+    """RandLANet.py:196-214 (Building_block.forward): f_pc [B,N,d/2] -> [B,N,d]."""
+    enc = ops_pm.relative_pos_encoding(xyz, nei)                             # [B,N,16,16] (10 used)
+    f_xyz = mlp(bb.mlp1, enc, pad_k=16)                                       # [B,N,16,d/2]
+    pooled = ops_pm.att_pool(f_pc, nei, f_xyz, fc_weight(bb.att_pooling_1))   # [B,N,d]
+    f_agg = mlp(bb.att_pooling_1.mlp, pooled)                                 # [B,N,d/2]
+    f_xyz = mlp(bb.mlp2, f_xyz)
+    pooled = ops_pm.att_pool(f_agg, nei, f_xyz, fc_weight(bb.att_pooling_2))
+    return mlp(bb.att_pooling_2.mlp, pooled)                                  # [B,N,d]
+
+
+def dilated_res_block(rb, feature, xyz, nei):
+    """RandLANet.py:179-184: leaky(mlp2(lfa(mlp1(f))) + shortcut(f)) with the sum as ONE GEMM over K = [lfa | f]."""
+    f = building_block(rb.lfa, xyz, mlp(rb.mlp1, feature), nei)
+
+    def build():
+        (w2, b2), (ws, bs) = folded(rb.mlp2), folded(rb.shortcut)
+        return torch.cat([w2, ws], dim=1).contiguous(), (b2 + bs).contiguous()
+    w, b = cached(rb, "res", mlp_sources(rb.mlp2) + mlp_sources(rb.shortcut), build)
+    return ops_pm.mlp(f, w, b, ops.ACT_LEAKY, x2=feature)
+
+
+def decode(stage, skip, p_emb, interp_idx):
+    """conv(cat(skip, interp(p))) (ffb6d.py:273-279,302-307) = W_a skip + gather(W_b p)."""
+    wa, wb, bias = split(stage, skip.shape[-1])
+    y = ops_pm.mlp(p_emb, wb)
+    return ops_pm.mlp(skip, wa, bias, stage.act_code, gather=(y, interp_idx.reshape(interp_idx.shape[0], -1)))
+
+
+# ----------------------------------------------------------------------------------------------------
+# colour branch (tensors kept as [B,H,W,C]; MIOpen sees them as channels_last NCHW views)
+# ----------------------------------------------------------------------------------------------------
+def conv(x, c):
+    """Dense convolution of a [B,H,W,C] map through MIOpen's NHWC path; returns [B,H',W',C']."""
+    w = cached(c, "cl", [c.weight], lambda: c.weight.detach().contiguous(memory_format=torch.channels_last))
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, None, c.stride, c.padding, c.dilation, c.groups)
+    y = y.permute(0, 2, 3, 1)
+    return y if y.is_contiguous() else y.contiguous()
+
+
+def res_block(rb, x):
+    """extractors.py:49-63 (BasicBlock): BN+ReLU and BN+residual(+BN of the projection)+ReLU as one pass each."""
+    y = ops_pm.affine_act_(conv(x, rb.conv1), *ops.bn_fold(rb.bn1), act=ops.ACT_RELU)
+    y = conv(y, rb.conv2)
+    if rb.downsample is not None:
+        return ops_pm.affine_act_(y, *ops.bn_fold(rb.bn2), act=ops.ACT_RELU, residual=conv(x, rb.downsample[0]),
+                                  res_affine=ops.bn_fold(rb.downsample[1]))
+    return ops_pm.affine_act_(y, *ops.bn_fold(rb.bn2), act=ops.ACT_RELU, residual=x)
+
+
+def pyramid_pooling(pp, x):
+    """pspnet.py:7-31 as W_x x + b + sum_i up_i((W_b,i W_i) pool_i(x)): no 2560-channel cat, bottleneck K = 512."""
+    B, h, w_, C = x.shape
+    sizes = [st[0].output_size[0] for st in pp.stages]
+    bw = pp.bottleneck.weight
+
+    def build():
+        ch = pp.stages[0][1].weight.shape[0]
+        wb = bw.detach().reshape(bw.shape[0], -1)                                            # [1024, 2560]
+        prods = [(wb[:, i * ch:(i + 1) * ch] @ st[1].weight.detach().reshape(ch, ch)).contiguous()
+                 for i, st in enumerate(pp.stages)]                                           # each [1024, 512]
+        return prods, wb[:, len(pp.stages) * ch:].contiguous()
+    prods, wx = cached(pp, "fold", [bw] + [st[1].weight for st in pp.stages], build)
+    pooled = ops_pm.psp_pool(x, sizes)                                                        # [B,50,512]
+    zs, off = [], 0
+    for s, wl in zip(sizes, prods):
+        zs.append(ops_pm.mlp(pooled[:, off:off + s * s].contiguous(), wl))
+        off += s * s
+    prior = ops_pm.psp_prior_sum(torch.cat(zs, dim=1), sizes, (h, w_))                        # [B,h,w,1024]
+    return ops_pm.mlp(x, wx, pp.bottleneck.bias.detach(), ops.ACT_RELU, add=prior)
+
+
+def up_block(ub, x):
+    """pspnet.py:34-45 (PSPUpsample): bilinear x2 (align_corners) -> conv3x3 -> [BN + PReLU in one pass]."""
+    B, h, w_, _ = x.shape
+    y = ops_pm.bilinear_resize(x, (2 * h, 2 * w_), align_corners=True)
+    cv, bn, prelu = ub.conv[1], ub.conv[2], ub.conv[3]
+    y = conv(y, cv)
+    if prelu.weight.numel() != 1:
+        raise NotImplementedError("per-channel PReLU in PSPUpsample")
+    slope = cached(ub, "slope", [prelu.weight], lambda: float(prelu.weight.detach().item()))
+    scale, shift = ops.bn_fold(bn)
+    # conv bias rides in the BatchNorm shift: BN(conv(y)+b) = scale*conv(y) + (shift + scale*b)
+    shift = cached(ub, "shift", [cv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var],
+                   lambda: (shift + scale * cv.bias.detach()).contiguous())
+    return ops_pm.affine_act_(y, scale, shift, act=ops.ACT_LEAKY, slope=slope)
+
+
+def final_head(fh, x):
+    """pspnet.py:108-112 `final`: Conv2d(64,64,1) + LogSoftmax(dim=1) as one GEMM with a log-softmax epilogue."""
+    cv = fh[0]
+    w = cached(fh, "w", [cv.weight], lambda: cv.weight.detach().reshape(cv.out_channels, -1).contiguous())
+    return ops_pm.mlp(x, w, cv.bias.detach(), ops_pm.ACT_LOG_SOFTMAX)
+
+
+def cnn_stage(stage, x):
+    """Run one entry of cnn_ds_stages / cnn_up_stages on a [B,H,W,C] map."""
+    from . import model
+    for m in (stage if isinstance(stage, torch.nn.Sequential) else [stage]):
+        if isinstance(m, model.ResBlock):
+            x = res_block(m, x)
+        elif isinstance(m, model.PyramidPooling):
+            x = pyramid_pooling(m, x)
+        elif isinstance(m, model.UpBlock):
+            x = up_block(m, x)
+        elif isinstance(m, model.FinalHead):
+            x = final_head(m, x)
+        elif isinstance(m, torch.nn.Dropout2d):
+            pass                                                  # eval mode
+        elif isinstance(m, torch.nn.Sequential):
+            x = cnn_stage(m, x)
+        else:
+            raise NotImplementedError(type(m).__name__)
+    return x
+
+
+def supported(net):
+    """The row kernels need channel counts that are multiples of 8 (every width of the reference's configuration is)."""
+    widths = [m.conv.weight.shape[0] for m in net.modules() if hasattr(m, "conv") and hasattr(m, "act_code")]
+    return all(w % 8 == 0 or w <= 64 for w in widths)
+
+
+# ----------------------------------------------------------------------------------------------------
+# whole forward (ffb6d.py:203-337)
+# ----------------------------------------------------------------------------------------------------
+def forward(net, inputs, end_points, two_streams=True, taps=None):
+    """taps: optional dict that receives the two embeddings after every fusion stage (`rgb_emb_ds{i}`, `p_emb_ds{i}`,
+    `rgb_emb_up{i}`, `p_emb_up{i}`), converted to the reference layout -- diagnostics / stage-level parity tests."""
+    dev = inputs['rgb'].device
+    main = torch.cuda.current_stream(dev)
+    side = net._side_stream(dev) if two_streams else main
+    if two_streams:
+        side.wait_stream(main)                      # inputs (and the index pyramid) come from `main`
+
+    def on_side():
+        return torch.cuda.stream(side)
+
+    def handover(t, producer, consumer):
+        """tensor produced on `producer`, about to be read on `consumer`"""
+        if producer is not consumer:
+            ev = torch.cuda.Event()
+            ev.record(producer)
+            consumer.wait_event(ev)
+            t.record_stream(consumer)
+        return t
+
+    def fuse(i, pre_p2r, fuse_p2r, pre_r2p, fuse_r2p, rgb0, p0, p2r_idx, r2p_idx):
+        """One bidirectional fusion step (ffb6d.py:245-263 / 281-298); both directions read the pre-fusion tensors."""
+        B, h, w_, c = rgb0.shape
+        handover(p0, side, main)
+        handover(rgb0, main, side)
+        if two_streams:
+            p2r_idx.record_stream(main)
+        # p2r on main: conv(cat(rgb0, interp(e))) = W_a rgb0 + gather(W_b e)
+        e = mlp(pre_p2r[i], p0)
+        wa, wb, bias = split(fuse_p2r[i], c)
+        y = ops_pm.mlp(e, wb)
+        rgb = ops_pm.mlp(rgb0, wa, bias, fuse_p2r[i].act_code, gather=(y, p2r_idx.reshape(B, -1)))
+        with on_side():     # r2p: max over the 16 nearest pixels, then conv(cat(p0, pre(.))) as a two-source GEMM
+            r2p = mlp(pre_r2p[i], ops_pm.random_sample(rgb0.view(B, h * w_, c), r2p_idx))
+            p = mlp(fuse_r2p[i], p0, x2=r2p)
+        return rgb, p
+
+    # ---- stems ----
+    rgb = inputs['rgb'].contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)       # [B,H,W,3] view
+    y = ops_pm.affine_act_(conv(rgb, net.cnn_pre_stages[0]), *ops.bn_fold(net.cnn_pre_stages[1]), act=ops.ACT_RELU)
+    rgb_emb = net.cnn_pre_stages[3](y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)                  # max pool, stays NHWC
+    with on_side():
+        raw = inputs['cld_rgb_nrm']                                                              # [B,9,N]
+        x0 = raw.new_zeros(raw.shape[0], raw.shape[2], (raw.shape[1] + 7) // 8 * 8)
+        x0[..., :raw.shape[1]] = raw.transpose(1, 2)
+        p_emb = mlp(net.rndla_pre_stages, x0, pad_k=x0.shape[-1])                                # [B,N,8]
+
+    # ---- encoder ----
+    ds_emb = []
+    for i in range(4):
+        rgb0 = cnn_stage(net.cnn_ds_stages[i], rgb_emb)
+        with on_side():
+            f_enc = dilated_res_block(net.rndla_ds_stages[i], p_emb, inputs['cld_xyz%d' % i], inputs['cld_nei_idx%d' % i])
+            p0 = ops_pm.random_sample(f_enc, inputs['cld_sub_idx%d' % i])
+        if i == 0:
+            ds_emb.append(f_enc)
+        rgb_emb, p_emb = fuse(i, net.ds_fuse_p2r_pre_layers, net.ds_fuse_p2r_fuse_layers, net.ds_fuse_r2p_pre_layers,
+                              net.ds_fuse_r2p_fuse_layers, rgb0, p0, inputs['p2r_ds_nei_idx%d' % i],
+                              inputs['r2p_ds_nei_idx%d' % i])
+        ds_emb.append(p_emb)
+        if taps is not None:
+            torch.cuda.synchronize(dev)
+            taps['rgb_emb_ds%d' % i], taps['p_emb_ds%d' % i] = rgb_emb.permute(0, 3, 1, 2), p_emb.transpose(1, 2).unsqueeze(3)
+
+    # ---- decoder ----
+    n_up = len(net.rndla_up_stages)
+    for i in range(n_up - 1):
+        rgb0 = cnn_stage(net.cnn_up_stages[i], rgb_emb)
+        with on_side():
+            p0 = decode(net.rndla_up_stages[i], ds_emb[-i - 2], p_emb, inputs['cld_interp_idx%d' % (n_up - i - 1)])
+        rgb_emb, p_emb = fuse(i, net.up_fuse_p2r_pre_layers, net.up_fuse_p2r_fuse_layers, net.up_fuse_r2p_pre_layers,
+                              net.up_fuse_r2p_fuse_layers, rgb0, p0, inputs['p2r_up_nei_idx%d' % i],
+                              inputs['r2p_up_nei_idx%d' % i])
+        if taps is not None:
+            torch.cuda.synchronize(dev)
+            taps['rgb_emb_up%d' % i], taps['p_emb_up%d' % i] = rgb_emb.permute(0, 3, 1, 2), p_emb.transpose(1, 2).unsqueeze(3)
+    rgb_emb = cnn_stage(net.cnn_up_stages[n_up - 1], rgb_emb)
+    with on_side():
+        p_emb = decode(net.rndla_up_stages[n_up - 1], ds_emb[0], p_emb, inputs['cld_interp_idx0'])
+    handover(p_emb, side, main)                 # also the final join: main is behind all side work
+
+    # ---- heads: conv(cat(rgb[choose], p_emb)) with the pick as the operand gather of the first GEMM ----
+    B, H, W_, c = rgb_emb.shape
+    img = rgb_emb.view(B, H * W_, c)
+    choose = inputs['choose'].reshape(B, -1)
+
+    def head(seq):
+        y = mlp(seq[0], img, x2=p_emb, x1_gather=choose)
+        for layer in list(seq)[1:]:
+            y = mlp(layer, y)
+        return y
+
+    n = p_emb.shape[1]
+    end_points['pred_rgbd_segs'] = head(net.rgbd_seg_layer).transpose(1, 2).contiguous()                   # [B,n_cls,N]
+    end_points['pred_kp_ofs'] = head(net.kp_ofst_layer).view(B, n, net.n_kps, 3).permute(0, 2, 1, 3).contiguous()
+    end_points['pred_ctr_ofs'] = head(net.ctr_ofst_layer).view(B, n, 1, 3).permute(0, 2, 1, 3).contiguous()
+    return end_points

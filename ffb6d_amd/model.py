@@ -22,7 +22,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import forward_pm, ops
+from .forward_pm import cached, mlp_sources
 
 D_OUT = (32, 64, 128, 256)   # ConfigRandLA.d_out (ffb6d/common.py:26)
 IN_C = 9                     # ConfigRandLA.in_c
@@ -60,7 +61,6 @@ class SharedMLP(nn.Module):
                 self.bn = _BN(cout, dims, 1e-6, 0.99)
             else:
                 self.normlayer = _BN(cout, dims, 1e-5, 0.1)
-        self._folded = None
 
     def _bn_module(self):
         return (self.bn if self.flavour == "randla" else self.normlayer).bn
@@ -71,9 +71,10 @@ class SharedMLP(nn.Module):
         return F.leaky_relu_(y, 0.2) if self.flavour == "randla" else F.relu_(y)
 
     def folded(self):
-        """(Wt [Cin,Cout], b [Cout]): transposed weights with eval-mode BatchNorm absorbed --
-        the operand layout of ops.shared_mlp."""
-        if self._folded is None:
+        """(Wt [Cin,Cout], b [Cout]): transposed weights with eval-mode BatchNorm absorbed -- the operand layout of
+        ops.shared_mlp (channel-major path).  Cached; the key covers version, storage and device of every source
+        tensor (forward_pm.cached), so load_state_dict / in-place edits / .to(device) are picked up."""
+        def build():
             w = self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1)
             if self.has_bn:
                 bn = self._bn_module()
@@ -82,8 +83,8 @@ class SharedMLP(nn.Module):
                 b = bn.bias.detach() - bn.running_mean * scale
             else:
                 b = self.conv.bias.detach()
-            self._folded = (w.t().contiguous(), b.contiguous())
-        return self._folded
+            return w.t().contiguous(), b.contiguous()
+        return cached(self, "cm_folded", mlp_sources(self), build)
 
     @property
     def act_code(self):
@@ -96,21 +97,13 @@ class SharedMLP(nn.Module):
 
     def split(self, k1):
         """(Wt_a [k1,Cout], Wt_b [Cin-k1,Cout], b) for conv(cat(a, gather(b))) == W_a a + gather(W_b b)."""
-        wt, b = self.folded()
-        if getattr(self, "_split", None) is None or self._split[0] is not wt:
-            self._split = (wt, wt[:k1].contiguous(), wt[k1:].contiguous())
-        return self._split[1], self._split[2], b
-
-    def train(self, mode=True):
-        self._folded = None
-        return super().train(mode)
-
-    def _load_from_state_dict(self, *a, **k):
-        self._folded = None
-        return super()._load_from_state_dict(*a, **k)
+        def build():
+            wt, b = self.folded()
+            return wt[:k1].contiguous(), wt[k1:].contiguous(), b
+        return cached(self, "cm_split%d" % k1, mlp_sources(self), build)
 
     def forward(self, x):
-        if _autograd_path(x):   # unfused conv -> BN -> act (training, DDP, CPU)
+        if _autograd_path(x, self):   # unfused conv -> BN -> act (training, DDP, CPU)
             y = self.conv(x)
             if self.has_bn:
                 y = (self.bn if self.flavour == "randla" else self.normlayer)(y)
@@ -118,13 +111,16 @@ class SharedMLP(nn.Module):
         return self.fused(x)
 
 
-def _autograd_path(x):
-    """True when the differentiable stock-torch layers (conv -> BN -> activation as separate modules)
-    must be used instead of the fused inference kernels: gradients enabled, or tensors not on a GPU.
+def _autograd_path(x, mod=None):
+    """True when the stock-torch layers (conv -> BN -> activation as separate modules) must be used instead of the
+    fused inference kernels: gradients enabled, tensors not on a GPU, or the module in train() mode -- the fused
+    kernels fold BatchNorm with its RUNNING statistics and skip dropout, which is eval() semantics only; train() under
+    torch.no_grad() (BN re-calibration, a validation loop that forgot eval()) must keep batch statistics, running-stat
+    updates and dropout exactly like the reference.
     This is no CPU forward: the neighbour operators (ops.random_sample, gather_neighbour, ...) have no
     CPU implementation and raise FFB6DNativeError on the first CPU tensor they see
     (tests/test_model_cpu.py::test_forward_on_cpu_tensors_fails_loudly)."""
-    return torch.is_grad_enabled() or not x.is_cuda
+    return torch.is_grad_enabled() or not x.is_cuda or (mod is not None and mod.training)
 
 
 # --------------------------------------------------------------------------------------
@@ -146,11 +142,10 @@ class AttPooling(nn.Module):
         """Inference: feature_set = cat(f_nei, f_xyz) is never materialised -- the score GEMM
         reads both halves as two K-ranges, the pooling kernel reads them as two channel blocks."""
         w = self.fc.weight
-        if getattr(self, "_fct", None) is None or self._fct[0] is not w:
-            self._fct = (w, w.detach().reshape(w.shape[0], -1).t().contiguous())
+        fct = cached(self, "cm_fct", [w], lambda: w.detach().reshape(w.shape[0], -1).t().contiguous())
         if f_nei.shape[3] == 16:    # score GEMM with the softmax pooling in its epilogue
-            return self.mlp.fused(ops.att_score_pool(f_nei, f_xyz, self._fct[1]))
-        att = ops.shared_mlp(f_nei, self._fct[1], None, ops.ACT_NONE, x2=f_xyz)
+            return self.mlp.fused(ops.att_score_pool(f_nei, f_xyz, fct))
+        att = ops.shared_mlp(f_nei, fct, None, ops.ACT_NONE, x2=f_xyz)
         return self.mlp.fused(ops.att_pool2(f_nei, f_xyz, att))
 
 
@@ -165,7 +160,7 @@ class BuildingBlock(nn.Module):
         self.att_pooling_2 = AttPooling(d_out, d_out)
 
     def forward(self, xyz, feature, neigh_idx):
-        if not _autograd_path(feature):
+        if not _autograd_path(feature, self):
             return self.fused(xyz, feature, neigh_idx)
         f_xyz = ops.relative_pos_encoding(xyz, neigh_idx).permute(0, 3, 1, 2).contiguous()
         f_xyz = self.mlp1(f_xyz)
@@ -202,14 +197,15 @@ class DilatedResBlock(nn.Module):
 
     def forward(self, feature, xyz, neigh_idx):
         f = self.lfa(xyz, self.mlp1(feature), neigh_idx)
-        if _autograd_path(feature):
+        if _autograd_path(feature, self):
             return F.leaky_relu(self.mlp2(f) + self.shortcut(feature), negative_slope=0.2)
+
         # leaky(mlp2(f) + shortcut(x)) as ONE GEMM over K = [f ; x] with summed biases
-        w2, b2 = self.mlp2.folded()
-        ws, bs = self.shortcut.folded()
-        if getattr(self, "_res", None) is None or self._res[0] is not w2 or self._res[1] is not ws:
-            self._res = (w2, ws, torch.cat([w2, ws], dim=0).contiguous(), (b2 + bs).contiguous())
-        return ops.shared_mlp(f, self._res[2], self._res[3], ops.ACT_LEAKY, x2=feature)
+        def build():
+            (w2, b2), (ws, bs) = self.mlp2.folded(), self.shortcut.folded()
+            return torch.cat([w2, ws], dim=0).contiguous(), (b2 + bs).contiguous()
+        w, b = cached(self, "cm_res", mlp_sources(self.mlp2) + mlp_sources(self.shortcut), build)
+        return ops.shared_mlp(f, w, b, ops.ACT_LEAKY, x2=feature)
 
 
 # --------------------------------------------------------------------------------------
@@ -229,7 +225,7 @@ class ResBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        if _autograd_path(x) or (x.shape[2] * x.shape[3]) % 4:
+        if _autograd_path(x, self) or (x.shape[2] * x.shape[3]) % 4:
             y = F.relu_(self.bn1(self.conv1(x)))
             y = self.bn2(self.conv2(y))
             if self.downsample is not None:
@@ -263,7 +259,7 @@ class PyramidPooling(nn.Module):
 
     def forward(self, x):
         h, w = x.shape[2:]
-        if torch.is_grad_enabled() or not x.is_cuda:
+        if _autograd_path(x, self):
             pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]
             return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
         if w % 4 or h * w * 4 > 160 * 1024:
@@ -311,7 +307,7 @@ class UpBlock(nn.Module):
                                   nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.PReLU())
 
     def forward(self, x):
-        if torch.is_grad_enabled() or not x.is_cuda:
+        if _autograd_path(x, self):
             return self.conv(x)
         y = ops.bilinear_resize(x, (2 * x.shape[2], 2 * x.shape[3]), align_corners=True)
         conv, bn, prelu = self.conv[1], self.conv[2], self.conv[3]
@@ -339,7 +335,7 @@ class FinalHead(nn.Sequential):
 
     def forward(self, x):
         conv = self[0]
-        if _autograd_path(x) or conv.out_channels not in (16, 32, 64):
+        if _autograd_path(x, self) or conv.out_channels not in (16, 32, 64):
             return super().forward(x)
         key = (conv.weight._version, conv.bias._version)
         if getattr(self, "_wt", None) is None or self._wt[0] != key:
@@ -425,7 +421,8 @@ class FFB6D(nn.Module):
         # drop every cached inference-time fold (BatchNorm scale/shift, split weights): they are
         # also version-checked, this covers edits made through `.data`
         for m in self.modules():
-            for attr in ("_ffb6d_fold", "_split", "_res", "_fct", "_slope", "_shift", "_wt", "_fold"):
+            m.__dict__.pop("_pm_cache", None)
+            for attr in ("_ffb6d_fold", "_slope", "_shift", "_wt", "_fold"):
                 if hasattr(m, attr):
                     setattr(m, attr, None)
         return super().train(mode)
@@ -438,7 +435,7 @@ class FFB6D(nn.Module):
         """One bidirectional fusion step (ffb6d.py:245-263 / 281-298); both directions read
         the pre-fusion tensors, so they are independent."""
         bs, c, hr, wr = rgb_emb0.shape
-        if _autograd_path(rgb_emb0):
+        if _autograd_path(rgb_emb0, self):
             p2r = ops.nearest_interpolation(pre_p2r[i](p_emb0), p2r_idx).view(bs, -1, hr, wr)
             rgb_emb = fuse_p2r[i](torch.cat((rgb_emb0, p2r), dim=1))
             r2p = ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx)
@@ -457,7 +454,7 @@ class FFB6D(nn.Module):
 
     def _decode(self, stage, skip, p_emb, interp_idx):
         """RandLA decoder step conv(cat(skip, interp(p))) (ffb6d.py:273-279,302-307)."""
-        if _autograd_path(skip):
+        if _autograd_path(skip, self):
             return stage(torch.cat([skip, ops.nearest_interpolation(p_emb, interp_idx)], dim=1))
         wa, wb, bias = stage.split(skip.shape[1])
         y = ops.shared_mlp(p_emb, wb, None, ops.ACT_NONE)
@@ -474,6 +471,9 @@ class FFB6D(nn.Module):
     # Tensors crossing streams are handed over with events and record_stream().
     # ------------------------------------------------------------------------------------------
     two_streams = True
+    # activation layout of the fused inference path: "pm" = point-major / pixel-major rows (forward_pm.py, default),
+    # "cm" = the reference's channel-major layout on the first-generation kernels (kept for A/B measurements)
+    layout = "pm"
 
     def _side_stream(self, device):
         st = getattr(self, "_side", None)
@@ -563,13 +563,16 @@ class FFB6D(nn.Module):
             bs, 1, 3, -1).permute(0, 1, 3, 2).contiguous()
         return end_points
 
-    def forward(self, inputs, end_points=None, scale=1):
+    def forward(self, inputs, end_points=None, scale=1, taps=None):
         if not end_points:
             end_points = {}
         rgb = inputs['rgb']
-        if self.two_streams and not _autograd_path(rgb) and (rgb.shape[2] * rgb.shape[3]) % 16 == 0:
+        fused = not _autograd_path(rgb, self)
+        if fused and self.layout == "pm" and forward_pm.supported(self):
+            return forward_pm.forward(self, inputs, end_points, two_streams=self.two_streams, taps=taps)
+        if self.two_streams and fused and (rgb.shape[2] * rgb.shape[3]) % 16 == 0:
             return self._forward_two_streams(inputs, end_points)
-        if _autograd_path(inputs['rgb']) or (inputs['rgb'].shape[2] * inputs['rgb'].shape[3]) % 16:
+        if not fused or (inputs['rgb'].shape[2] * inputs['rgb'].shape[3]) % 16:
             rgb_emb = self.cnn_pre_stages(inputs['rgb'])
         else:   # stem: conv7x7 -> [BN+ReLU in one pass] -> maxpool
             y = ops.affine_act_(self.cnn_pre_stages[0](inputs['rgb']), *ops.bn_fold(self.cnn_pre_stages[1]),
@@ -608,7 +611,7 @@ class FFB6D(nn.Module):
         rgb_emb_c = ops.choose_gather(rgb_emb, inputs['choose'])
 
         def head(seq):
-            if _autograd_path(p_emb):
+            if not fused:
                 return seq(torch.cat([rgb_emb_c, p_emb], dim=1))
             y = seq[0].fused(rgb_emb_c, x2=p_emb)          # cat(rgb_c, p_emb) as two K-ranges
             for layer in list(seq)[1:]:

@@ -1,0 +1,254 @@
+"""Operators of the point-major / pixel-major ("channels last") inference path: every activation is a matrix
+[rows, C] with one contiguous row of C floats per point or pixel, rows running over all frames of the batch.
+Thin wrappers around the C ABI (include/ffb6d_ops.h); inference only (no autograd), GPU only (no CPU fallback).
+
+Reference functions these implement are cited per wrapper; the layout itself is this package's choice (every gather
+of the hot path moves whole rows, both GEMM operands are K-contiguous -- csrc/mlp_pm.hip)."""
+import torch
+
+from . import _lib
+from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU, _idx, _need_gpu, _stream  # noqa: F401
+
+
+def rows_view(x):
+    """[..., C] tensor whose leading dims are row-regular -> (2-d view [rows, C], row stride in floats)."""
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    if x2.stride(1) != 1 or x2.data_ptr() % 16 or (x2.shape[0] > 1 and x2.stride(0) % 4):
+        x2 = x2.contiguous()
+    return x2, (x2.stride(0) if x2.shape[0] > 1 else C)
+
+
+ACT_LOG_SOFTMAX = 3
+
+
+def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gather=None, out=None, tile_hint=0):
+    """Shared MLP (1x1 conv + folded BatchNorm + activation; pytorch_utils.py:75-129, RandLA/pytorch_utils.py:35-111)
+    on row-major activations:  out[r,:] = act(w @ cat(x1[r], x2[r]) + bias + extra[r])
+        x1 [..., K1], x2 [..., K2] or None, w [Cout, K1+K2] (conv weight layout, BN folded), bias [Cout] or None
+        add       = Y [..., Cout] with the output's leading shape: extra[r] = Y[r]          (residual / broadcast sums)
+        gather    = (Y [B, Py, Cout], idx [B, P]): extra[b, p] = Y[b, idx[b, p]]            (conv(cat(a, interp(b))))
+        x1_gather = idx [B, P]: x1 is [B, M, K1] and row (b, p) of the GEMM reads x1[b, idx[b, p]]   (`choose`, :309-312)
+    act: ACT_NONE / ACT_RELU / ACT_LEAKY / ACT_LOG_SOFTMAX (over the Cout <= 64 channels, pspnet.py:108-112).
+    Returns [..., Cout] (or writes `out`, which may be a channel slice of a wider row buffer)."""
+    _need_gpu(x1, w)
+    lib = _lib.load()
+    if x1.dtype != torch.float32 or w.dtype != torch.float32:
+        raise TypeError("float32 expected")
+    a, ld1 = rows_view(x1.detach())
+    K1 = a.shape[1]
+    xi, px, bits = None, 0, 0
+    lead = x1.shape[:-1]
+    if x1_gather is not None:
+        if x1.dim() != 3 or x1_gather.dim() != 2 or x1_gather.shape[0] != x1.shape[0]:
+            raise ValueError("x1_gather needs x1 [B,M,K1] and idx [B,P]")
+        xi, bits = _idx(x1_gather.reshape(-1))
+        px = x1.shape[1]
+        lead = tuple(x1_gather.shape)
+    rows = 1
+    for n in lead:
+        rows *= int(n)
+    P = rows // lead[0] if (x1_gather is not None or gather is not None) and len(lead) else rows
+    b, ld2, K2 = None, 0, 0
+    if x2 is not None:
+        b, ld2 = rows_view(x2.detach())
+        K2 = b.shape[1]
+        if b.shape[0] != rows:
+            raise ValueError(f"x2 {tuple(x2.shape)} does not match the {rows} output rows")
+    if w.dim() != 2 or w.shape[1] != K1 + K2 or not w.is_contiguous():
+        raise ValueError(f"w must be contiguous [Cout, {K1 + K2}], got {tuple(w.shape)}")
+    Cout = w.shape[0]
+    y = gi = None
+    ldy = py = 0
+    if gather is not None:
+        yv, gidx = gather
+        B = yv.shape[0]
+        y, ldy = rows_view(yv.detach())
+        py = yv.shape[1]
+        gi, gbits = _idx(gidx.reshape(-1))
+        if xi is not None and gbits != bits:
+            raise TypeError("x1_gather and gather indices must have the same dtype")
+        bits = gbits
+        if gi.numel() != rows or rows % B:
+            raise ValueError("gather index must have one entry per output row")
+        P = rows // B
+    elif add is not None:
+        y, ldy = rows_view(add.detach())
+        if y.shape[0] != rows or y.shape[1] != Cout:
+            raise ValueError(f"add {tuple(add.shape)} does not match the output [{rows}, {Cout}]")
+    if out is None:
+        out = torch.empty(tuple(lead) + (Cout,), dtype=torch.float32, device=x1.device)
+    if out.stride(-1) != 1 or out.numel() != rows * Cout:
+        raise ValueError("out must be [..., Cout] with contiguous channels")
+    ldo = out.stride(-2) if out.dim() >= 2 and rows > 1 else Cout
+    if out.dim() > 2 and any(out.stride(i) != out.stride(i + 1) * out.shape[i + 1] for i in range(out.dim() - 2)):
+        raise ValueError("out must be row-regular (a channel slice of a contiguous row buffer is fine)")
+    nbytes = 4 * ((K1 + K2) * Cout + rows * (K1 + K2) + rows * Cout) + rows * (bits // 8) * ((gi is not None) + (xi is not None)) + \
+        (4 * (y.shape[0] if gi is None else rows) * Cout if y is not None else 0)
+    if _lib.TRACER is not None:      # tag = the kernel instantiation a profile lists this launch under
+        tile = int(tile_hint) if tile_hint > 0 else lib.ffb6d_mlp_pm_tile(rows, Cout, K1 + K2, int(act))
+    else:
+        tile = 0
+    with torch.cuda.device(x1.device), _lib.traced("mlp_pm", nbytes, (K1 + K2, Cout, rows, tile)):
+        rc = lib.ffb6d_mlp_pm_f32(w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                  a.data_ptr(), K1, ld1, xi.data_ptr() if xi is not None else None, px,
+                                  b.data_ptr() if b is not None else None, K2, ld2,
+                                  y.data_ptr() if y is not None else None, ldy,
+                                  gi.data_ptr() if gi is not None else None, py, bits, P,
+                                  out.data_ptr(), ldo, rows, Cout, int(act), int(tile_hint), _stream(x1))
+    _lib.check(rc, "ffb6d_mlp_pm_f32")
+    return out
+
+
+def att_pool(f, nei_idx, g, w_fc, out=None):
+    """Att_pooling.forward up to the pooled tensor (RandLANet.py:243-248) with the neighbour gather fused in.
+    f [B,N,C1] point features, nei_idx [B,N,16], g [B,N,16,C2] per-pair features, w_fc [C1+C2, C1+C2] (fc conv weight)
+    -> [B,N,C1+C2] = sum_k S * softmax_k(S w_fc^T), S[(n,k)] = cat(f[nei[n,k]], g[n,k])."""
+    _need_gpu(f, g, w_fc)
+    lib = _lib.load()
+    B, N, C1 = f.shape
+    K, C2 = g.shape[2], g.shape[3]
+    if g.shape[:2] != (B, N) or nei_idx.shape != (B, N, K) or w_fc.shape != (C1 + C2, C1 + C2) or not w_fc.is_contiguous():
+        raise ValueError(f"bad shapes {tuple(f.shape)} / {tuple(nei_idx.shape)} / {tuple(g.shape)} / {tuple(w_fc.shape)}")
+    f2, ldf = rows_view(f.detach())
+    g2, ldg = rows_view(g.detach())
+    idx, bits = _idx(nei_idx)
+    d = C1 + C2
+    if out is None:
+        out = torch.empty((B, N, d), dtype=torch.float32, device=f.device)
+    nbytes = 4 * (d * d + B * N * C1 + B * N * K * C2 + B * N * d) + (bits // 8) * B * N * K
+    with torch.cuda.device(f.device), _lib.traced("att_pool_pm", nbytes, (d, N)):
+        rc = lib.ffb6d_att_pool_pm_f32(w_fc.data_ptr(), f2.data_ptr(), C1, ldf, idx.data_ptr(), bits, g2.data_ptr(), C2, ldg,
+                                       out.data_ptr(), out.stride(-2), B, N, K, _stream(f))
+    _lib.check(rc, "ffb6d_att_pool_pm_f32")
+    return out
+
+
+def random_sample(feature, pool_idx):
+    """FFB6D.random_sample (ffb6d.py:159-177) on rows: feature [B,M,C], pool_idx [B,Np,K] -> [B,Np,C] (max over K rows)."""
+    _need_gpu(feature, pool_idx)
+    lib = _lib.load()
+    f = feature.detach()
+    f = f if f.is_contiguous() else f.contiguous()
+    B, M, C = f.shape
+    Np, K = pool_idx.shape[1], pool_idx.shape[2]
+    idx, bits = _idx(pool_idx)
+    out = torch.empty((B, Np, C), dtype=torch.float32, device=f.device)
+    nbytes = 4 * B * C * M + (bits // 8) * B * Np * K + 4 * B * C * Np
+    with torch.cuda.device(f.device), _lib.traced("random_sample_pm", nbytes, (C, M, Np)):
+        rc = lib.ffb6d_random_sample_pm_f32(f.data_ptr(), idx.data_ptr(), bits, out.data_ptr(), B, M, C, Np, K, _stream(f))
+    _lib.check(rc, "ffb6d_random_sample_pm_f32")
+    return out
+
+
+def gather_rows(feature, idx):
+    """FFB6D.nearest_interpolation / the `choose` pick (ffb6d.py:179-194,309-312) on rows:
+    feature [B,M,C], idx [B,U] -> [B,U,C]."""
+    _need_gpu(feature, idx)
+    lib = _lib.load()
+    f = feature.detach()
+    f = f if f.is_contiguous() else f.contiguous()
+    B, M, C = f.shape
+    i, bits = _idx(idx.reshape(B, -1))
+    U = i.shape[1]
+    out = torch.empty((B, U, C), dtype=torch.float32, device=f.device)
+    nbytes = 4 * B * C * M + (bits // 8) * B * U + 4 * B * C * U
+    with torch.cuda.device(f.device), _lib.traced("gather_rows_pm", nbytes, (C, M, U)):
+        rc = lib.ffb6d_gather_rows_pm_f32(f.data_ptr(), i.data_ptr(), bits, out.data_ptr(), B, M, C, U, _stream(f))
+    _lib.check(rc, "ffb6d_gather_rows_pm_f32")
+    return out
+
+
+def relative_pos_encoding(xyz, neigh_idx):
+    """relative_pos_encoding (RandLANet.py:216-223) as rows of 16 floats [dis, p-q, p, q, 0*6]: xyz [B,N,3],
+    neigh_idx [B,N,K] -> [B,N,K,16] (the zero padding makes the row a legal K of the point-major shared MLP)."""
+    _need_gpu(xyz, neigh_idx)
+    lib = _lib.load()
+    x = xyz.detach().contiguous()
+    idx, bits = _idx(neigh_idx)
+    B, N, K = idx.shape
+    out = torch.empty((B, N, K, 16), dtype=torch.float32, device=x.device)
+    nbytes = 12 * B * N + (bits // 8) * B * N * K + 64 * B * N * K
+    with torch.cuda.device(x.device), _lib.traced("relative_pos_encoding_pm", nbytes, (N,)):
+        rc = lib.ffb6d_relative_pos_encoding_pm_f32(x.data_ptr(), idx.data_ptr(), bits, out.data_ptr(), B, N, K, _stream(x))
+    _lib.check(rc, "ffb6d_relative_pos_encoding_pm_f32")
+    return out
+
+
+def affine_act_(x, scale, shift, act=ACT_NONE, slope=0.0, residual=None, res_affine=None):
+    """In-place per-channel affine + optional (affine) residual + activation on [..., C] rows (the eval-mode
+    BatchNorm / ReLU / PReLU / residual glue of the colour branch, extractors.py:49-63, pspnet.py:34-45)."""
+    _need_gpu(x)
+    lib = _lib.load()
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise ValueError("affine_act_ needs a contiguous float32 tensor")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    r = rs = rb = None
+    if residual is not None:
+        r = residual if residual.is_contiguous() else residual.contiguous()
+        if r.shape != x.shape:
+            raise ValueError("residual shape mismatch")
+        if res_affine is not None:
+            rs, rb = res_affine
+    nbytes = 4 * x.numel() * (3 if r is not None else 2)
+    with torch.cuda.device(x.device), _lib.traced("affine_act_pm", nbytes, (C, rows)):
+        rc = lib.ffb6d_affine_act_pm_f32(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                         r.data_ptr() if r is not None else None,
+                                         rs.data_ptr() if rs is not None else None,
+                                         rb.data_ptr() if rb is not None else None,
+                                         x.data_ptr(), rows, C, int(act), float(slope), _stream(x))
+    _lib.check(rc, "ffb6d_affine_act_pm_f32")
+    return x
+
+
+def bilinear_resize(x, size, align_corners):
+    """x [B,IH,IW,C] -> [B,OH,OW,C], bilinear (pspnet.py:24-28 align_corners=False; :37-42 align_corners=True)."""
+    _need_gpu(x)
+    lib = _lib.load()
+    xc = x.detach()
+    xc = xc if xc.is_contiguous() else xc.contiguous()
+    B, IH, IW, C = xc.shape
+    OH, OW = int(size[0]), int(size[1])
+    out = torch.empty((B, OH, OW, C), dtype=torch.float32, device=x.device)
+    nbytes = 4 * B * C * (IH * IW + OH * OW)
+    with torch.cuda.device(x.device), _lib.traced("bilinear_resize_pm", nbytes, (C, OH, OW)):
+        rc = lib.ffb6d_bilinear_resize_pm_f32(xc.data_ptr(), out.data_ptr(), B, IH, IW, OH, OW, C,
+                                              1 if align_corners else 0, _stream(xc))
+    _lib.check(rc, "ffb6d_bilinear_resize_pm_f32")
+    return out
+
+
+def _int_array(values):
+    import ctypes
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
+
+
+def psp_pool(x, sizes):
+    """All adaptive average pools of `sizes` of x [B,H,W,C] in one launch -> [B, sum(s*s), C]."""
+    _need_gpu(x)
+    lib = _lib.load()
+    xc = x.detach()
+    xc = xc if xc.is_contiguous() else xc.contiguous()
+    B, H, W, C = xc.shape
+    nb = sum(int(s) * int(s) for s in sizes)
+    out = torch.empty((B, nb, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _lib.traced("psp_pool_pm", 4 * xc.numel() + 4 * out.numel(), (C, H * W)):
+        rc = lib.ffb6d_psp_pool_pm_f32(xc.data_ptr(), out.data_ptr(), B, H, W, C, _int_array(sizes), len(sizes), _stream(xc))
+    _lib.check(rc, "ffb6d_psp_pool_pm_f32")
+    return out
+
+
+def psp_prior_sum(z, sizes, size):
+    """z [B, sum(s*s), M] -> [B,H,W,M] = sum over levels of the bilinear (align_corners=False) up-sampling to (H,W)."""
+    _need_gpu(z)
+    lib = _lib.load()
+    zc = z.detach()
+    zc = zc if zc.is_contiguous() else zc.contiguous()
+    B, _, M = zc.shape
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty((B, H, W, M), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device), _lib.traced("psp_prior_sum_pm", 4 * zc.numel() + 4 * out.numel(), (M, H * W)):
+        rc = lib.ffb6d_psp_prior_sum_pm_f32(zc.data_ptr(), out.data_ptr(), B, H, W, M, _int_array(sizes), len(sizes), _stream(zc))
+    _lib.check(rc, "ffb6d_psp_prior_sum_pm_f32")
+    return out

@@ -109,6 +109,58 @@ int ffb6d_shared_mlp_f32(const float* wt, const float* bias, const float* x1, in
  * K loop is split across workgroups and reduced by a second kernel). */
 size_t ffb6d_shared_mlp_workspace_bytes(int64_t B, int64_t cout, int64_t K, int64_t P);
 
+/* ==== point-major / pixel-major ("channels last") operators: one row of C contiguous floats per point or pixel ====
+ * (csrc/mlp_pm.hip, csrc/ops_pm.hip).  Rows run over the points of ALL frames unless stated; row strides (ld*) are in floats. */
+
+/* Shared MLP: out[r,m] = act( sum_k w[m,k] * X[r,k] + bias[m] + y[yrow(r), m] ), X = [x1 | x2] along k.
+ * w [cout, k1+k2] is the conv weight in the layout nn.Conv stores it (BN folded); x1 [.., ld1] / x2 [rows, ld2], the first
+ * k1 / k2 floats of a row are used (multiples of 8).  Optional operand gather: with x1_idx [rows] the x1 row of output row r
+ * is (r / rows_per_frame) * x1_rows_per_frame + x1_idx[r] (the `choose` pick of ffb6d.py:309-312 fused into the head GEMM).
+ * Optional epilogue rows y [.., ldy]: with y_idx [rows] row (r / rows_per_frame) * y_rows_per_frame + y_idx[r]
+ * (conv(cat(a, interp(b))) == W_a a + gather(W_b b), ffb6d.py:247-253,273-279), with y_idx NULL row r itself.
+ * idx_bits 32/64 applies to both index arrays.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 log_softmax over the cout <= 64
+ * channels (pspnet.py:108-112).  out [rows, ldo].  tile_hint 0 = choose the tile shape from the problem size. */
+int ffb6d_mlp_pm_f32(const float* w, const float* bias, const float* x1, int64_t k1, int64_t ld1, const void* x1_idx,
+                     int64_t x1_rows_per_frame, const float* x2, int64_t k2, int64_t ld2, const float* y, int64_t ldy,
+                     const void* y_idx, int64_t y_rows_per_frame, int idx_bits, int64_t rows_per_frame, float* out,
+                     int64_t ldo, int64_t rows, int64_t cout, int act, int tile_hint, ffb6d_stream_t stream);
+
+/* Tile shape ffb6d_mlp_pm_f32 picks for tile_hint 0 (pure host logic): 1 = 128 ch x 128 pt, 2 = 64 x 256, 3 = 32 x 256,
+ * 4 = 64 x 64, 5 = 64 x 32 with K split over the four waves -- i.e. which kernel instantiation a profile will list. */
+int ffb6d_mlp_pm_tile(int64_t rows, int64_t cout, int64_t K, int act);
+
+/* Att_pooling.forward up to the pooled tensor (RandLANet.py:243-248) with the neighbour gather fused in:
+ * S[(n,k),:] = [ f[nei[n,k],:] | g[(n,k),:] ], out[n,m] = sum_k S[(n,k),m] * softmax_k((S w_fc^T)[(n,k),m]).
+ * f [B*N, ldf] point rows (c1 channels), nei [B,N,16] indices inside the frame, g [B*N*16, ldg] pair rows (c2 channels),
+ * w_fc [c1+c2, c1+c2] (conv layout), out [B*N, ldo].  Neither the gathered tensor nor the scores are written. */
+int ffb6d_att_pool_pm_f32(const float* w_fc, const float* f, int64_t c1, int64_t ldf, const void* nei, int idx_bits,
+                          const float* g, int64_t c2, int64_t ldg, float* out, int64_t ldo, int64_t B, int64_t N, int K,
+                          ffb6d_stream_t stream);
+
+/* FFB6D.random_sample (ffb6d.py:159-177): out[b,n,:] = max_k feat[b, idx[b,n,k], :]; feat [B,M,C], idx [B,Np,K], C % 4 == 0. */
+int ffb6d_random_sample_pm_f32(const float* feat, const void* idx, int idx_bits, float* out, int64_t B, int64_t M, int64_t C,
+                               int64_t Np, int K, ffb6d_stream_t stream);
+/* FFB6D.nearest_interpolation / the `choose` pick (ffb6d.py:179-194,309-312): out[b,u,:] = feat[b, idx[b,u], :]. */
+int ffb6d_gather_rows_pm_f32(const float* feat, const void* idx, int idx_bits, float* out, int64_t B, int64_t M, int64_t C,
+                             int64_t U, ffb6d_stream_t stream);
+/* relative_pos_encoding (RandLANet.py:216-223) as rows of 16 floats: [dis, p-q, p, q, 0 x 6]; out [B,N,K,16]. */
+int ffb6d_relative_pos_encoding_pm_f32(const float* xyz, const void* idx, int idx_bits, float* out, int64_t B, int64_t N,
+                                       int K, ffb6d_stream_t stream);
+/* out = act( scale[c]*x + shift[c] + (res ? (rscale ? rscale[c]*res + rshift[c] : res) : 0) ) on [rows, C]; act as
+ * ffb6d_affine_act_f32.  In place (out == x) allowed. */
+int ffb6d_affine_act_pm_f32(const float* x, const float* scale, const float* shift, const float* res, const float* rscale,
+                            const float* rshift, float* out, int64_t rows, int64_t C, int act, float slope,
+                            ffb6d_stream_t stream);
+/* Bilinear resize [B,IH,IW,C] -> [B,OH,OW,C] (ATen upsample_bilinear2d arithmetic; pspnet.py:24-28,37-42). */
+int ffb6d_bilinear_resize_pm_f32(const float* in, float* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
+                                 int64_t C, int align_corners, ffb6d_stream_t stream);
+/* All adaptive average pools of `sizes` of x [B,H,W,C] -> [B, sum(s*s), C] (bins of sizes[0] first, row-major in a level). */
+int ffb6d_psp_pool_pm_f32(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, const int* sizes,
+                          int nsizes, ffb6d_stream_t stream);
+/* out[b,y,x,:] = sum over levels of the bilinear (align_corners = 0) up-sampling of z [B, sum(s*s), M] to (H,W). */
+int ffb6d_psp_prior_sum_pm_f32(const float* z, float* out, int64_t B, int64_t H, int64_t W, int64_t M, const int* sizes,
+                               int nsizes, ffb6d_stream_t stream);
+
 /* Attentive pooling with the score GEMM fused in (Att_pooling.forward, RandLANet.py:243-248, up to
  * the pooled tensor): scores = W_fc * S over the feature set S = cat(x1 [B,k1,N,16], x2 [B,k2,N,16]),
  * out[b,m,n] = sum_k S[b,m,n,k] * softmax_k(scores[b,m,n,:]).  wt = W_fc transposed [k1+k2, k1+k2];

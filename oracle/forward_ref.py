@@ -123,8 +123,10 @@ def head(x, w):
     return mlp_pvn(x, w.sub("3"), act=False)
 
 
-def ffb6d_forward(state_dict, inputs, n_kps=8):
-    """inputs: the reference's input dict (torch CPU tensors, int64 indices)."""
+def ffb6d_forward(state_dict, inputs, n_kps=8, taps=None):
+    """inputs: the reference's input dict (torch CPU tensors, int64 indices).
+    taps: optional dict that receives the two embeddings after every fusion stage (`rgb_emb_ds{i}`, `p_emb_ds{i}`,
+    `rgb_emb_up{i}`, `p_emb_up{i}`, reference layout [B,C,H,W] / [B,C,N,1]) for stage-level parity checks."""
     w = _W(state_dict)
     rgb_emb = F.conv2d(inputs["rgb"], w["cnn_pre_stages.0.weight"], None, 2, 3)
     rgb_emb = F.relu(_bn(rgb_emb, w.sub("cnn_pre_stages.1"), 1e-5))
@@ -155,6 +157,8 @@ def ffb6d_forward(state_dict, inputs, n_kps=8):
         r2p = mlp_pvn(r2p, w.sub(f"ds_fuse_r2p_pre_layers.{i}"))
         p_emb = mlp_pvn(torch.cat((p_emb0, r2p), dim=1), w.sub(f"ds_fuse_r2p_fuse_layers.{i}"))
         ds_emb.append(p_emb)
+        if taps is not None:
+            taps[f"rgb_emb_ds{i}"], taps[f"p_emb_ds{i}"] = rgb_emb, p_emb
 
     for i in range(3):
         cw = w.sub(f"cnn_up_stages.{i}")
@@ -168,6 +172,8 @@ def ffb6d_forward(state_dict, inputs, n_kps=8):
         r2p = ops_ref.random_sample(rgb_emb0.reshape(bs, c, hr * wr), inputs[f"r2p_up_nei_idx{i}"])
         r2p = mlp_pvn(r2p, w.sub(f"up_fuse_r2p_pre_layers.{i}"))
         p_emb = mlp_pvn(torch.cat((p_emb0, r2p), dim=1), w.sub(f"up_fuse_r2p_fuse_layers.{i}"))
+        if taps is not None:
+            taps[f"rgb_emb_up{i}"], taps[f"p_emb_up{i}"] = rgb_emb, p_emb
 
     cw = w.sub("cnn_up_stages.3")
     rgb_emb = final_head(psp_upsample(rgb_emb, cw.sub("0")), cw.sub("1"))

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 #    convolution algorithms over ~110 layers (the plain-torch GPU run shows the same
 #    deviation, asserted below), so the bar is looser and the measured value is printed.
 HOT_TOL = 1e-5
-E2E_TOL = 1e-2
+E2E_TOL = 1e-3
 
 
 def build(n_classes, n_pts, device):
@@ -34,8 +34,24 @@ def build(n_classes, n_pts, device):
 
 
 def rel_err(got, want):
-    scale = max(float(np.abs(want).max()), 1.0)
+    """max |got - want| relative to the range of THIS tensor (no floor: the small-magnitude offset heads are judged
+    on their own scale, not on the logits')."""
+    scale = float(np.abs(want).max())
+    assert scale > 0
     return float(np.abs(got - want).max()) / scale
+
+
+def assert_close_scaled(got, want, tol, what):
+    """per-tensor range bar `tol` plus an elementwise bar: |diff| <= 10*tol*|want| + tol*range."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = float(np.abs(want).max())
+    assert scale > 0, what
+    diff = np.abs(got - want)
+    err = float(diff.max()) / scale
+    print(what, "max err / range", err)
+    assert err <= tol, (what, err)
+    assert (diff <= 10 * tol * np.abs(want) + tol * scale).all(), what
 
 
 def oracle_on_device(net, inputs):
@@ -45,19 +61,100 @@ def oracle_on_device(net, inputs):
         return forward_ref.ffb6d_forward(sd, {k: (v.long() if v.dtype == torch.int32 else v) for k, v in inputs.items()})
 
 
-@pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (1, 1, 12288, 480, 640, 22), (4, 1, 24576, 480, 640, 22)])
-def test_hot_path_matches_plain_torch_on_the_same_device(device, cfg):
+# the last two are the benchmarked configurations (BASELINE.json configs 2 and 4: bs=8, N=12288 / N=24576)
+@pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (1, 1, 12288, 480, 640, 22), (4, 1, 24576, 480, 640, 22),
+                                 (2, 8, 12288, 480, 640, 22), (4, 8, 24576, 480, 640, 22)])
+@pytest.mark.parametrize("layout", ["pm", "cm"])
+def test_hot_path_matches_plain_torch_on_the_same_device(device, cfg, layout):
     config, bs, n_pts, h, w, n_cls = cfg
+    if layout == "cm" and bs == 8:
+        pytest.skip("channel-major A/B path: covered at bs <= 2")
     frames = synth.make_batch(config, bs, n_points=n_pts, height=h, width=w)
     net = build(n_cls, n_pts, device)
+    net.layout = layout
     inputs = pyramid.frames_to_device(frames, device)
     with torch.no_grad():
         ep = net(inputs)
     ref = oracle_on_device(net, inputs)
     for k in ("pred_rgbd_segs", "pred_kp_ofs", "pred_ctr_ofs"):
-        err = rel_err(ep[k].cpu().numpy(), ref[k].cpu().numpy())
-        print(cfg, k, "hot-path max rel err", err)
-        assert err <= HOT_TOL, (k, err)
+        assert_close_scaled(ep[k].cpu().numpy(), ref[k].cpu().numpy(), HOT_TOL, (cfg, layout, k))
+
+
+@pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (1, 2, 12288, 480, 640, 22)])
+def test_every_fusion_stage_matches_plain_torch(device, cfg):
+    """Stage-level parity of the fused point-major path: both embeddings after each of the 4 encoder and 3 decoder
+    fusion stages (ffb6d.py:245-263,281-298) against the plain-torch restatement on the same device, each on the
+    range of its own tensor (a whole-network bar alone would hide an O(1)-wrong sub-stage behind later layers)."""
+    from oracle import forward_ref
+    config, bs, n_pts, h, w, n_cls = cfg
+    frames = synth.make_batch(config, bs, n_points=n_pts, height=h, width=w)
+    net = build(n_cls, n_pts, device)
+    inputs = pyramid.frames_to_device(frames, device)
+    taps, ref_taps = {}, {}
+    with torch.no_grad():
+        net(inputs, taps=taps)
+        forward_ref.ffb6d_forward(dict(net.state_dict()), inputs, taps=ref_taps)
+    assert sorted(taps) == sorted(ref_taps) and len(taps) == 14
+    for k in sorted(taps):
+        assert_close_scaled(taps[k].cpu().numpy(), ref_taps[k].cpu().numpy(), HOT_TOL, (cfg, k))
+
+
+def test_weight_updates_reach_the_fused_kernels(device):
+    """Stale-cache guard (folded / split / padded / channels-last weights are cached per module): a model that already
+    ran in eval() and then gets other weights -- load_state_dict, an in-place edit -- must answer like a fresh model."""
+    frames = synth.make_batch(7, 1, n_points=1024, height=120, width=160)
+    with open(os.path.join(GOLDEN, "state_dict_keys.json")) as fh:
+        shapes = json.load(fh)
+    sd_a = synth.synth_state_dict_from_shapes(shapes, seed=0, n_classes=5)
+    sd_b = synth.synth_state_dict_from_shapes(shapes, seed=1, n_classes=5)
+    inputs = pyramid.frames_to_device(frames, device)
+    for layout in ("pm", "cm"):
+        net = M.FFB6D(n_classes=5, n_pts=1024)
+        net.load_state_dict(sd_a)
+        net = net.to(device).eval()
+        net.layout = layout
+        fresh = M.FFB6D(n_classes=5, n_pts=1024)
+        fresh.load_state_dict(sd_b)
+        fresh = fresh.to(device).eval()
+        fresh.layout = layout
+        with torch.no_grad():
+            first = {k: v.clone() for k, v in net(inputs).items()}
+            net.load_state_dict(sd_b)                      # same Parameter objects, new values
+            second = net(inputs)
+            want = fresh(inputs)
+            for k in want:
+                assert not torch.equal(first[k], second[k]), (layout, k)
+                assert_close_scaled(second[k].cpu().numpy(), want[k].cpu().numpy(), HOT_TOL, (layout, k, "reload"))
+            w = net.rndla_ds_stages[1].lfa.att_pooling_1.fc.weight
+            w.mul_(1.5)                                    # in-place edit while staying in eval()
+            fresh.rndla_ds_stages[1].lfa.att_pooling_1.fc.weight.mul_(1.5)
+            third, want = net(inputs), fresh(inputs)
+            for k in want:
+                assert_close_scaled(third[k].cpu().numpy(), want[k].cpu().numpy(), HOT_TOL, (layout, k, "edit"))
+            assert any(not torch.equal(third[k], second[k]) for k in want)
+
+
+def test_train_mode_without_grad_keeps_training_semantics(device):
+    """train() under torch.no_grad() (BatchNorm re-calibration, a validation loop without eval()): the fused kernels
+    fold RUNNING statistics, so they must not be used -- batch statistics, running-stat updates and the autograd-capable
+    operators run instead, exactly like the unfused layers."""
+    torch.manual_seed(0)
+    mlp = M.SharedMLP(16, 8).to(device)
+    x = torch.randn(2, 16, 300, 1, device=device)
+    mlp.train()
+    before = mlp.bn.bn.running_mean.clone()
+    with torch.no_grad():
+        got = mlp(x)
+    assert not torch.equal(mlp.bn.bn.running_mean, before)          # statistics were updated
+    y = torch.nn.functional.conv2d(x, mlp.conv.weight)
+    mean, var = y.mean(dim=(0, 2, 3)), y.var(dim=(0, 2, 3), unbiased=False)
+    want = torch.nn.functional.leaky_relu((y - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + 1e-6) *
+                                          mlp.bn.bn.weight.view(1, -1, 1, 1) + mlp.bn.bn.bias.view(1, -1, 1, 1), 0.2)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    mlp.eval()
+    with torch.no_grad():
+        fused = mlp(x)                                             # eval + no_grad: folded running statistics
+    assert not torch.allclose(fused, got)
 
 
 def test_forward_small_matches_reference(device):
@@ -72,7 +169,7 @@ def test_forward_small_matches_reference(device):
             got = ep[k].cpu().numpy()
             assert got.shape == gold[k].shape
             err = rel_err(got, gold[k])
-            print(k, "max rel err", err)
+            print(k, "max err / range vs the reference's CPU end_points", err)
             assert err <= E2E_TOL, (k, err)
 
 
@@ -88,7 +185,7 @@ def test_forward_full_size_matches_reference_sample(device):
     assert ep["pred_ctr_ofs"].shape == (1, 1, 12288, 3)
     plain = oracle_on_device(net, inputs)
     for k in ("pred_rgbd_segs", "pred_kp_ofs", "pred_ctr_ofs"):
-        scale = max(float(gold[k + "/absmax"]), 1.0)
+        scale = float(gold[k + "/absmax"])
         err = float(np.abs(ep[k].cpu().numpy().reshape(-1)[::97] - gold[k]).max()) / scale
         err_plain = float(np.abs(plain[k].cpu().numpy().reshape(-1)[::97] - gold[k]).max()) / scale
         print(k, "max rel err vs reference CPU: ours", err, "plain torch on GPU", err_plain)
@@ -120,7 +217,7 @@ def test_two_stream_forward_equals_single_stream(device):
                 if reproducible:
                     assert torch.equal(got[k], want[k]), (rep, k, float((got[k] - want[k]).abs().max()))
                 else:
-                    scale = max(float(want[k].abs().max()), 1.0)
+                    scale = float(want[k].abs().max())
                     assert float((got[k] - want[k]).abs().max()) <= HOT_TOL * scale, (rep, k)
 
 

@@ -58,8 +58,78 @@ def test_batchnorm_folding_is_exact_algebra(flavour, dims):
     torch.testing.assert_close(y.view_as(want), want, rtol=1e-5, atol=1e-5)
     wa, wb, b2 = mlp.split(5)
     assert torch.equal(torch.cat([wa, wb]), wt) and b2 is b
-    mlp.train()
-    assert mlp._folded is None
+    # point-major operands of the same layer: conv-layout weight (optionally K-padded with zero columns), same bias
+    from ffb6d_amd import forward_pm
+    w_pm, b_pm = forward_pm.folded(mlp)
+    assert torch.equal(w_pm, wt.t()) and torch.equal(b_pm, b)
+    w16, _ = forward_pm.folded(mlp, pad_k=16)
+    assert w16.shape == (7, 16) and torch.equal(w16[:, :12], w_pm) and (w16[:, 12:] == 0).all()
+
+
+def test_folded_weight_caches_follow_in_place_edits_and_load_state_dict():
+    """Every inference-time weight cache is keyed on the version / storage / device of its sources
+    (forward_pm.cached): optimizer-style in-place edits, load_state_dict into a model that already ran in eval(),
+    and BatchNorm statistic updates must all be picked up without a train() round trip."""
+    from ffb6d_amd import forward_pm
+    torch.manual_seed(1)
+    mlp = M.SharedMLP(8, 4, flavour="pvn").eval()
+    wt0, b0 = mlp.folded()
+    assert mlp.folded()[0] is wt0                                   # cache hit
+    with torch.no_grad():
+        mlp.conv.weight.mul_(2.0)
+    wt1, _ = mlp.folded()
+    torch.testing.assert_close(wt1, 2 * wt0)
+    with torch.no_grad():
+        mlp._bn_module().running_mean.add_(1.0)
+    assert not torch.equal(mlp.folded()[1], b0)
+    other = M.SharedMLP(8, 4, flavour="pvn").eval()
+    mlp.load_state_dict(other.state_dict())
+    torch.testing.assert_close(mlp.folded()[0], other.folded()[0])
+    torch.testing.assert_close(forward_pm.folded(mlp)[0], forward_pm.folded(other)[0])
+    att = M.AttPooling(8, 4).eval()
+    w_a = forward_pm.fc_weight(att).clone()
+    att.load_state_dict(M.AttPooling(8, 4).state_dict())
+    assert not torch.equal(forward_pm.fc_weight(att), w_a)
+    blk = M.DilatedResBlock(8, 16).eval()
+    net_like = torch.nn.ModuleList([blk])
+    net_like.train()                                                # FFB6D.train() analogue is covered on the GPU
+    assert blk.training
+
+
+@pytest.mark.reference
+def test_patcher_swaps_the_real_reference_classes():
+    """patch_reference on the reference's own modules (models/ffb6d.py, models/RandLA/RandLANet.py): the five members
+    are ours afterwards, keep the reference's call signatures, and undo() restores the originals."""
+    import inspect
+    from ffb6d_amd import ops, patch
+    from oracle import ref_harness as rh
+    m_ffb6d, m_randla, _ = rh.reference_modules()
+    orig = {"rs": m_ffb6d.FFB6D.__dict__["random_sample"], "ni": m_ffb6d.FFB6D.__dict__["nearest_interpolation"],
+            "gn": m_randla.Building_block.__dict__["gather_neighbour"],
+            "rpe": m_randla.Building_block.__dict__["relative_pos_encoding"], "att": m_randla.Att_pooling.__dict__["forward"]}
+    sig = lambda f: list(inspect.signature(f).parameters)           # noqa: E731
+    want_sig = {"rs": sig(orig["rs"].__func__), "ni": sig(orig["ni"].__func__), "gn": sig(orig["gn"].__func__),
+                "rpe": sig(orig["rpe"]), "att": sig(orig["att"])}
+    undo = patch.patch_reference(m_ffb6d, m_randla)
+    try:
+        assert m_ffb6d.FFB6D.random_sample is ops.random_sample
+        assert m_ffb6d.FFB6D.nearest_interpolation is ops.nearest_interpolation
+        assert m_randla.Building_block.gather_neighbour is ops.gather_neighbour
+        assert m_randla.Building_block.relative_pos_encoding is patch._relative_pos_encoding
+        assert m_randla.Att_pooling.forward is patch._att_pooling_forward
+        if hasattr(m_randla, "Network"):
+            assert m_randla.Network.random_sample is ops.random_sample
+        got_sig = {"rs": sig(ops.random_sample), "ni": sig(ops.nearest_interpolation), "gn": sig(ops.gather_neighbour),
+                   "rpe": sig(patch._relative_pos_encoding), "att": sig(patch._att_pooling_forward)}
+        assert got_sig == want_sig
+        # an instance built after patching dispatches to our operators: on CPU tensors they refuse loudly
+        from ffb6d_amd import _lib
+        with pytest.raises(_lib.FFB6DNativeError):
+            m_ffb6d.FFB6D.random_sample(torch.zeros(1, 4, 10, 1), torch.zeros(1, 3, 16, dtype=torch.int64))
+    finally:
+        undo()
+    assert m_ffb6d.FFB6D.__dict__["random_sample"] is orig["rs"]
+    assert m_randla.Att_pooling.__dict__["forward"] is orig["att"]
 
 
 def test_patcher_swaps_reference_operators():

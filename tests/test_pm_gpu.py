@@ -1,0 +1,191 @@
+"""GPU parity of the point-major / pixel-major ("channels last") inference operators (ffb6d_amd/ops_pm.py,
+csrc/mlp_pm.hip ...) against float64 / plain-torch references of the same mathematics.  GEMM bar: 1e-5
+(north_star: pooled features within 1e-5 fp32); gathers and max pooling: bit exact."""
+import pytest
+import torch
+
+from ffb6d_amd import ops, ops_pm
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x1, w, bias, act, x2=None, add=None, gather=None):
+    x = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+    y = x.double() @ w.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    if gather is not None:
+        Y, idx = gather
+        y = y + torch.gather(Y.double(), 1, idx.long().unsqueeze(2).expand(-1, -1, Y.shape[2]))
+    if add is not None:
+        y = y + add.double()
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = torch.nn.functional.leaky_relu(y, 0.2)
+    return y.float()
+
+
+# (B, P, K1, K2, Cout, act, py [>0 gather, <0 add], tile_hint)
+CASES = [
+    (2, 12288, 64, 64, 128, 1, 0, 0), (1, 4800, 1024, 0, 1024, 1, 48, 0), (2, 4800, 128, 0, 64, 1, 768, 0),
+    (8, 48, 1024, 0, 512, 1, 0, 0), (8, 192, 512, 256, 256, 2, 0, 0), (8, 192, 256, 0, 256, 1, 48, 0),
+    (1, 12288, 128, 0, 22, 0, 0, 0), (1, 12288, 128, 0, 3, 0, 0, 0), (3, 301, 24, 8, 37, 1, 13, 0),
+    (2, 130, 128, 0, 128, 2, 0, 0), (1, 196608, 16, 0, 16, 2, 0, 0), (2, 3072, 32, 16, 64, 2, 0, 0),
+    (1, 4800, 512, 0, 1024, 1, -1, 0), (1, 1, 8, 0, 8, 0, 0, 0), (1, 33, 8, 8, 5, 1, 0, 0),
+    (2, 1000, 64, 0, 136, 1, 7, 0),
+] + [(2, 777, 40, 24, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)] + [(1, 4100, 256, 0, 200, 1, -1, h) for h in (1, 2, 3, 4, 5)]
+
+
+@pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", CASES)
+def test_mlp_pm_matches_fp64_reference(device, B, P, K1, K2, Cout, act, py, hint):
+    g = torch.Generator().manual_seed(K1 + Cout + P)
+    x1 = torch.randn(B, P, K1, generator=g)
+    x2 = torch.randn(B, P, K2, generator=g) if K2 else None
+    w = torch.randn(Cout, K1 + K2, generator=g) / (K1 + K2) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    gather = (torch.randn(B, py, Cout, generator=g), torch.randint(0, py, (B, P), generator=g)) if py > 0 else None
+    add = torch.randn(B, P, Cout, generator=g) if py < 0 else None
+    want = _ref(x1, w, bias, act, x2, add, gather)
+    d = lambda t: None if t is None else t.to(device)
+    got = ops_pm.mlp(d(x1), d(w), d(bias), act, x2=d(x2), add=d(add),
+                     gather=None if gather is None else (d(gather[0]), d(gather[1])), tile_hint=hint).cpu()
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_mlp_pm_channel_slices_and_int32_indices(device):
+    """Operands / outputs that are channel slices of wider row buffers (row stride > row length), int32 gather
+    indices, no bias: what the fused forward feeds it (cat buffers are written in place, never copied)."""
+    g = torch.Generator().manual_seed(3)
+    B, P, py = 2, 500, 60
+    wide = torch.randn(B, P, 96, generator=g).to(device)
+    x1, x2 = wide[..., :32], wide[..., 64:88]
+    w = (torch.randn(48, 56, generator=g) / 7).to(device)
+    Y = torch.randn(B, py, 48, generator=g).to(device)
+    idx = torch.randint(0, py, (B, P), generator=g).to(device)
+    out_wide = torch.full((B, P, 80), float("nan"), device=device)
+    got = ops_pm.mlp(x1, w, None, ops.ACT_LEAKY, x2=x2, gather=(Y, idx.int()), out=out_wide[..., 16:64])
+    want = _ref(x1.cpu(), w.cpu(), None, 2, x2.cpu(), None, (Y.cpu(), idx.cpu()))
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+    assert torch.isnan(out_wide[..., :16]).all() and torch.isnan(out_wide[..., 64:]).all()   # neighbours untouched
+
+
+def test_mlp_pm_rejects_what_it_cannot_do(device):
+    from ffb6d_amd import _lib
+    x = torch.randn(1, 10, 12, device=device)
+    with pytest.raises(_lib.FFB6DNativeError):       # K not a multiple of 8
+        ops_pm.mlp(x, torch.randn(4, 12, device=device))
+    with pytest.raises(_lib.FFB6DNativeError):       # CPU tensor: no fallback
+        ops_pm.mlp(x.cpu(), torch.randn(4, 12))
+
+
+def test_mlp_pm_operand_gather_and_log_softmax(device):
+    """`choose` pick fused into the head GEMM (x1 rows gathered by index, ffb6d.py:309-312) and the colour branch's
+    `final` 1x1 conv + LogSoftmax as one launch (pspnet.py:108-112)."""
+    g = torch.Generator().manual_seed(5)
+    B, M, P = 2, 700, 333
+    img = torch.randn(B, M, 64, generator=g)
+    pts = torch.randn(B, P, 64, generator=g)
+    choose = torch.randint(0, M, (B, P), generator=g)
+    w = torch.randn(128, 128, generator=g) / 11
+    bias = torch.randn(128, generator=g)
+    picked = torch.gather(img, 1, choose.unsqueeze(2).expand(-1, -1, 64))
+    want = _ref(picked, w, bias, 1, pts)
+    for dt in (torch.int64, torch.int32):
+        got = ops_pm.mlp(img.to(device), w.to(device), bias.to(device), ops.ACT_RELU, x2=pts.to(device),
+                         x1_gather=choose.to(device).to(dt)).cpu()
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    for C in (64, 32, 16, 40):
+        x = torch.randn(3, 50, 7, 64, generator=g)
+        wf = torch.randn(C, 64, generator=g) / 8
+        bf = torch.randn(C, generator=g)
+        want = torch.log_softmax((x.double() @ wf.double().t() + bf.double()), dim=-1).float()
+        got = ops_pm.mlp(x.to(device), wf.to(device), bf.to(device), ops_pm.ACT_LOG_SOFTMAX).cpu()
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,M,C,Np,K,dt", [(2, 3072, 64, 768, 16, torch.int64), (1, 19200, 64, 3072, 16, torch.int32),
+                                           (3, 192, 512, 48, 16, torch.int64), (2, 100, 8, 37, 5, torch.int64),
+                                           (1, 4800, 1024, 48, 16, torch.int32)])
+def test_random_sample_and_gather_rows_pm_are_bit_exact(device, B, M, C, Np, K, dt):
+    g = torch.Generator().manual_seed(M + C)
+    f = torch.randn(B, M, C, generator=g)
+    idx = torch.randint(0, M, (B, Np, K), generator=g)
+    want = torch.gather(f, 1, idx.reshape(B, -1, 1).expand(-1, -1, C)).view(B, Np, K, C).max(dim=2).values
+    got = ops_pm.random_sample(f.to(device), idx.to(device).to(dt)).cpu()
+    assert torch.equal(got, want)
+    up = torch.randint(0, M, (B, 4 * Np + 3), generator=g)
+    want = torch.gather(f, 1, up.unsqueeze(2).expand(-1, -1, C))
+    assert torch.equal(ops_pm.gather_rows(f.to(device), up.to(device).to(dt)).cpu(), want)
+
+
+def test_random_sample_pm_propagates_nan_like_torch_max(device):
+    f = torch.zeros(1, 20, 4)
+    f[0, 7, 2] = float("nan")
+    idx = torch.arange(16).view(1, 1, 16).repeat(1, 2, 1)
+    idx[0, 1] += 4                                    # second point's neighbourhood: 4..19 (also holds row 7)
+    got = ops_pm.random_sample(f.to(device), idx.to(device)).cpu()
+    assert torch.isnan(got[0, :, 2]).all() and (got[0, :, [0, 1, 3]] == 0).all()
+
+
+def test_relative_pos_encoding_pm_matches_reference_formula(device):
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(1)
+    xyz = torch.rand(2, 500, 3, generator=g)
+    nei = torch.randint(0, 500, (2, 500, 16), generator=g)
+    want = ops_ref.relative_pos_encoding(xyz, nei)                       # [B,N,K,10], RandLANet.py:216-223
+    got = ops_pm.relative_pos_encoding(xyz.to(device), nei.to(device)).cpu()
+    assert got.shape == (2, 500, 16, 16) and (got[..., 10:] == 0).all()
+    assert torch.equal(got[..., 1:10], want[..., 1:])
+    torch.testing.assert_close(got[..., 0], want[..., 0], rtol=2e-7, atol=0)     # sqrt: <= 1 ulp vs torch CPU
+
+
+def test_colour_branch_glue_pm_matches_torch(device):
+    g = torch.Generator().manual_seed(2)
+    F = torch.nn.functional
+    x = torch.randn(2, 12, 16, 64, generator=g)                                # [B,H,W,C]
+    sc, sh, rs, rb = (torch.randn(64, generator=g) for _ in range(4))
+    res = torch.randn(2, 12, 16, 64, generator=g)
+    d = lambda t: t.to(device)
+    want = F.leaky_relu(x * sc + sh + res * rs + rb, 0.25)
+    got = ops_pm.affine_act_(d(x).clone(), d(sc), d(sh), ops.ACT_LEAKY, 0.25, residual=d(res), res_affine=(d(rs), d(rb))).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    want = torch.relu(x * sc + sh + res)
+    got = ops_pm.affine_act_(d(x).clone(), d(sc), d(sh), ops.ACT_RELU, residual=d(res)).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    for size, ac in (((24, 32), True), ((30, 41), False), ((12, 16), False)):
+        want = F.interpolate(x.permute(0, 3, 1, 2), size=size, mode="bilinear", align_corners=ac).permute(0, 2, 3, 1)
+        got = ops_pm.bilinear_resize(d(x), size, ac).cpu()
+        torch.testing.assert_close(got, want.contiguous(), rtol=1e-5, atol=1e-5)
+    sizes = (1, 2, 3, 6)
+    xx = torch.randn(2, 60, 80, 32, generator=g)
+    want = torch.cat([F.adaptive_avg_pool2d(xx.permute(0, 3, 1, 2), s).flatten(2) for s in sizes], dim=2).transpose(1, 2)
+    got = ops_pm.psp_pool(d(xx), sizes).cpu()
+    torch.testing.assert_close(got, want.contiguous(), rtol=1e-5, atol=1e-5)
+    z = torch.randn(2, 50, 16, generator=g)
+    want, off = 0, 0
+    for s in sizes:
+        lvl = z[:, off:off + s * s].transpose(1, 2).reshape(2, 16, s, s)
+        want = want + F.interpolate(lvl, size=(60, 80), mode="bilinear", align_corners=False)
+        off += s * s
+    got = ops_pm.psp_prior_sum(d(z), sizes, (60, 80)).cpu()
+    torch.testing.assert_close(got, want.permute(0, 2, 3, 1).contiguous(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,C1,C2,dt", [(2, 1000, 16, 16, torch.int64), (1, 777, 32, 32, torch.int32), (2, 192, 64, 64, torch.int64),
+                                          (3, 48, 128, 128, torch.int64), (1, 50, 24, 8, torch.int64), (1, 3, 16, 48, torch.int32)])
+def test_att_pool_pm_matches_fp64_reference(device, B, N, C1, C2, dt):
+    """Attentive pooling with the neighbour gather and the score GEMM fused (RandLANet.py:243-248):
+    sum_k S * softmax_k(fc(S)), S = cat(gather(f), g)."""
+    g = torch.Generator().manual_seed(N + C1)
+    f = torch.randn(B, N, C1, generator=g)
+    nei = torch.randint(0, N, (B, N, 16), generator=g)
+    pair = torch.randn(B, N, 16, C2, generator=g)
+    d_ = C1 + C2
+    w = torch.randn(d_, d_, generator=g) / d_ ** 0.5 * 3
+    S = torch.cat([torch.gather(f, 1, nei.reshape(B, -1, 1).expand(-1, -1, C1)).view(B, N, 16, C1), pair], dim=3).double()
+    scores = torch.softmax(S @ w.double().t(), dim=2)
+    want = (S * scores).sum(dim=2).float()
+    got = ops_pm.att_pool(f.to(device), nei.to(device).to(dt), pair.to(device), w.to(device)).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
