@@ -48,7 +48,8 @@ SIGNATURES = {
     "ffb6d_relative_pos_encoding_pm_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_affine_act_pm_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _c.c_float, _vp]),
     "ffb6d_bilinear_resize_pm_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
-    "ffb6d_psp_pool_pm_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "ffb6d_psp_pool_pm_workspace_bytes": (_sz, [_i64, _i64, _i64, _vp, _i32]),
+    "ffb6d_psp_pool_pm_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp]),
     "ffb6d_psp_prior_sum_pm_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp]),
     "ffb6d_att_score_pool_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_shared_mlp_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),

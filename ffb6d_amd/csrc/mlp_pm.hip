@@ -63,11 +63,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // KSPLIT: the four waves of the workgroup share ONE TM x TN tile and each take a quarter of K (partial sums meet
 // in LDS) -- for the deep layers, where a frame has a few hundred points and K up to 1024: without it a handful of
 // workgroups would each walk the whole K.
+// (Measured and dropped: 128 x 64 / 64 x 128 tiles per wave, and stages of 32 k = one whole 128-byte line per row and lane
+// pair -- all within +-5 % of this form on the MFMA-bound layers, profiles/r02_mlp_pm_tiles.txt.)
 template <int TM, int TN, int WM, int WN, bool KSPLIT>
 __global__ void __launch_bounds__(BLK)
 mlp_pm_kernel(const PmParams p)
 {
     static_assert(WM * WN == 4, "four waves");
+    constexpr int KW = 1;                               // float4 per lane, row and stage
     constexpr int BC = 32 * TM * (KSPLIT ? 1 : WM);     // channels per workgroup
     constexpr int BP = 32 * TN * (KSPLIT ? 1 : WN);     // points per workgroup
 
@@ -94,7 +97,7 @@ mlp_pm_kernel(const PmParams p)
     // per-lane byte offsets of this lane's rows (k = 0); rows past the end are out of range -> zeros
     int w_vo[TM], x1_vo[TN], x2_vo[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) w_vo[i] = ((c0 + (wm * TM + i) * 32 + l31) * K + 4 * kh) * 4;
+    for (int i = 0; i < TM; ++i) w_vo[i] = ((c0 + (wm * TM + i) * 32 + l31) * K + 4 * KW * kh) * 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = r0 + (wn * TN + j) * 32 + l31;
@@ -105,11 +108,11 @@ mlp_pm_kernel(const PmParams p)
                 xr = (r / p.P) * p.px + (p.idx64 ? (int)static_cast<const long long*>(p.xidx)[r]
                                                  : static_cast<const int*>(p.xidx)[r]);
         }
-        x1_vo[j] = (xr * p.ld1 + 4 * kh) * 4;
-        x2_vo[j] = (r * p.ld2 + 4 * kh) * 4;
+        x1_vo[j] = (xr * p.ld1 + 4 * KW * kh) * 4;
+        x2_vo[j] = (r * p.ld2 + 4 * KW * kh) * 4;
     }
 
-    const int n1 = p.k1 >> 3, nsteps = K >> 3;            // k-steps of 8 (k1, k2 multiples of 8)
+    const int n1 = p.k1 / (8 * KW), nsteps = K / (8 * KW);    // k-steps of 8 * KW (k1, k2 multiples of that)
     // this wave's step range
     int s_beg = 0, s_end = nsteps;
     if (KSPLIT) {
@@ -126,49 +129,58 @@ mlp_pm_kernel(const PmParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // three register stages; a stage = 8 k of every row of the wave's tile.  The k offset travels in the per-lane
-    // offset (the scalar offset of a buffer load is not range checked): a surplus prefetch past the last step reads
-    // the following floats of the row buffer or, past its end, zeros -- never used either way.
-    u32x4 wa0[TM], wa1[TM], wa2[TM], xb0[TN], xb1[TN], xb2[TN];
-    auto load = [&](int step, u32x4 (&wa)[TM], u32x4 (&xb)[TN]) {
+    // register stages; a stage = 8 * KW k of every row of the wave's tile: lane (row, kh) holds k0 + 4*KW*kh .. + 4*KW - 1 and
+    // MFMA step t pairs k0 + t with k0 + 4*KW + t.  The k offset travels in the per-lane offset (the scalar offset of a
+    // buffer load is not range checked): a surplus prefetch past the last step reads the following floats of the row buffer
+    // or, past its end, zeros -- never used either way.
+    u32x4 wa0[TM][KW], wa1[TM][KW], wa2[TM][KW], xb0[TN][KW], xb1[TN][KW], xb2[TN][KW];
+    auto load = [&](int step, u32x4 (&wa)[TM][KW], u32x4 (&xb)[TN][KW]) {
         const bool second = step >= n1;
         const __amdgpu_buffer_rsrc_t rx = second ? rs_x2 : rs_x1;
-        const int wko = step * 32;                                  // bytes: 8 floats per step
-        const int xko = (second ? step - n1 : step) * 32;
+        const int wko = step * 32 * KW;                              // bytes
+        const int xko = (second ? step - n1 : step) * 32 * KW;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) wa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[i] + wko, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int u = 0; u < KW; ++u) wa[i][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[i] + wko + 16 * u, 0, 0);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (second ? x2_vo[j] : x1_vo[j]) + xko, 0, 0);
+#pragma unroll
+            for (int u = 0; u < KW; ++u)
+                xb[j][u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (second ? x2_vo[j] : x1_vo[j]) + xko + 16 * u, 0, 0);
     };
-    auto compute = [&](const u32x4 (&wa)[TM], const u32x4 (&xb)[TN]) {
+    auto compute = [&](const u32x4 (&wa)[TM][KW], const u32x4 (&xb)[TN][KW]) {
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int u = 0; u < KW; ++u)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wa[i][tt]), __uint_as_float(xb[j][tt]),
-                                                                     acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wa[i][u][tt]), __uint_as_float(xb[j][u][tt]),
+                                                                         acc[i][j], 0, 0, 0);
     };
 
-    int st = s_beg;
-    load(st, wa0, xb0);
-    load(st + 1, wa1, xb1);
-    // one basic block per iteration: the loads of step s+2 fly under the MFMAs of steps s and s+1.  sched_barrier pins
+    // one basic block per iteration: the loads of the next stages fly under the MFMAs of the current one.  sched_barrier pins
     // the issue order (hipcc otherwise sinks the loads below the MFMA groups and every iteration starts by draining them).
 #define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
-    for (; st + 3 <= s_end; st += 3) {
-        load(st + 2, wa2, xb2); FFB6D_PIN();
-        compute(wa0, xb0);      FFB6D_PIN();
-        load(st + 3, wa0, xb0); FFB6D_PIN();
-        compute(wa1, xb1);      FFB6D_PIN();
-        load(st + 4, wa1, xb1); FFB6D_PIN();
-        compute(wa2, xb2);      FFB6D_PIN();
+    int st = s_beg;
+    if constexpr (KW == 1) {
+        load(st, wa0, xb0);
+        load(st + 1, wa1, xb1);
+        for (; st + 3 <= s_end; st += 3) {
+            load(st + 2, wa2, xb2); FFB6D_PIN();
+            compute(wa0, xb0);      FFB6D_PIN();
+            load(st + 3, wa0, xb0); FFB6D_PIN();
+            compute(wa1, xb1);      FFB6D_PIN();
+            load(st + 4, wa1, xb1); FFB6D_PIN();
+            compute(wa2, xb2);      FFB6D_PIN();
+        }
+        if (st < s_end) compute(wa0, xb0);
+        if (st + 1 < s_end) compute(wa1, xb1);
     }
 #undef FFB6D_PIN
-    if (st < s_end) compute(wa0, xb0);
-    if (st + 1 < s_end) compute(wa1, xb1);
 
     if constexpr (KSPLIT) {
         // partial sums of waves 1..3 -> LDS (lane-contiguous), wave 0 adds them and runs the epilogue

@@ -165,35 +165,36 @@ __device__ __forceinline__ float src_index(float scale, int dst, bool align_corn
     return s < 0.f ? 0.f : s;
 }
 
+// blockIdx.y = output row (b, oy): the two source rows and the vertical weights are wave-uniform scalars;
+// blockIdx.x * 256 + thread = (output column, channel quad) of that row, one float4 per thread
 __global__ void __launch_bounds__(BLK)
-bilinear_pm_kernel(const float4* __restrict__ in, float4* __restrict__ out, int IH, int IW, int OH, int OW, int q, float rh,
-                   float rw, int align_corners, size_t total /* B*OH*OW*q */)
+bilinear_pm_kernel(const float4* __restrict__ in, float4* __restrict__ out, int IH, int IW, int OH, int OW, int q, int qshift,
+                   float rh, float rw, int align_corners)
 {
-    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
-    if (t >= total) return;
-    const size_t pix = t / q;
-    const int c4 = (int)(t - pix * q);
-    const int ox = (int)(pix % OW);
-    const size_t row = pix / OW;
-    const int oy = (int)(row % OH);
-    const size_t b = row / OH;
+    const int row = blockIdx.y;                  // b*OH + oy
+    const int oy = row % OH, b = row / OH;
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    if (t >= OW * q) return;
     const float h1r = src_index(rh, oy, align_corners);
     const int h1 = (int)h1r;
     const int h1p = (h1 < IH - 1) ? 1 : 0;
     const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const float4* r0 = in + ((size_t)b * IH + h1) * IW * q;
+    const float4* r1 = r0 + (size_t)h1p * IW * q;
+    const int ox = qshift >= 0 ? (t >> qshift) : t / q;
+    const int c4 = t - ox * q;
     const float w1r = src_index(rw, ox, align_corners);
     const int w1 = (int)w1r;
     const int w1p = (w1 < IW - 1) ? 1 : 0;
     const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-    const float4* r0 = in + ((b * IH + h1) * (size_t)IW + w1) * q + c4;
-    const float4* r1 = r0 + (size_t)h1p * IW * q;
-    const float4 a = r0[0], bq = r0[(size_t)w1p * q], c = r1[0], d = r1[(size_t)w1p * q];
-    float4 o;
-    o.x = h0l * (w0l * a.x + w1l * bq.x) + h1l * (w0l * c.x + w1l * d.x);
-    o.y = h0l * (w0l * a.y + w1l * bq.y) + h1l * (w0l * c.y + w1l * d.y);
-    o.z = h0l * (w0l * a.z + w1l * bq.z) + h1l * (w0l * c.z + w1l * d.z);
-    o.w = h0l * (w0l * a.w + w1l * bq.w) + h1l * (w0l * c.w + w1l * d.w);
-    out[t] = o;
+    const int i0 = w1 * q + c4, i1 = i0 + w1p * q;
+    const float4 a = r0[i0], bq = r0[i1], c = r1[i0], d = r1[i1];
+    float4 v;
+    v.x = h0l * (w0l * a.x + w1l * bq.x) + h1l * (w0l * c.x + w1l * d.x);
+    v.y = h0l * (w0l * a.y + w1l * bq.y) + h1l * (w0l * c.y + w1l * d.y);
+    v.z = h0l * (w0l * a.z + w1l * bq.z) + h1l * (w0l * c.z + w1l * d.z);
+    v.w = h0l * (w0l * a.w + w1l * bq.w) + h1l * (w0l * c.w + w1l * d.w);
+    out[(size_t)row * OW * q + t] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -205,38 +206,56 @@ bilinear_pm_kernel(const float4* __restrict__ in, float4* __restrict__ out, int 
 constexpr int PSP_MAX = 4;
 struct PspSizes { int n; int s[PSP_MAX]; int off[PSP_MAX + 1]; };
 
-__global__ void __launch_bounds__(1024)
-psp_pool_pm_kernel(const float4* __restrict__ x, float4* __restrict__ out, int H, int W, int q, PspSizes sz)
+// Pass 1: a workgroup per (frame, image row) reads that row once and leaves, for every level, the row's partial sum of
+// each horizontal bin: part[b, y, xbin, :], xbin running over the sum(s) horizontal bins of all levels.  Pass 2: a
+// workgroup per (frame, bin) adds the rows of its vertical extent.  (One workgroup per bin cannot pull the 1x1 level's
+// 10 MB through a single CU in reasonable time; this way the map is streamed once by H*B workgroups.)
+__global__ void __launch_bounds__(BLK)
+psp_rowsum_pm_kernel(const float4* __restrict__ x, float4* __restrict__ part, int H, int W, int q, int nx, PspSizes sz)
 {
-    extern __shared__ float4 part[];             // [groups][q]
+    const int by = blockIdx.x;                               // b*H + y
+    const float4* src = x + (size_t)by * W * q;
+    for (int c4 = threadIdx.x; c4 < q; c4 += BLK) {
+        int slot = 0;
+        for (int l = 0; l < sz.n; ++l) {
+            const int s = sz.s[l];
+            for (int j = 0; j < s; ++j, ++slot) {
+                const int x0 = (j * W) / s, x1 = ((j + 1) * W + s - 1) / s;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int xx = x0; xx < x1; xx += 8) {          // 8 independent loads in flight, surplus ones are dropped
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(xx + u, x1 - 1) * q + c4];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (xx + u < x1) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                }
+                part[((size_t)by * nx + slot) * q + c4] = acc;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BLK)
+psp_binsum_pm_kernel(const float4* __restrict__ part, float4* __restrict__ out, int H, int W, int q, int nx, PspSizes sz)
+{
     const int total = sz.off[sz.n];
     const int b = blockIdx.x / total, bin = blockIdx.x % total;
-    int lvl = 0;
-    while (bin >= sz.off[lvl + 1]) ++lvl;
+    int lvl = 0, xoff = 0;
+    while (bin >= sz.off[lvl + 1]) { xoff += sz.s[lvl]; ++lvl; }
     const int s = sz.s[lvl];
     const int by = (bin - sz.off[lvl]) / s, bxi = (bin - sz.off[lvl]) % s;
     // ATen adaptive pooling: start = floor(i*in/out), end = ceil((i+1)*in/out)
     const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s;
     const int x0 = (bxi * W) / s, x1 = ((bxi + 1) * W + s - 1) / s;
-    const int rw = x1 - x0, n = (y1 - y0) * rw;
-    const int groups = blockDim.x / q;
-    const int c4 = threadIdx.x % q, g = threadIdx.x / q;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g < groups) {
-        const float4* src = x + (size_t)b * H * W * q + c4;
-        for (int i = g; i < n; i += groups) {
-            const float4 v = src[((size_t)(y0 + i / rw) * W + x0 + i % rw) * q];
+    const float inv = (float)((y1 - y0) * (x1 - x0));
+    for (int c4 = threadIdx.x; c4 < q; c4 += BLK) {
+        const float4* src = part + ((size_t)b * H * nx + xoff + bxi) * q + c4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int y = y0; y < y1; ++y) {
+            const float4 v = src[(size_t)y * nx * q];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        part[g * q + c4] = acc;
-    }
-    __syncthreads();
-    if (g == 0) {
-        for (int o = 1; o < groups; ++o) {
-            const float4 v = part[o * q + c4];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-        const float inv = (float)n;
         out[((size_t)b * total + bin) * q + c4] = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
     }
 }
@@ -395,26 +414,47 @@ int ffb6d_bilinear_resize_pm_f32(const float* in, float* out, int64_t B, int64_t
         rh = (float)IH / (float)OH;
         rw = (float)IW / (float)OW;
     }
-    const size_t total = (size_t)B * OH * OW * (C / 4);
-    hipLaunchKernelGGL(bilinear_pm_kernel, dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, as_stream(stream),
-                       reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), (int)IH, (int)IW, (int)OH, (int)OW,
-                       (int)(C / 4), rh, rw, align_corners, total);
+    FFB6D_REQUIRE(B * OH < (1LL << 31) && OW * (C / 4) < (1LL << 31), "bilinear_resize_pm: too large");
+    const int q = (int)(C / 4);
+    int qshift = -1;
+    if ((q & (q - 1)) == 0) for (qshift = 0; (1 << qshift) < q; ++qshift) {}
+    FFB6D_REQUIRE(B * OH < 65536, "bilinear_resize_pm: B * OH must stay below 65536 (grid y)");
+    hipLaunchKernelGGL(bilinear_pm_kernel, dim3((unsigned)ceil_div(OW * (int64_t)q, BLK), (unsigned)(B * OH)), dim3(BLK), 0,
+                       as_stream(stream), reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), (int)IH, (int)IW,
+                       (int)OH, (int)OW, q, qshift, rh, rw, align_corners);
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
 
+size_t ffb6d_psp_pool_pm_workspace_bytes(int64_t B, int64_t H, int64_t C, const int* sizes, int nsizes)
+{
+    PspSizes sz;
+    if (fill_sizes(sz, sizes, nsizes) != 0 || B <= 0 || H <= 0 || C <= 0) return 0;
+    int nx = 0;
+    for (int i = 0; i < sz.n; ++i) nx += sz.s[i];
+    return (size_t)B * H * nx * C * sizeof(float);
+}
+
 int ffb6d_psp_pool_pm_f32(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, const int* sizes, int nsizes,
-                          ffb6d_stream_t stream)
+                          void* workspace, size_t workspace_bytes, ffb6d_stream_t stream)
 {
     PspSizes sz;
     FFB6D_REQUIRE(fill_sizes(sz, sizes, nsizes) == 0, "psp_pool_pm: 1..4 pool sizes in [1,64] expected");
-    FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && C >= 4 && (C & 3) == 0 && C <= 4096, "psp_pool_pm: bad shape");
+    FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && C >= 4 && (C & 3) == 0, "psp_pool_pm: bad shape");
     if (B == 0) return FFB6D_OK;
     FFB6D_REQUIRE(x && out && al16(x) && al16(out), "psp_pool_pm: null or unaligned pointer");
+    const size_t need = ffb6d_psp_pool_pm_workspace_bytes(B, H, C, sizes, nsizes);
+    if (!workspace || workspace_bytes < need || !al16(workspace))
+        return set_error(FFB6D_ERR_WORKSPACE, "psp_pool_pm: 16-byte aligned workspace of %zu bytes required, got %zu", need,
+                         workspace ? workspace_bytes : (size_t)0);
+    int nx = 0;
+    for (int i = 0; i < sz.n; ++i) nx += sz.s[i];
     const int q = (int)(C / 4);
-    const int threads = q >= 1024 ? 1024 : (1024 / q) * q;      // whole pixel groups of q lanes
-    hipLaunchKernelGGL(psp_pool_pm_kernel, dim3((unsigned)(B * sz.off[sz.n])), dim3(threads), (size_t)threads * sizeof(float4),
-                       as_stream(stream), reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), (int)H, (int)W, q, sz);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(psp_rowsum_pm_kernel, dim3((unsigned)(B * H)), dim3(BLK), 0, st, reinterpret_cast<const float4*>(x),
+                       static_cast<float4*>(workspace), (int)H, (int)W, q, nx, sz);
+    hipLaunchKernelGGL(psp_binsum_pm_kernel, dim3((unsigned)(B * sz.off[sz.n])), dim3(BLK), 0, st,
+                       static_cast<const float4*>(workspace), reinterpret_cast<float4*>(out), (int)H, (int)W, q, nx, sz);
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }

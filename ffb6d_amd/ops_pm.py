@@ -233,8 +233,12 @@ def psp_pool(x, sizes):
     B, H, W, C = xc.shape
     nb = sum(int(s) * int(s) for s in sizes)
     out = torch.empty((B, nb, C), dtype=torch.float32, device=x.device)
+    sz = _int_array(sizes)
+    wbytes = lib.ffb6d_psp_pool_pm_workspace_bytes(B, H, C, sz, len(sizes))
+    ws = torch.empty((wbytes,), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device), _lib.traced("psp_pool_pm", 4 * xc.numel() + 4 * out.numel(), (C, H * W)):
-        rc = lib.ffb6d_psp_pool_pm_f32(xc.data_ptr(), out.data_ptr(), B, H, W, C, _int_array(sizes), len(sizes), _stream(xc))
+        rc = lib.ffb6d_psp_pool_pm_f32(xc.data_ptr(), out.data_ptr(), B, H, W, C, sz, len(sizes), ws.data_ptr(), wbytes,
+                                       _stream(xc))
     _lib.check(rc, "ffb6d_psp_pool_pm_f32")
     return out
 

@@ -154,9 +154,11 @@ int ffb6d_affine_act_pm_f32(const float* x, const float* scale, const float* shi
 /* Bilinear resize [B,IH,IW,C] -> [B,OH,OW,C] (ATen upsample_bilinear2d arithmetic; pspnet.py:24-28,37-42). */
 int ffb6d_bilinear_resize_pm_f32(const float* in, float* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
                                  int64_t C, int align_corners, ffb6d_stream_t stream);
-/* All adaptive average pools of `sizes` of x [B,H,W,C] -> [B, sum(s*s), C] (bins of sizes[0] first, row-major in a level). */
+/* All adaptive average pools of `sizes` of x [B,H,W,C] -> [B, sum(s*s), C] (bins of sizes[0] first, row-major in a level).
+ * Two passes (row partial sums, then bins) through a workspace of ffb6d_psp_pool_pm_workspace_bytes(...) bytes. */
+size_t ffb6d_psp_pool_pm_workspace_bytes(int64_t B, int64_t H, int64_t C, const int* sizes, int nsizes);
 int ffb6d_psp_pool_pm_f32(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, const int* sizes,
-                          int nsizes, ffb6d_stream_t stream);
+                          int nsizes, void* workspace, size_t workspace_bytes, ffb6d_stream_t stream);
 /* out[b,y,x,:] = sum over levels of the bilinear (align_corners = 0) up-sampling of z [B, sum(s*s), M] to (H,W). */
 int ffb6d_psp_prior_sum_pm_f32(const float* z, float* out, int64_t B, int64_t H, int64_t W, int64_t M, const int* sizes,
                                int nsizes, ffb6d_stream_t stream);

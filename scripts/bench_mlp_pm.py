@@ -21,6 +21,8 @@ SHAPES = [("ds3 p2r_fuse 1024->1024 +gather", 1024, 0, 1024, 4800, 48), ("psp bo
           ("ds3 y 1024->1024 @48", 1024, 0, 1024, 48, 0), ("ds3 r2p_fuse [512;512]->512 @48", 512, 512, 512, 48, 0),
           ("res3 [256;256]->512 @192", 256, 256, 512, 192, 0), ("dec0 768->256 @192", 512, 256, 256, 192, 0)]
 hints = [int(h) for h in sys.argv[1:]] or [0]
+if os.environ.get("MLP_PM_BIG"):
+    SHAPES = SHAPES[:4] + SHAPES[8:10]
 
 
 def timeit(fn, n=10):

@@ -34,7 +34,8 @@ CASES = [
     (2, 130, 128, 0, 128, 2, 0, 0), (1, 196608, 16, 0, 16, 2, 0, 0), (2, 3072, 32, 16, 64, 2, 0, 0),
     (1, 4800, 512, 0, 1024, 1, -1, 0), (1, 1, 8, 0, 8, 0, 0, 0), (1, 33, 8, 8, 5, 1, 0, 0),
     (2, 1000, 64, 0, 136, 1, 7, 0),
-] + [(2, 777, 40, 24, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)] + [(1, 4100, 256, 0, 200, 1, -1, h) for h in (1, 2, 3, 4, 5)]
+]
+CASES += [(2, 777, 40, 24, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)] + [(1, 4100, 256, 0, 200, 1, -1, h) for h in (1, 2, 3, 4, 5)]
 
 
 @pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", CASES)
