@@ -58,6 +58,9 @@ def parse():
                     help="infer (default, the BASELINE metric): pyramid + forward, eval, no_grad.  train: BASELINE "
                          "config 3 shape -- pyramid + forward + backward + Adam step in train() mode, wrapped in "
                          "DistributedDataParallel (RCCL gradient all-reduce) when launched with more than one rank")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="train mode, >1 rank: torch.nn.SyncBatchNorm like the reference's apex SyncBN (train_lm.py:592); "
+                         "default = local BatchNorm statistics, gradients are the only collective (north_star)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, one GPU per rank) for real runs; gloo lets several ranks share one GPU "
                          "to exercise the multi-process path on a single-GPU box")
@@ -224,7 +227,7 @@ def main():
     opt = None
     if train:
         net.train()
-        ddp = distributed.wrap_ddp(net, dev) if world > 1 else net     # RCCL all-reduce of 33.85 M fp32 grads
+        ddp = distributed.wrap_ddp(net, dev, sync_bn=args.sync_bn) if world > 1 else net     # RCCL all-reduce of 33.85 M fp32 grads
         opt = torch.optim.Adam(net.parameters(), lr=1e-5)              # train_lm.py:596
     else:
         net.eval()
@@ -346,24 +349,33 @@ def main():
                 flat = pcols < 2048 and pcols % 4 == 0
                 tr.records.setdefault("shared_mlp<%d,%s>" % (bm, "flat" if flat else "frame"), []).append(rec)
             for rec in tr.records.pop("mlp_pm", []):
-                tr.records.setdefault("mlp_pm<%s>" % PM_TILES.get(rec[3][3], "?"), []).append(rec)
+                # the same instantiation serves layers on both sides of the ridge (157.3 TFLOP/s / 8 TB/s = 19.7 flop per
+                # byte): arithmetic intensity of a row = 2 K Cout flop over 4 (K + Cout) bytes
+                k, cout = rec[3][0], rec[3][1]
+                side = "mfma" if 2.0 * k * cout / (4.0 * (k + cout)) >= VALU_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"
+                tr.records.setdefault("mlp_pm<%s,%s>" % (PM_TILES.get(rec[3][3], "?"), side), []).append(rec)
 
         def is_gemm(name):
             return name.startswith(("shared_mlp", "mlp_pm", "att_pool_pm", "att_score_pool"))
+
+        def mfma_bound(name):
+            return is_gemm(name) and not name.endswith(",hbm>")
 
         def roofline_of(tr, op):
             summ = tr.summary().get(op)
             if not summ or not summ["launches"]:
                 return None
             sec = summ["total_ms"] * 1e-3
-            if is_gemm(op):
+            if mfma_bound(op):
                 flops = sum(gemm_flops(op, t, args.batch) for _, _, _, t in tr.records[op])
                 ach = flops / sec / 1e12
                 return {"bound": "mfma", "achieved": ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / VALU_PEAK_TFLOPS, "kernel": MLP_KERNEL_NAMES.get(op, op) + " (fp32 MFMA 32x32x2)",
+                        "frac": ach / VALU_PEAK_TFLOPS,
+                        "kernel": MLP_KERNEL_NAMES.get(op.replace(",mfma>", ">"), op) + " (fp32 MFMA 32x32x2)",
                         "launches": summ["launches"], "avg_launch_us": summ["avg_us"], "flops": flops, "bytes": summ["bytes"]}
             return {"bound": "hbm", "achieved": summ["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": summ["gbps"] / HBM_PEAK_GBS, "kernel": op, "launches": summ["launches"],
+                    "frac": summ["gbps"] / HBM_PEAK_GBS, "kernel": MLP_KERNEL_NAMES.get(op.replace(",hbm>", ">"), op),
+                    "launches": summ["launches"],
                     "avg_launch_us": summ["avg_us"], "flops": 0.0, "bytes": summ["bytes"]}
 
         split_mlp(tracer)
@@ -381,7 +393,8 @@ def main():
             if os.path.exists(pmc_file):      # HBM bytes per launch measured offline with rocprofv3 --pmc
                 with open(pmc_file) as fh:
                     table = json.load(fh)
-                    traffic = table.get(roof_op, table.get(roof_op.split("<")[0], {})).get("hbm_bytes_per_launch")
+                    key = roof_op.replace(",mfma>", ">").replace(",hbm>", ">")
+                    traffic = table.get(key, table.get(key.split("<")[0], {})).get("hbm_bytes_per_launch")
             roofline = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
                         "frac": r["frac"], "traffic": traffic, "kernel": r["kernel"],
                         "launches_per_step": r["launches"] / args.steps, "avg_launch_us": r["avg_launch_us"],
@@ -404,10 +417,29 @@ def main():
                 fl = sum(gemm_flops(k, t, args.batch) for _, _, _, t in tracer.records[k])
                 ops_table[k]["algorithmic_TFLOPs"] = fl / (summary[k]["total_ms"] * 1e-3) / 1e12
         if "knn" in summary:
-            # exact KNN is VALU/latency bound, not HBM bound: report brute-force-equivalent pairs/s
-            pairs = sum(tag[0] * tag[1] for _, _, _, tag in tracer.records["knn"]) * args.batch
+            # exact KNN is VALU/latency bound, not HBM bound: brute-force-equivalent pairs/s, and the pairs
+            # the pruned search really evaluated (device counter, one extra untimed pyramid) against the fp32 VALU roof
+            recs = tracer.records["knn"]
+            pairs = sum(tag[0] * tag[1] for _, _, _, tag in recs) * args.batch
             sec = summary["knn"]["total_ms"] * 1e-3
             ops_table["knn"]["bruteforce_equivalent_Gpairs_per_s"] = pairs / sec / 1e9
+            lib = _lib.load()
+            ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            _lib.check(lib.ffb6d_knn_set_pair_counter(ctr.data_ptr()), "ffb6d_knn_set_pair_counter")
+            pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
+            torch.cuda.synchronize()
+            _lib.check(lib.ffb6d_knn_set_pair_counter(None), "ffb6d_knn_set_pair_counter")
+            scanned = sum(tag[0] * tag[1] for _, _, _, tag in recs[:len(recs) // args.steps]
+                          if not lib.ffb6d_knn_uses_pruning(args.batch, tag[0], tag[1], tag[2])) * args.batch
+            evaluated = int(ctr.item()) + scanned
+            per_step_s = sec / args.steps
+            ops_table["knn"].update({
+                "evaluated_Mpairs_per_step": evaluated / 1e6,
+                "evaluated_fraction_of_bruteforce": evaluated / (pairs / args.steps),
+                "evaluated_Gpairs_per_s": evaluated / per_step_s / 1e9,
+                # 8 flop per pair (3 sub, 3 mul, 2 add) against the fp32 vector peak
+                "valu_frac_of_fp32_peak": evaluated * 8.0 / per_step_s / (VALU_PEAK_TFLOPS * 1e12)})
         line = {
             "metric": (METRIC.replace("12288", str(args.n_points)).replace("bs=8", "bs=%d" % args.batch)) if not train else
                       f"RGB-D frames/sec train step (fwd+bwd+Adam, 480x640, N={args.n_points}, bs={args.batch}/GPU)",
@@ -415,10 +447,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("FFB6D forward" if not train else "FFB6D training step (forward + backward + Adam, "
-                                    "train-mode BatchNorm, DDP gradient all-reduce when n_gpus > 1)") +
+                                    "train-mode BatchNorm with %s statistics, DDP gradient all-reduce when n_gpus > 1)" %
+                                    ("synchronised (SyncBatchNorm)" if args.sync_bn and world > 1 else "per-rank")) +
                                    " incl. on-device 22-call KNN index pyramid; "
                                    f"bs={args.batch}/GPU, N={args.n_points} pts, 480x640 RGB-D, "
-                                   f"{args.n_classes} classes, fp32, eval",
+                                   f"{args.n_classes} classes, fp32, {'train' if train else 'eval'}",
                        "baseline_config": args.config, "global_batch": args.batch * world, "n_points": args.n_points,
                        "index_dtype": args.index_dtype, "layout": args.layout,
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "

@@ -25,6 +25,7 @@ SIGNATURES = {
     "ffb6d_knn_prepare_workspace_bytes": (_sz, [_i64, _i64]),
     "ffb6d_knn_prepare": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp, _sz, _vp]),
     "ffb6d_knn_search_prepared": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ffb6d_knn_set_pair_counter": (_i32, [_vp]),
     "ffb6d_knn_uses_pruning": (_i32, [_i64, _i64, _i64, _i32]),
     "ffb6d_random_sample_f32": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_random_sample_bwd_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
@@ -59,6 +60,9 @@ SIGNATURES = {
     "ffb6d_psp_pool_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "ffb6d_psp_prior_sum_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "ffb6d_depth_to_cloud_f32": (_i32, [_vp, _vp, _c.c_float, _vp, _i64, _i64, _i64, _vp]),
+    "ffb6d_sample_points_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "ffb6d_sample_points_f32": (_i32, [_vp, _c.c_float, _vp, _vp, _i32, _vp, _c.c_uint64, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                       _i64, _vp, _sz, _vp]),
     "ffb6d_check_index_range": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     # include/ffb6d_pose.h
     "ffb6d_vote_sets_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _vp]),

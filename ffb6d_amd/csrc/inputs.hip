@@ -1,0 +1,153 @@
+// ffb6d_amd/csrc/inputs.hip -- on-device input pipeline in front of the index pyramid:
+// valid-pixel sampling and point assembly of the reference's Dataset.get_item
+//   ffb6d/datasets/linemod/linemod_dataset.py:262-289 (same block: datasets/ycb/ycb_dataset.py:217-245)
+//       choose   = indices of pixels with depth > 1e-6
+//       more than N valid: a uniformly random N-subset (shuffled 0/1 mask), fewer: np.pad(..., 'wrap')
+//       then a uniformly random order (np.random.shuffle)
+//       cld / rgb_pt / nrm_pt = per-point rows of the xyz, colour and normal images; cld_rgb_nrm = their concatenation
+//
+// Here, without any host round trip (the reference's nonzero / shuffle run in numpy inside DataLoader workers):
+//   1. every pixel gets a 64-bit sort key  frame << 32 | (valid ? hash32(seed, frame, pixel) : 0xffffffff);
+//   2. ONE radix sort over all frames (rocprim) puts each frame's valid pixels first, in uniformly random order;
+//   3. the first N entries of a frame's segment are the sample: a uniformly random N-subset in uniformly random order.
+//      A frame with fewer than N valid pixels repeats its permutation cyclically (the reference repeats the ascending
+//      list and shuffles afterwards: same multiset up to which pixels get the extra copy, and the prefix of any length --
+//      what the index pyramid's "random" sub-sampling takes, linemod_dataset.py:322-323 -- is a random subset either way);
+//   4. one gather kernel writes choose, the point cloud [B,N,3] and cld_rgb_nrm [B,9,N].
+// Distribution-equivalent to the reference, not bit-identical (the reference draws from numpy's global generator).
+#include "common.h"
+#include "ffb6d_ops.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace ffb6d {
+namespace {
+
+constexpr int BLK = 256;
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x)     // murmur3 finaliser: bijective 32-bit mixing
+{
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+
+__global__ void __launch_bounds__(BLK)
+sample_keys_kernel(const float* __restrict__ depth, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+                   int32_t* __restrict__ n_valid, int HW, float min_depth, uint32_t seed_lo, uint32_t seed_hi)
+{
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * BLK + threadIdx.x;
+    bool valid = false;
+    if (pix < HW) {
+        valid = depth[(size_t)b * HW + pix] > min_depth;           // NaN compares false: invalid
+        const uint32_t h = mix32(mix32((uint32_t)pix ^ seed_lo) + 0x9e3779b9u * (uint32_t)(b + 1) + seed_hi);
+        // valid keys stay below 0xffffffff so that every invalid pixel sorts behind every valid one
+        const uint32_t k = valid ? (h == 0xffffffffu ? 0xfffffffeu : h) : 0xffffffffu;
+        keys[(size_t)b * HW + pix] = ((unsigned long long)b << 32) | k;
+        vals[(size_t)b * HW + pix] = (uint32_t)pix;
+    }
+    const unsigned long long ball = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && ball) atomicAdd(n_valid + b, (int)__popcll(ball));
+}
+
+// choose[b,j] = sorted pixel (j mod n_valid[b]); cld [B,N,3] and cld_rgb_nrm [B,9,N] gathered from the images
+template <typename RgbT>
+__global__ void __launch_bounds__(BLK)
+assemble_points_kernel(const uint32_t* __restrict__ sorted, const int32_t* __restrict__ n_valid, const float* __restrict__ xyz,
+                       const RgbT* __restrict__ rgb, const float* __restrict__ nrm, long long* __restrict__ choose,
+                       float* __restrict__ cld, float* __restrict__ crn, int HW, int N)
+{
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * BLK + threadIdx.x;
+    if (j >= N) return;
+    const int nv = n_valid[b];
+    const uint32_t pix = nv > 0 ? sorted[(size_t)b * HW + (j % nv)] : 0u;
+    choose[(size_t)b * N + j] = (long long)pix;
+    if (!xyz) return;                         // indices only
+    const float* x = xyz + (size_t)b * 3 * HW + pix;
+    const RgbT* c = rgb + (size_t)b * 3 * HW + pix;
+    const float* n = nrm + (size_t)b * 3 * HW + pix;
+    float* o = crn + (size_t)b * 9 * N + j;
+    float* p = cld + ((size_t)b * N + j) * 3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = x[(size_t)a * HW];
+        p[a] = v;
+        o[(size_t)a * N] = v;
+        o[(size_t)(3 + a) * N] = (float)c[(size_t)a * HW];
+        o[(size_t)(6 + a) * N] = n[(size_t)a * HW];
+    }
+}
+
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct SampleLayout { size_t keys_in, keys_out, vals_in, vals_out, temp, temp_bytes, total; };
+
+SampleLayout sample_layout(int64_t B, int64_t HW)
+{
+    SampleLayout L;
+    const size_t n = (size_t)B * HW;
+    size_t off = 0;
+    L.keys_in = off; off += align256(n * 8);
+    L.keys_out = off; off += align256(n * 8);
+    L.vals_in = off; off += align256(n * 4);
+    L.vals_out = off; off += align256(n * 4);
+    size_t need = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, need, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
+                                    (uint32_t*)nullptr, n, 0u, 64u, (hipStream_t) nullptr);
+    L.temp = off; L.temp_bytes = align256(need + 256); off += L.temp_bytes;
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+using namespace ffb6d;
+
+extern "C" size_t ffb6d_sample_points_workspace_bytes(int64_t B, int64_t H, int64_t W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return sample_layout(B, H * W).total;
+}
+
+extern "C" int ffb6d_sample_points_f32(const float* depth, float min_depth, const float* xyz, const void* rgb, int rgb_is_u8,
+                                       const float* nrm, uint64_t seed, int64_t* choose, float* cld, float* cld_rgb_nrm,
+                                       int32_t* n_valid, int64_t B, int64_t H, int64_t W, int64_t N, void* workspace,
+                                       size_t workspace_bytes, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && N >= 1, "sample_points: bad shape");
+    FFB6D_REQUIRE(H * W < (1LL << 31) && B < 65536 && N < (1LL << 31), "sample_points: size too large");
+    if (B == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(depth && choose && n_valid, "sample_points: null pointer");
+    const bool gather = xyz || rgb || nrm || cld || cld_rgb_nrm;
+    FFB6D_REQUIRE(!gather || (xyz && rgb && nrm && cld && cld_rgb_nrm),
+                  "sample_points: the image sources and point outputs come together (or all NULL for indices only)");
+    const int64_t HW = H * W;
+    const SampleLayout L = sample_layout(B, HW);
+    if (!workspace || workspace_bytes < L.total)
+        return set_error(FFB6D_ERR_WORKSPACE, "sample_points: workspace of %zu bytes required, got %zu", L.total,
+                         workspace ? workspace_bytes : (size_t)0);
+    char* ws = static_cast<char*>(workspace);
+    auto* keys_in = reinterpret_cast<unsigned long long*>(ws + L.keys_in);
+    auto* keys_out = reinterpret_cast<unsigned long long*>(ws + L.keys_out);
+    auto* vals_in = reinterpret_cast<uint32_t*>(ws + L.vals_in);
+    auto* vals_out = reinterpret_cast<uint32_t*>(ws + L.vals_out);
+    hipStream_t st = as_stream(stream);
+    FFB6D_HIP_TRY(hipMemsetAsync(n_valid, 0, (size_t)B * sizeof(int32_t), st));
+    hipLaunchKernelGGL(sample_keys_kernel, dim3((unsigned)ceil_div(HW, BLK), (unsigned)B), dim3(BLK), 0, st, depth, keys_in, vals_in,
+                       n_valid, (int)HW, min_depth, (uint32_t)seed, (uint32_t)(seed >> 32));
+    unsigned end_bit = 32;
+    while ((1LL << (end_bit - 32)) < B) ++end_bit;
+    size_t have = L.temp_bytes;
+    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(ws + L.temp, have, keys_in, keys_out, vals_in, vals_out, (size_t)(B * HW), 0u, end_bit, st));
+    const dim3 grid((unsigned)ceil_div(N, BLK), (unsigned)B);
+    if (rgb_is_u8)
+        hipLaunchKernelGGL((assemble_points_kernel<uint8_t>), grid, dim3(BLK), 0, st, vals_out, n_valid, xyz,
+                           static_cast<const uint8_t*>(rgb), nrm, reinterpret_cast<long long*>(choose), cld, cld_rgb_nrm, (int)HW, (int)N);
+    else
+        hipLaunchKernelGGL((assemble_points_kernel<float>), grid, dim3(BLK), 0, st, vals_out, n_valid, xyz,
+                           static_cast<const float*>(rgb), nrm, reinterpret_cast<long long*>(choose), cld, cld_rgb_nrm, (int)HW, (int)N);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}

@@ -32,6 +32,21 @@
 namespace ffb6d {
 namespace {
 
+// Optional instrumentation (bench.py): when set, the search kernels add the number of point pairs whose distance they
+// actually evaluated to *g_pair_counter (one atomic per wave).  SURVEY.md section 8d asks for KNN as evaluated pairs/s
+// against the fp32 VALU roof; the pruned search evaluates a small, data-dependent fraction of the S x Q candidates.
+__device__ unsigned long long* g_pair_counter = nullptr;
+
+__device__ __forceinline__ void publish_pairs(unsigned int mine)
+{
+    unsigned long long* ctr = g_pair_counter;
+    if (!ctr) return;
+    unsigned long long v = mine;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(ctr, v);
+}
+
 constexpr int PT = 64;      // points per tile (one box per tile)
 constexpr int BLK = 256;
 constexpr int QCAP = 16;    // per-lane queue slots
@@ -371,6 +386,7 @@ knn_pruned_kernel(const float4* __restrict__ spts, const float4* __restrict__ bo
     // 1) seed: each lane scans the tile of its OWN query (per-lane addresses), which gives it a
     //    tight K-th distance before the wave-uniform sweep starts; otherwise a lane would meet
     //    ever closer tiles during the sweep and insert nearly every point of them.
+    unsigned int pairs = live ? PT : 0;      // evaluated distances of this lane (seed tile below)
     {
         const float4* tp = sp + (size_t)my_tile * PT;
 #pragma unroll 1
@@ -393,6 +409,7 @@ knn_pruned_kernel(const float4* __restrict__ spts, const float4* __restrict__ bo
         const float lb = box_bound(q.x, q.y, q.z, blo, bhi);
         const float limit = (t == my_tile) ? -1.0f : worst;   // own seed tile is already in the list
         if (!__any(lb <= limit)) return;
+        pairs += PT;                                     // every lane evaluates the whole tile
         __builtin_amdgcn_wave_barrier();
         tile[lane] = sp[(size_t)t * PT + lane];          // one coalesced 1 KiB load per wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -443,6 +460,7 @@ knn_pruned_kernel(const float4* __restrict__ spts, const float4* __restrict__ bo
         }
     }
     drain();
+    publish_pairs(pairs);
 
     if (live) {
         const size_t o = ((size_t)b * Q + q_orig) * (size_t)Kout;
@@ -538,8 +556,10 @@ knn_row16_kernel(const float4* __restrict__ spts, const float4* __restrict__ box
         worst = live ? __uint_as_float((uint32_t)(row_get(L, K - 1) >> 32)) : -1.0f;
     };
 
+    unsigned int pairs = 0;
     auto scan_tile = [&](int t) {                            // t row-uniform
         const float4* tp = sp + (size_t)t * PT;
+        pairs += PT / 16;
         float4 p[PT / 16];
 #pragma unroll
         for (int c = 0; c < PT / 16; ++c) p[c] = tp[c * 16 + r];   // 4 x 256 B per row, all in flight
@@ -605,6 +625,7 @@ knn_row16_kernel(const float4* __restrict__ spts, const float4* __restrict__ box
         }
     }
 
+    publish_pairs(pairs);
     if (live && r < Kout) {
         const size_t o = ((size_t)b * Q + q_orig) * (size_t)Kout + r;
         const uint32_t id = (uint32_t)L;
@@ -777,3 +798,9 @@ int ffb6d_knn_search_prepared(const void* prep_support, const void* prep_query, 
 }
 
 }  // extern "C"
+
+extern "C" int ffb6d_knn_set_pair_counter(unsigned long long* device_counter)
+{
+    FFB6D_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ffb6d::g_pair_counter), &device_counter, sizeof(device_counter)));
+    return FFB6D_OK;
+}

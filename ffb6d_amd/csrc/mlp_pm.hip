@@ -481,8 +481,8 @@ extern "C" int ffb6d_mlp_pm_tile(int64_t rows, int64_t cout, int64_t K, int act)
     const int64_t big = ceil_div(rows, 128) * ceil_div(cout, 128);
     const int64_t mid = ceil_div(rows, 256) * ceil_div(cout, 64);
     const int64_t small = ceil_div(rows, 64) * ceil_div(cout, 64);
+    if (cout > 32 && mid >= 384) return 2;            // 64 x 256 measured >= 128 x 128 on every large layer (profiles/r02_mlp_pm_tiles.txt)
     if (cout > 64 && big >= 384) return 1;
-    if (cout > 32 && cout <= 64 && mid >= 384) return 2;
     if (cout <= 32) return ceil_div(rows, 256) >= 256 ? 3 : 5;
     if (small >= 512 || K < 64) return 4;
     return 5;

@@ -92,9 +92,16 @@ def timed_steps(step, warmup, steps, group, sync=lambda: None):
     return group.max_over_ranks(elapsed)
 
 
-def wrap_ddp(model, device):
+def wrap_ddp(model, device, sync_bn=False):
     """DistributedDataParallel exactly as the reference sets it up (train_lm.py:625-628), with
-    RCCL-friendly defaults: gradients as bucket views, 25 MB buckets overlapped with backward."""
+    RCCL-friendly defaults: gradients as bucket views, 25 MB buckets overlapped with backward.
+
+    BatchNorm: the reference additionally converts every BatchNorm to apex SyncBatchNorm (train_lm.py:592), i.e. one
+    more all-reduce of the batch statistics per BN layer and direction (~150 small collectives per step).  BASELINE.json's
+    north_star asks for "RCCL all-reduce over xGMI for DDP gradients only", so the DEFAULT here is local statistics per
+    rank (8 frames per GPU); sync_bn=True swaps in torch.nn.SyncBatchNorm for recipe parity with the reference."""
     from torch.nn.parallel import DistributedDataParallel
+    if sync_bn:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     return DistributedDataParallel(model, device_ids=[device.index] if device.type == "cuda" else None,
                                    find_unused_parameters=True, gradient_as_bucket_view=True)

@@ -7,8 +7,9 @@ inputs, so a frame needs no host-side geometry at all.
                                                     'wrap' padding when fewer than N are valid)
     assemble_inputs  == cld / cld_rgb_nrm / choose + build_index_pyramid   linemod_dataset.py:284-353
 
-Sampling uses torch's generator instead of numpy's global RNG, so it is distribution-equivalent,
-not bit-identical, to the reference (any N-subset of the valid pixels in uniformly random order).
+Sampling hashes (seed, frame, pixel) into sort keys instead of drawing from numpy's global RNG, so it is
+distribution-equivalent, not bit-identical, to the reference (any N-subset of the valid pixels in uniformly random
+order); csrc/inputs.hip has the details.
 """
 import torch
 
@@ -41,44 +42,85 @@ def depth_to_cloud(depth, K, cam_scale=1.0):
     return out
 
 
-def sample_choose(depth, n_points, generator=None, min_points=400):
-    """Per frame: indices (into H*W) of `n_points` valid-depth pixels in uniformly random order;
-    frames with fewer valid pixels are padded by wrapping around (np.pad(..., 'wrap'),
-    linemod_dataset.py:276-277).  Returns int64 [B,1,n_points] (the model's `choose`).
-    Raises if a frame has fewer than `min_points` valid pixels (the reference skips such frames)."""
-    B = depth.shape[0]
-    flat = depth.reshape(B, -1)
-    out = torch.empty((B, 1, n_points), dtype=torch.int64, device=depth.device)
-    for b in range(B):
-        valid = torch.nonzero(flat[b] > 1e-6, as_tuple=False).squeeze(1)
-        n = valid.numel()
-        if n < min_points:
-            raise ValueError(f"frame {b}: only {n} valid depth pixels")
-        if n >= n_points:
-            pick = valid[torch.randperm(n, device=depth.device, generator=generator)[:n_points]]
+def _seed(seed, generator):
+    if seed is not None:
+        return int(seed) & 0xFFFFFFFFFFFFFFFF
+    # a draw from a CPU generator (torch's default one when none is given) never touches the device queue
+    return int(torch.randint(0, 2 ** 62, (1,), generator=generator,
+                             device=generator.device if generator is not None else "cpu").item())
+
+
+def sample_points(depth, n_points, dpt_xyz=None, rgb=None, normals=None, seed=None, generator=None, min_depth=1e-6):
+    """Valid-pixel sampling (+ point assembly) of Dataset.get_item, linemod_dataset.py:262-289, on the device and without a
+    host round trip: per frame a uniformly random `n_points`-subset of the pixels with depth > min_depth in uniformly random
+    order ('wrap'-style repetition when a frame has fewer valid pixels).  depth [B,H,W] float32.
+    Returns a dict: choose int64 [B,1,N] (the model's `choose`), n_valid int32 [B], and -- when dpt_xyz [B,3,H,W],
+    rgb [B,3,H,W] (uint8 or float32) and normals [B,3,H,W] are given -- cld [B,N,3] and cld_rgb_nrm [B,9,N]."""
+    if not depth.is_cuda:
+        raise _lib.FFB6DNativeError("sample_points needs GPU tensors (no CPU fallback)")
+    if depth.dim() != 3 or depth.dtype != torch.float32:
+        raise TypeError("depth must be float32 [B,H,W]")
+    lib = _lib.load()
+    d = depth.contiguous()
+    B, H, W = d.shape
+    N = int(n_points)
+    dev = d.device
+    out = {"choose": torch.empty((B, 1, N), dtype=torch.int64, device=dev),
+           "n_valid": torch.empty((B,), dtype=torch.int32, device=dev)}
+    gather = dpt_xyz is not None
+    xyz = rgb_c = nrm = None
+    is_u8 = 0
+    if gather:
+        if rgb is None or normals is None:
+            raise ValueError("dpt_xyz, rgb and normals come together")
+        xyz, nrm = dpt_xyz.contiguous(), normals.contiguous()
+        if rgb.dtype == torch.uint8:
+            rgb_c, is_u8 = rgb.contiguous(), 1
         else:
-            wrapped = valid[torch.arange(n_points, device=depth.device) % n]
-            pick = wrapped[torch.randperm(n_points, device=depth.device, generator=generator)]
-        out[b, 0] = pick
+            rgb_c = rgb.float().contiguous()
+        for t in (xyz, rgb_c, nrm):
+            if tuple(t.shape) != (B, 3, H, W):
+                raise ValueError(f"image sources must be [B,3,H,W] = {(B, 3, H, W)}, got {tuple(t.shape)}")
+        if xyz.dtype != torch.float32 or nrm.dtype != torch.float32:
+            raise TypeError("dpt_xyz and normals must be float32")
+        out["cld"] = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        out["cld_rgb_nrm"] = torch.empty((B, 9, N), dtype=torch.float32, device=dev)
+    wbytes = lib.ffb6d_sample_points_workspace_bytes(B, H, W)
+    ws = torch.empty((wbytes,), dtype=torch.uint8, device=dev)
+    ptr = lambda t: t.data_ptr() if t is not None else None       # noqa: E731
+    with torch.cuda.device(dev), _lib.traced("sample_points", 4 * d.numel() + 48 * B * N, (H, W, N)):
+        rc = lib.ffb6d_sample_points_f32(d.data_ptr(), float(min_depth), ptr(xyz), ptr(rgb_c), is_u8, ptr(nrm),
+                                         _seed(seed, generator), out["choose"].data_ptr(), ptr(out.get("cld")),
+                                         ptr(out.get("cld_rgb_nrm")), out["n_valid"].data_ptr(), B, H, W, N,
+                                         ws.data_ptr(), wbytes, torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "ffb6d_sample_points_f32")
     return out
 
 
-def assemble_inputs(rgb, depth, normals, K, n_points, cam_scale=1.0, generator=None, index_dtype=torch.int64):
+def sample_choose(depth, n_points, generator=None, min_points=400, seed=None):
+    """Per frame: indices (into H*W) of `n_points` valid-depth pixels in uniformly random order (see sample_points).
+    Returns int64 [B,1,n_points] (the model's `choose`).  Raises if a frame has fewer than `min_points` valid pixels (the
+    reference skips such frames, linemod_dataset.py:264-268); pass min_points=0 to skip that check and its host sync."""
+    res = sample_points(depth, n_points, seed=seed, generator=generator)
+    if min_points:
+        nv = res["n_valid"].cpu()
+        if int(nv.min()) < min_points:
+            raise ValueError(f"frame {int(nv.argmin())}: only {int(nv.min())} valid depth pixels")
+    return res["choose"]
+
+
+def assemble_inputs(rgb, depth, normals, K, n_points, cam_scale=1.0, generator=None, index_dtype=torch.int64, seed=None):
     """rgb [B,3,H,W] (uint8 or float), depth [B,H,W] f32, normals [B,3,H,W] f32, K intrinsics ->
-    the complete input dict of FFB6D.forward, everything computed on the device."""
+    the complete input dict of FFB6D.forward, everything computed on the device, no host synchronisation
+    (`n_valid` [B] is returned for the caller to drop frames with too few valid pixels)."""
     dpt_xyz = depth_to_cloud(depth, K, cam_scale)
-    choose = sample_choose(depth / cam_scale, n_points, generator)
-    B, _, H, W = dpt_xyz.shape
-    idx = choose.expand(B, 3, n_points)
-    cld_c = torch.gather(dpt_xyz.reshape(B, 3, H * W), 2, idx)                      # [B,3,N]
-    rgb_f = rgb.float()
-    rgb_pt = torch.gather(rgb_f.reshape(B, 3, H * W), 2, idx)
-    nrm_pt = torch.gather(normals.reshape(B, 3, H * W), 2, idx)
+    pts = sample_points(depth / cam_scale, n_points, dpt_xyz, rgb, normals, seed=seed, generator=generator)
     inputs = {
-        'rgb': rgb_f,
-        'cld_rgb_nrm': torch.cat([cld_c, rgb_pt, nrm_pt], dim=1).contiguous(),     # [B,9,N]
-        'choose': choose,
+        'rgb': rgb.float(),
+        'cld_rgb_nrm': pts["cld_rgb_nrm"],     # [B,9,N]
+        'choose': pts["choose"],
         'dpt_xyz': dpt_xyz,
+        'n_valid': pts["n_valid"],
     }
-    inputs.update(build_index_pyramid(cld_c.transpose(1, 2).contiguous(), dpt_xyz, index_dtype=index_dtype))
+    inputs.update(build_index_pyramid(pts["cld"], dpt_xyz, index_dtype=index_dtype))
     return inputs

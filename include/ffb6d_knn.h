@@ -121,6 +121,11 @@ int ffb6d_knn_search_prepared(const void* prepared_support, const void* prepared
                               const float* raw_query, int64_t batch_size, int64_t npts, int64_t nqueries,
                               int K, int64_t* idx64, int32_t* idx32, float* dist, ffb6d_stream_t stream);
 
+/* Instrumentation: while a device pointer to a zero-initialised 64-bit counter is set, every prepared-set search adds the
+ * number of (query, support) pairs whose distance it actually evaluated; NULL (the default) switches the counting off.
+ * Device-wide, not stream-ordered with respect to running kernels: set it between searches. */
+int ffb6d_knn_set_pair_counter(unsigned long long* device_counter);
+
 /* 1 when ffb6d_knn_batch_device would take the prepared/pruned route for this shape
  * (large support sets), 0 when it scans brute force. */
 int ffb6d_knn_uses_pruning(int64_t batch_size, int64_t npts, int64_t nqueries, int K);

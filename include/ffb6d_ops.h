@@ -109,6 +109,19 @@ int ffb6d_shared_mlp_f32(const float* wt, const float* bias, const float* x1, in
  * K loop is split across workgroups and reduced by a second kernel). */
 size_t ffb6d_shared_mlp_workspace_bytes(int64_t B, int64_t cout, int64_t K, int64_t P);
 
+/* Valid-pixel sampling + point assembly of Dataset.get_item (linemod_dataset.py:262-289) without a host round trip:
+ * per frame a uniformly random N-subset of the pixels with depth > min_depth in uniformly random order (fewer than N valid
+ * pixels: their random permutation repeated cyclically), from one batched radix sort of hashed keys.  depth [B,H,W];
+ * xyz [B,3,H,W] (ffb6d_depth_to_cloud_f32), rgb [B,3,H,W] uint8 (rgb_is_u8) or float32, nrm [B,3,H,W].  Outputs:
+ * choose [B,N] int64 (pixel index y*W+x), cld [B,N,3], cld_rgb_nrm [B,9,N] (ffb6d.py:222-224 input layout),
+ * n_valid [B] int32 (valid pixels per frame; the reference drops frames with fewer than 400).  seed: any 64-bit value.
+ * xyz, rgb, nrm, cld and cld_rgb_nrm may all be NULL: only choose and n_valid are produced then. */
+size_t ffb6d_sample_points_workspace_bytes(int64_t B, int64_t H, int64_t W);
+int ffb6d_sample_points_f32(const float* depth, float min_depth, const float* xyz, const void* rgb, int rgb_is_u8,
+                            const float* nrm, uint64_t seed, int64_t* choose, float* cld, float* cld_rgb_nrm,
+                            int32_t* n_valid, int64_t B, int64_t H, int64_t W, int64_t N, void* workspace,
+                            size_t workspace_bytes, ffb6d_stream_t stream);
+
 /* ==== point-major / pixel-major ("channels last") operators: one row of C contiguous floats per point or pixel ====
  * (csrc/mlp_pm.hip, csrc/ops_pm.hip).  Rows run over the points of ALL frames unless stated; row strides (ld*) are in floats. */
 

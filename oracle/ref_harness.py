@@ -216,3 +216,29 @@ def reference_pose_modules(mesh_kps=None, mesh_ctr=None, r_lst=None):
     if r_lst is not None:
         pose_mod.config.ycb_r_lst = list(np.asarray(r_lst, np.float64))
     return ms_mod, pose_mod
+
+
+def reference_dataset_class():
+    """The reference's LineMOD `Dataset` class (ffb6d/datasets/linemod/linemod_dataset.py:25) importable without its
+    third-party stack: `cv2`, `torchvision(.transforms)`, `termcolor`, `normalSpeed`, `plyfile` -> stub modules (none of
+    them is touched by the methods the tests call UNBOUND: `dpt_2_pcld`, :188-199).  Nothing in the reference is edited."""
+    install()
+    for name in ("cv2", "torchvision", "torchvision.transforms", "termcolor", "normalSpeed", "plyfile"):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.imshow = mod.waitKey = mod.colored = lambda *a, **k: None
+            mod.PlyData = object
+            sys.modules[name] = mod
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    # by file path: an installed `datasets` distribution (HuggingFace) shadows the reference's namespace package
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ffb6d_reference_linemod_dataset", os.path.join(REF_FFB6D, "datasets", "linemod", "linemod_dataset.py"))
+    lm = importlib.util.module_from_spec(spec)
+    cwd = os.getcwd()
+    os.chdir(REF_FFB6D)
+    try:
+        spec.loader.exec_module(lm)
+    finally:
+        os.chdir(cwd)
+    return lm.Dataset

@@ -42,8 +42,38 @@ def test_sample_choose_properties(device):
     few.view(-1)[:500] = 1.0
     ch = inputs.sample_choose(few, 1024)                          # wrap padding
     assert set(ch.unique().tolist()) == set(range(500))
+    counts = torch.bincount(ch.reshape(-1), minlength=500)
+    assert int(counts.min()) == 2 and int(counts.max()) == 3     # 1024 = 2 * 500 + 24: every pixel twice, 24 of them 3 times
     with pytest.raises(ValueError):
         inputs.sample_choose(torch.zeros(1, 60, 80, device=device), 128)
+
+
+def test_sample_points_is_a_uniform_subset_and_reproducible(device):
+    """Same seed -> same sample; different seeds -> different samples; every valid pixel is (about) equally likely to be
+    drawn and to land in the first quarter (the index pyramid's 'random' sub-sampling takes prefixes)."""
+    d = torch.from_numpy(np.stack([_depth(5), _depth(6)])).to(device)
+    d = torch.nan_to_num(d, nan=0.0, posinf=0.0)
+    a = inputs.sample_points(d, 2048, seed=11)
+    b = inputs.sample_points(d, 2048, seed=11)
+    c = inputs.sample_points(d, 2048, seed=12)
+    assert torch.equal(a["choose"], b["choose"]) and not torch.equal(a["choose"], c["choose"])
+    assert a["n_valid"].tolist() == [(d[i] > 1e-6).sum().item() for i in range(2)]
+    n_valid = int(a["n_valid"][0])
+    hits = torch.zeros(120 * 160, device=device)
+    first = torch.zeros(120 * 160, device=device)
+    trials = 300
+    for s in range(trials):
+        ch = inputs.sample_points(d[:1], 2048, seed=1000 + s)["choose"][0, 0]
+        hits[ch] += 1
+        first[ch[:512]] += 1
+    valid = d[0].reshape(-1) > 1e-6
+    assert float(hits[~valid].sum()) == 0
+    p = 2048 / n_valid                                               # inclusion probability of a valid pixel
+    mean = float(hits[valid].mean()) / trials
+    assert abs(mean - p) < 1e-6
+    sd = (p * (1 - p) / trials) ** 0.5
+    assert float((hits[valid] / trials - p).abs().max()) < 6 * sd    # no pixel is favoured
+    assert float((first[valid] / trials - p / 4).abs().max()) < 6 * (p / 4 * (1 - p / 4) / trials) ** 0.5
 
 
 def test_assemble_inputs_feeds_the_model(device):
@@ -55,7 +85,10 @@ def test_assemble_inputs_feeds_the_model(device):
     d = inputs.assemble_inputs(rgb, deps, nrm, synth.LINEMOD_K, 1024, cam_scale=1000.0)
     assert d['cld_rgb_nrm'].shape == (2, 9, 1024) and d['cld_xyz0'].shape == (2, 1024, 3)
     flat = d['dpt_xyz'].reshape(2, 3, -1)
-    assert torch.equal(d['cld_rgb_nrm'][:, :3], torch.gather(flat, 2, d['choose'].expand(2, 3, 1024)))
+    idx = d['choose'].expand(2, 3, 1024)
+    assert torch.equal(d['cld_rgb_nrm'][:, :3], torch.gather(flat, 2, idx))
+    assert torch.equal(d['cld_rgb_nrm'][:, 3:6], torch.gather(rgb.float().reshape(2, 3, -1), 2, idx))      # linemod_dataset.py:285
+    assert torch.equal(d['cld_rgb_nrm'][:, 6:9], torch.gather(nrm.reshape(2, 3, -1), 2, idx))
     assert torch.equal(d['cld_xyz0'], d['cld_rgb_nrm'][:, :3].transpose(1, 2))
     for k in ('cld_nei_idx0', 'r2p_ds_nei_idx3', 'p2r_up_nei_idx2'):
         assert k in d

@@ -138,6 +138,30 @@ def test_ops_ref_equals_reference_functions():
     assert torch.equal(ops_ref.relative_pos_encoding(xyz, nei), bb.relative_pos_encoding(xyz, nei))
 
 
+@pytest.mark.reference
+def test_inputs_ref_equals_the_reference_dpt_2_pcld():
+    """oracle/inputs_ref.dpt_2_pcld against the reference's own Dataset.dpt_2_pcld (linemod_dataset.py:188-199, called
+    unbound on an object that carries the two index maps its __init__ builds, :31-32) followed by the NaN/Inf clean-up
+    of get_item (:258-259): bit-identical, including invalid, NaN and Inf depth pixels and both intrinsics."""
+    import types
+    from oracle import inputs_ref
+    from oracle import ref_harness as rh
+    Dataset = rh.reference_dataset_class()
+    me = types.SimpleNamespace(xmap=np.array([[j for i in range(640)] for j in range(480)]),
+                               ymap=np.array([[i for i in range(640)] for j in range(480)]))
+    rng = np.random.RandomState(3)
+    dpt = (1000.0 * (0.5 + rng.rand(480, 640))).astype(np.float32)
+    dpt[rng.rand(480, 640) < 0.1] = 0.0
+    dpt[7, 9], dpt[8, 10] = np.nan, np.inf
+    for K, cam_scale in ((synth.LINEMOD_K, 1000.0), (np.array([[1066.778, 0., 312.9869], [0., 1067.487, 241.3109], [0., 0., 1.]]), 10000.0)):
+        want = Dataset.dpt_2_pcld(me, dpt.copy(), cam_scale, K)
+        want[np.isnan(want)] = 0.0
+        want[np.isinf(want)] = 0.0
+        got = inputs_ref.dpt_2_pcld(dpt.copy(), cam_scale, K)
+        assert got.dtype == want.dtype
+        np.testing.assert_array_equal(got, want)
+
+
 # ---- whole-forward restatement (oracle/forward_ref.py) against the reference's end_points ----
 def _oracle_forward(config, bs, n_points, h, w, n_classes):
     from oracle import forward_ref
