@@ -35,6 +35,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_TFLOPS = 157.3     # fp32 peak, vector FMA = f32-input MFMA (MI355X_MICROARCH.md)
+BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline figure is 2:1 sparse)
 METRIC = "RGB-D frames/sec fwd (480x640, N=12288, bs=8)"      # BASELINE.json; --config 4 reports N=24576 in its line
 
 
@@ -73,15 +74,19 @@ def parse():
     ap.add_argument("--layout", choices=["pm", "cm"], default="pm",
                     help="activation layout of the fused forward: pm = point-major / pixel-major rows (default), "
                          "cm = the reference's channel-major layout on the first-generation kernels (A/B)")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 4),
-                    help="BASELINE.json workload: 2 = bs=8, N=12288, 22 classes (the headline metric, default); "
-                         "4 = YCB-shaped bs=8, N=24576, 22 classes.  Explicit --batch / --n-points override it")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
+                    help="BASELINE.json workload: 2 = bs=8, N=12288, 22 classes, fp32 (the headline metric, default); "
+                         "4 = YCB-shaped bs=8, N=24576, 22 classes, fp32; 5 = bs=16, N=12288, bf16 mixed precision "
+                         "(bfloat16 activations / weights, fp32 accumulation).  Explicit --batch / --n-points override it")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default=None, help="default: by --config")
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 8
+        args.batch = 16 if args.config == 5 else 8
+    if args.precision is None:
+        args.precision = "bf16" if args.config == 5 else "fp32"
     if args.n_points is None:
         args.n_points = 24576 if args.config == 4 else 12288
     return args
@@ -251,6 +256,7 @@ def main():
     overlap = bool(args.streams == 2) and not train
     net.two_streams = overlap
     net.layout = args.layout
+    net.precision = args.precision
     side = net._side_stream(dev) if (overlap and args.overlap_pyramid) else None
 
     def step(record=False):
@@ -352,7 +358,8 @@ def main():
                 # the same instantiation serves layers on both sides of the ridge (157.3 TFLOP/s / 8 TB/s = 19.7 flop per
                 # byte): arithmetic intensity of a row = 2 K Cout flop over 4 (K + Cout) bytes
                 k, cout = rec[3][0], rec[3][1]
-                side = "mfma" if 2.0 * k * cout / (4.0 * (k + cout)) >= VALU_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"
+                esz, peak = (2.0, BF16_PEAK_TFLOPS) if args.precision == "bf16" else (4.0, VALU_PEAK_TFLOPS)
+                side = "mfma" if 2.0 * k * cout / (esz * (k + cout)) >= peak * 1e3 / HBM_PEAK_GBS else "hbm"
                 tr.records.setdefault("mlp_pm<%s,%s>" % (PM_TILES.get(rec[3][3], "?"), side), []).append(rec)
 
         def is_gemm(name):
@@ -369,9 +376,10 @@ def main():
             if mfma_bound(op):
                 flops = sum(gemm_flops(op, t, args.batch) for _, _, _, t in tr.records[op])
                 ach = flops / sec / 1e12
-                return {"bound": "mfma", "achieved": ach, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / VALU_PEAK_TFLOPS,
-                        "kernel": MLP_KERNEL_NAMES.get(op.replace(",mfma>", ">"), op) + " (fp32 MFMA 32x32x2)",
+                peak = BF16_PEAK_TFLOPS if args.precision == "bf16" and op.startswith(("mlp_pm", "att_pool_pm")) else VALU_PEAK_TFLOPS
+                return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                        "kernel": MLP_KERNEL_NAMES.get(op.replace(",mfma>", ">"), op) +
+                        (" (bf16 MFMA 32x32x16)" if peak == BF16_PEAK_TFLOPS else " (fp32 MFMA 32x32x2)"),
                         "launches": summ["launches"], "avg_launch_us": summ["avg_us"], "flops": flops, "bytes": summ["bytes"]}
             return {"bound": "hbm", "achieved": summ["gbps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": summ["gbps"] / HBM_PEAK_GBS, "kernel": MLP_KERNEL_NAMES.get(op.replace(",hbm>", ">"), op),
@@ -445,13 +453,14 @@ def main():
                       f"RGB-D frames/sec train step (fwd+bwd+Adam, 480x640, N={args.n_points}, bs={args.batch}/GPU)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": ("FFB6D forward" if not train else "FFB6D training step (forward + backward + Adam, "
                                     "train-mode BatchNorm with %s statistics, DDP gradient all-reduce when n_gpus > 1)" %
                                     ("synchronised (SyncBatchNorm)" if args.sync_bn and world > 1 else "per-rank")) +
                                    " incl. on-device 22-call KNN index pyramid; "
                                    f"bs={args.batch}/GPU, N={args.n_points} pts, 480x640 RGB-D, "
-                                   f"{args.n_classes} classes, fp32, {'train' if train else 'eval'}",
+                                   f"{args.n_classes} classes, " + ("bf16 activations/weights with fp32 accumulation" if args.precision == "bf16" else "fp32") +
+                                   f", {'train' if train else 'eval'}",
                        "baseline_config": args.config, "global_batch": args.batch * world, "n_points": args.n_points,
                        "index_dtype": args.index_dtype, "layout": args.layout,
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "

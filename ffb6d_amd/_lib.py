@@ -44,14 +44,17 @@ SIGNATURES = {
                                 _i64, _i64, _i64, _i32, _i32, _vp]),
     "ffb6d_mlp_pm_tile": (_i32, [_i64, _i64, _i64, _i32]),
     "ffb6d_att_pool_pm_f32": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _vp]),
-    "ffb6d_random_sample_pm_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
-    "ffb6d_gather_rows_pm_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp]),
-    "ffb6d_relative_pos_encoding_pm_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp]),
-    "ffb6d_affine_act_pm_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _c.c_float, _vp]),
-    "ffb6d_bilinear_resize_pm_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_mlp_pm_bf16": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _vp,
+                                 _i64, _i64, _i64, _i32, _i32, _vp]),
+    "ffb6d_att_pool_pm_bf16": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_random_sample_pm": (_i32, [_i32, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "ffb6d_gather_rows_pm": (_i32, [_i32, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "ffb6d_relative_pos_encoding_pm": (_i32, [_i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp]),
+    "ffb6d_affine_act_pm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _c.c_float, _vp]),
+    "ffb6d_bilinear_resize_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_psp_pool_pm_workspace_bytes": (_sz, [_i64, _i64, _i64, _vp, _i32]),
-    "ffb6d_psp_pool_pm_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp]),
-    "ffb6d_psp_prior_sum_pm_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "ffb6d_psp_pool_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp]),
+    "ffb6d_psp_prior_sum_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp]),
     "ffb6d_att_score_pool_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_shared_mlp_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "ffb6d_bilinear_resize_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),

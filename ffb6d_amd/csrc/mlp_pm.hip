@@ -25,6 +25,12 @@
 // channel), B = activation rows (j = point): accumulator register r of lane l is channel (r&3)+8*(r>>2)+4*(l>>5)
 // of point l&31, i.e. a lane owns 4 x 4 consecutive channels of ONE point and the epilogue (bias, gathered row of
 // Y, activation) is four 16-byte loads and four 16-byte stores per 32 x 32 tile.
+//
+// bf16 (BASELINE.json configuration 5: mixed precision, fp32 accumulation): the kernels are templated on the element
+// type of the activations / weights.  v_mfma_f32_32x32x16_bf16 takes 8 consecutive k per lane -- again one 16-byte load
+// (lane l: k0 + 8*(l>>5) .. +7) -- so the byte arithmetic of the operand stream is identical: a step is 32 bytes of
+// every row, i.e. 8 k and four MFMAs in fp32, 16 k and ONE MFMA (16x the rate) in bf16.  Bias and all epilogue
+// arithmetic stay fp32; stores round to nearest even (v_cvt_pk_bf16_f32).
 #include "common.h"
 #include "ffb6d_ops.h"
 
@@ -33,18 +39,69 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BLK = 256;
 
+// element-type traits: bytes, k per 32-byte step, 4-channel group load / store of the epilogue
+template <typename T> struct El;
+template <> struct El<float> {
+    static constexpr int SZ = 4;
+    static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct El<__bf16> {
+    static constexpr int SZ = 2;
+    static __device__ __forceinline__ float4 ld4(const __bf16* p)
+    {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void st4(__bf16* p, float4 v)
+    {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<bf16x4*>(p) = b;
+    }
+    static __device__ __forceinline__ float ld(const __bf16* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(__bf16* p, float v) { *p = (__bf16)v; }
+};
+
+// one 32-byte step of a TM x TN tile: fp32 = 8 k as four 32x32x2 MFMAs (pairs k0+t, k0+4+t), bf16 = 16 k as one 32x32x16
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void mfma_step(f32x16 (&acc)[TM][TN], const u32x4 (&a)[TM], const u32x4 (&b)[TN])
+{
+    if constexpr (El<T>::SZ == 4) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i][tt]), __uint_as_float(b[j][tt]),
+                                                                     acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                                    acc[i][j], 0, 0, 0);
+    }
+}
+
 struct PmParams {
-    const float* w;       // [cout, k1 + k2]  (nn.Conv weight layout, BatchNorm folded)
-    const float* bias;    // [cout] or null
-    const float* x1;      // [rows, ld1] (or [B * px, ld1] when xidx), first k1 floats of a row are used
+    const void* w;        // [cout, k1 + k2]  (nn.Conv weight layout, BatchNorm folded), element type T
+    const float* bias;    // [cout] fp32 or null
+    const void* x1;       // [rows, ld1] (or [B * px, ld1] when xidx), first k1 elements of a row are used
     const void* xidx;     // [rows] int32/int64 or null: x1 row of output row r = (r / P) * px + xidx[r]  (operand gather)
-    const float* x2;      // [rows, ld2] or null
-    const float* y;       // [B * py, ldy] rows added in the epilogue, or null
+    const void* x2;       // [rows, ld2] or null
+    const void* y;        // [B * py, ldy] rows added in the epilogue, or null
     const void* gidx;     // [rows] int32/int64: row of the frame's py rows to add; null with y != null: row r itself
-    float* out;           // [rows, ldo]
+    void* out;            // [rows, ldo]
     int rows, cout, k1, k2, ld1, ld2, ldy, ldo;
     int P, py, px;        // output rows per frame (for the gathers), rows of Y / of X1 per frame
     int act, idx64;
@@ -65,12 +122,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 // workgroups would each walk the whole K.
 // (Measured and dropped: 128 x 64 / 64 x 128 tiles per wave, and stages of 32 k = one whole 128-byte line per row and lane
 // pair -- all within +-5 % of this form on the MFMA-bound layers, profiles/r02_mlp_pm_tiles.txt.)
-template <int TM, int TN, int WM, int WN, bool KSPLIT>
+template <typename T, int TM, int TN, int WM, int WN, bool KSPLIT>
 __global__ void __launch_bounds__(BLK)
 mlp_pm_kernel(const PmParams p)
 {
     static_assert(WM * WN == 4, "four waves");
-    constexpr int KW = 1;                               // float4 per lane, row and stage
+    constexpr int SZ = El<T>::SZ;
+    constexpr int KSTEP = 32 / SZ;                      // k per step: 8 (fp32) or 16 (bf16)
     constexpr int BC = 32 * TM * (KSPLIT ? 1 : WM);     // channels per workgroup
     constexpr int BP = 32 * TN * (KSPLIT ? 1 : WN);     // points per workgroup
 
@@ -89,15 +147,15 @@ mlp_pm_kernel(const PmParams p)
     const int wm = KSPLIT ? 0 : wave / WN, wn = KSPLIT ? 0 : wave % WN;
 
     const int K = p.k1 + p.k2;
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)K * 4u);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)K * SZ);
     const unsigned x1_rows = p.xidx ? (unsigned)(p.rows / p.P) * (unsigned)p.px : (unsigned)p.rows;
-    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, x1_rows * (unsigned)p.ld1 * 4u);
-    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? (unsigned)p.rows * (unsigned)p.ld2 * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, x1_rows * (unsigned)p.ld1 * SZ);
+    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? (unsigned)p.rows * (unsigned)p.ld2 * SZ : 0u);
 
     // per-lane byte offsets of this lane's rows (k = 0); rows past the end are out of range -> zeros
     int w_vo[TM], x1_vo[TN], x2_vo[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) w_vo[i] = ((c0 + (wm * TM + i) * 32 + l31) * K + 4 * KW * kh) * 4;
+    for (int i = 0; i < TM; ++i) w_vo[i] = (c0 + (wm * TM + i) * 32 + l31) * K * SZ + 16 * kh;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = r0 + (wn * TN + j) * 32 + l31;
@@ -108,11 +166,11 @@ mlp_pm_kernel(const PmParams p)
                 xr = (r / p.P) * p.px + (p.idx64 ? (int)static_cast<const long long*>(p.xidx)[r]
                                                  : static_cast<const int*>(p.xidx)[r]);
         }
-        x1_vo[j] = (xr * p.ld1 + 4 * KW * kh) * 4;
-        x2_vo[j] = (r * p.ld2 + 4 * KW * kh) * 4;
+        x1_vo[j] = xr * p.ld1 * SZ + 16 * kh;
+        x2_vo[j] = r * p.ld2 * SZ + 16 * kh;
     }
 
-    const int n1 = p.k1 / (8 * KW), nsteps = K / (8 * KW);    // k-steps of 8 * KW (k1, k2 multiples of that)
+    const int n1 = p.k1 / KSTEP, nsteps = K / KSTEP;      // steps of 32 bytes per row (k1, k2 multiples of KSTEP)
     // this wave's step range
     int s_beg = 0, s_end = nsteps;
     if (KSPLIT) {
@@ -129,58 +187,39 @@ mlp_pm_kernel(const PmParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // register stages; a stage = 8 * KW k of every row of the wave's tile: lane (row, kh) holds k0 + 4*KW*kh .. + 4*KW - 1 and
-    // MFMA step t pairs k0 + t with k0 + 4*KW + t.  The k offset travels in the per-lane offset (the scalar offset of a
-    // buffer load is not range checked): a surplus prefetch past the last step reads the following floats of the row buffer
-    // or, past its end, zeros -- never used either way.
-    u32x4 wa0[TM][KW], wa1[TM][KW], wa2[TM][KW], xb0[TN][KW], xb1[TN][KW], xb2[TN][KW];
-    auto load = [&](int step, u32x4 (&wa)[TM][KW], u32x4 (&xb)[TN][KW]) {
+    // three register stages; a stage = 32 bytes of every row of the wave's tile, 16 per half-wave.  The k offset travels in
+    // the per-lane offset (the scalar offset of a buffer load is not range checked): a surplus prefetch past the last step
+    // reads the following elements of the row buffer or, past its end, zeros -- never used either way.
+    u32x4 wa0[TM], wa1[TM], wa2[TM], xb0[TN], xb1[TN], xb2[TN];
+    auto load = [&](int step, u32x4 (&wa)[TM], u32x4 (&xb)[TN]) {
         const bool second = step >= n1;
         const __amdgpu_buffer_rsrc_t rx = second ? rs_x2 : rs_x1;
-        const int wko = step * 32 * KW;                              // bytes
-        const int xko = (second ? step - n1 : step) * 32 * KW;
+        const int wko = step * 32;                                  // bytes
+        const int xko = (second ? step - n1 : step) * 32;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int u = 0; u < KW; ++u) wa[i][u] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[i] + wko + 16 * u, 0, 0);
+        for (int i = 0; i < TM; ++i) wa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[i] + wko, 0, 0);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int u = 0; u < KW; ++u)
-                xb[j][u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (second ? x2_vo[j] : x1_vo[j]) + xko + 16 * u, 0, 0);
-    };
-    auto compute = [&](const u32x4 (&wa)[TM][KW], const u32x4 (&xb)[TN][KW]) {
-#pragma unroll
-        for (int u = 0; u < KW; ++u)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wa[i][u][tt]), __uint_as_float(xb[j][u][tt]),
-                                                                         acc[i][j], 0, 0, 0);
+            xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (second ? x2_vo[j] : x1_vo[j]) + xko, 0, 0);
     };
 
-    // one basic block per iteration: the loads of the next stages fly under the MFMAs of the current one.  sched_barrier pins
+    // one basic block per iteration: the loads of step s+2 fly under the MFMAs of steps s and s+1.  sched_barrier pins
     // the issue order (hipcc otherwise sinks the loads below the MFMA groups and every iteration starts by draining them).
 #define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
     int st = s_beg;
-    if constexpr (KW == 1) {
-        load(st, wa0, xb0);
-        load(st + 1, wa1, xb1);
-        for (; st + 3 <= s_end; st += 3) {
-            load(st + 2, wa2, xb2); FFB6D_PIN();
-            compute(wa0, xb0);      FFB6D_PIN();
-            load(st + 3, wa0, xb0); FFB6D_PIN();
-            compute(wa1, xb1);      FFB6D_PIN();
-            load(st + 4, wa1, xb1); FFB6D_PIN();
-            compute(wa2, xb2);      FFB6D_PIN();
-        }
-        if (st < s_end) compute(wa0, xb0);
-        if (st + 1 < s_end) compute(wa1, xb1);
+    load(st, wa0, xb0);
+    load(st + 1, wa1, xb1);
+    for (; st + 3 <= s_end; st += 3) {
+        load(st + 2, wa2, xb2);                FFB6D_PIN();
+        mfma_step<T, TM, TN>(acc, wa0, xb0);   FFB6D_PIN();
+        load(st + 3, wa0, xb0);                FFB6D_PIN();
+        mfma_step<T, TM, TN>(acc, wa1, xb1);   FFB6D_PIN();
+        load(st + 4, wa1, xb1);                FFB6D_PIN();
+        mfma_step<T, TM, TN>(acc, wa2, xb2);   FFB6D_PIN();
     }
 #undef FFB6D_PIN
+    if (st < s_end) mfma_step<T, TM, TN>(acc, wa0, xb0);
+    if (st + 1 < s_end) mfma_step<T, TM, TN>(acc, wa1, xb1);
 
     if constexpr (KSPLIT) {
         // partial sums of waves 1..3 -> LDS (lane-contiguous), wave 0 adds them and runs the epilogue
@@ -206,25 +245,28 @@ mlp_pm_kernel(const PmParams p)
     }
 
     // epilogue: lane = one point, 4 groups of 4 consecutive channels per 32 x 32 tile
+    const T* yb = static_cast<const T*>(p.y);
+    T* ob = static_cast<T*>(p.out);
     const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
+    constexpr int AL = 4 * SZ - 1;                         // alignment mask of a 4-channel group
     const bool vec = (p.cout & 3) == 0 && (p.ldo & 3) == 0 && (p.ldy & 3) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.y) |
-                       reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
+                     ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.y)) & AL) == 0 &&
+                     (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = r0 + (wn * TN + j) * 32 + l31;
         const bool live = r < p.rows;
-        const float* yrow = nullptr;
-        if (p.y && live) {
+        const T* yrow = nullptr;
+        if (yb && live) {
             long long yr = r;
             if (p.gidx) {
                 const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[r]
                                              : (long long)static_cast<const int*>(p.gidx)[r];
                 yr = (long long)(r / p.P) * p.py + gi;
             }
-            yrow = p.y + yr * p.ldy;
+            yrow = yb + yr * p.ldy;
         }
-        float* orow = p.out + (size_t)r * p.ldo;
+        T* orow = ob + (size_t)r * p.ldo;
         if (vec) {
             float4 v[TM][4];
 #pragma unroll
@@ -239,7 +281,7 @@ mlp_pm_kernel(const PmParams p)
                         v[i][g].x += b4.x; v[i][g].y += b4.y; v[i][g].z += b4.z; v[i][g].w += b4.w;
                     }
                     if (yrow) {
-                        const float4 y4 = *reinterpret_cast<const float4*>(yrow + ch);
+                        const float4 y4 = El<T>::ld4(yrow + ch);
                         v[i][g].x += y4.x; v[i][g].y += y4.y; v[i][g].z += y4.z; v[i][g].w += y4.w;
                     }
                 }
@@ -270,8 +312,7 @@ mlp_pm_kernel(const PmParams p)
                     for (int g = 0; g < 4; ++g) {
                         const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
                         if (ch < p.cout && live)
-                            *reinterpret_cast<float4*>(orow + ch) =
-                                make_float4(v[i][g].x - lse, v[i][g].y - lse, v[i][g].z - lse, v[i][g].w - lse);
+                            El<T>::st4(orow + ch, make_float4(v[i][g].x - lse, v[i][g].y - lse, v[i][g].z - lse, v[i][g].w - lse));
                     }
             } else {
 #pragma unroll
@@ -280,9 +321,8 @@ mlp_pm_kernel(const PmParams p)
                     for (int g = 0; g < 4; ++g) {
                         const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
                         if (ch < p.cout && live)
-                            *reinterpret_cast<float4*>(orow + ch) =
-                                make_float4(activate(v[i][g].x, slope), activate(v[i][g].y, slope), activate(v[i][g].z, slope),
-                                            activate(v[i][g].w, slope));
+                            El<T>::st4(orow + ch, make_float4(activate(v[i][g].x, slope), activate(v[i][g].y, slope),
+                                                              activate(v[i][g].z, slope), activate(v[i][g].w, slope)));
                     }
             }
         } else if (live) {
@@ -294,8 +334,8 @@ mlp_pm_kernel(const PmParams p)
                     if (ch >= p.cout) continue;
                     float u = acc[i][j][q];
                     if (p.bias) u += p.bias[ch];
-                    if (yrow) u += yrow[ch];
-                    orow[ch] = activate(u, slope);
+                    if (yrow) u += El<T>::ld(yrow + ch);
+                    El<T>::st(orow + ch, activate(u, slope));
                 }
             }
         }
@@ -316,19 +356,21 @@ mlp_pm_kernel(const PmParams p)
 // the scores are multiplied with are re-read channel-contiguous (128-byte segments, L1-resident after the operand loads).
 // ---------------------------------------------------------------------------------------------------------------
 struct AttParams {
-    const float* w;       // [d, d] fc weight, nn.Conv layout
-    const float* f;       // [B * N, ldf] point rows, first c1 floats used
+    const void* w;        // [d, d] fc weight, nn.Conv layout, element type T
+    const void* f;        // [B * N, ldf] point rows, first c1 elements used
     const void* nei;      // [B * N * 16] int32/int64 neighbour indices inside the frame
-    const float* g;       // [B * N * 16, ldg] pair rows, first c2 floats used
-    float* out;           // [B * N, ldo]
+    const void* g;        // [B * N * 16, ldg] pair rows, first c2 elements used
+    void* out;            // [B * N, ldo]
     int npts, N, c1, c2, ldf, ldg, ldo, idx64;
     int n_pt, n_ct;
 };
 
-template <int TM, int TN>
+template <typename T, int TM, int TN>
 __global__ void __launch_bounds__(BLK)
 att_pool_pm_kernel(const AttParams p)
 {
+    constexpr int SZ = El<T>::SZ;
+    constexpr int KSTEP = 32 / SZ;
     constexpr int PTS = 2 * TM * 4;                 // points per workgroup (4 waves along the points)
     constexpr int BC = 32 * TN;                     // channels per workgroup
     const int t = blockIdx.x;
@@ -342,10 +384,13 @@ att_pool_pm_kernel(const AttParams p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pbase = pt * PTS + wave * (2 * TM);   // first point of this wave
     const int d = p.c1 + p.c2;
+    const T* fb = static_cast<const T*>(p.f);
+    const T* gb = static_cast<const T*>(p.g);
+    T* ob = static_cast<T*>(p.out);
 
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)d * (unsigned)d * 4u);
-    const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.f, (unsigned)p.npts * (unsigned)p.ldf * 4u);
-    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(p.g, (unsigned)p.npts * 16u * (unsigned)p.ldg * 4u);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)d * (unsigned)d * SZ);
+    const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.f, (unsigned)p.npts * (unsigned)p.ldf * SZ);
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(p.g, (unsigned)p.npts * 16u * (unsigned)p.ldg * SZ);
 
     // A operand: this lane's pair of every row tile
     const int a_pp = (l31 >> 2) & 1, a_nb = (l31 & 3) + 4 * (l31 >> 3);
@@ -360,11 +405,11 @@ att_pool_pm_kernel(const AttParams p)
             frow = (n / p.N) * p.N + nb;
             grow = (int)pair;
         }
-        f_vo[i] = (frow * p.ldf + 4 * kh) * 4;
-        g_vo[i] = (grow * p.ldg + 4 * kh) * 4;
+        f_vo[i] = frow * p.ldf * SZ + 16 * kh;
+        g_vo[i] = grow * p.ldg * SZ + 16 * kh;
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) w_vo[j] = ((c0 + j * 32 + l31) * d + 4 * kh) * 4;
+    for (int j = 0; j < TN; ++j) w_vo[j] = (c0 + j * 32 + l31) * d * SZ + 16 * kh;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -374,7 +419,7 @@ att_pool_pm_kernel(const AttParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int n1 = p.c1 >> 3, nsteps = d >> 3;
+    const int n1 = p.c1 / KSTEP, nsteps = d / KSTEP;
     u32x4 xa0[TM], xa1[TM], xa2[TM], wb0[TN], wb1[TN], wb2[TN];
     auto load = [&](int step, u32x4 (&xa)[TM], u32x4 (&wb)[TN]) {
         const bool second = step >= n1;
@@ -386,38 +431,28 @@ att_pool_pm_kernel(const AttParams p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) wb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_vo[j] + wko, 0, 0);
     };
-    auto compute = [&](const u32x4 (&xa)[TM], const u32x4 (&wb)[TN]) {
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(xa[i][tt]), __uint_as_float(wb[j][tt]),
-                                                                     acc[i][j], 0, 0, 0);
-    };
     int st = 0;
     load(0, xa0, wb0);
     load(1, xa1, wb1);
 #define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
     for (; st + 3 <= nsteps; st += 3) {
-        load(st + 2, xa2, wb2); FFB6D_PIN();
-        compute(xa0, wb0);      FFB6D_PIN();
-        load(st + 3, xa0, wb0); FFB6D_PIN();
-        compute(xa1, wb1);      FFB6D_PIN();
-        load(st + 4, xa1, wb1); FFB6D_PIN();
-        compute(xa2, wb2);      FFB6D_PIN();
+        load(st + 2, xa2, wb2);                FFB6D_PIN();
+        mfma_step<T, TM, TN>(acc, xa0, wb0);   FFB6D_PIN();
+        load(st + 3, xa0, wb0);                FFB6D_PIN();
+        mfma_step<T, TM, TN>(acc, xa1, wb1);   FFB6D_PIN();
+        load(st + 4, xa1, wb1);                FFB6D_PIN();
+        mfma_step<T, TM, TN>(acc, xa2, wb2);   FFB6D_PIN();
     }
 #undef FFB6D_PIN
-    if (st < nsteps) compute(xa0, wb0);
-    if (st + 1 < nsteps) compute(xa1, wb1);
+    if (st < nsteps) mfma_step<T, TM, TN>(acc, xa0, wb0);
+    if (st + 1 < nsteps) mfma_step<T, TM, TN>(acc, xa1, wb1);
 
     // epilogue: lane (channel l31 of each column tile, point kh of each row tile) owns 16 scores = one neighbourhood
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int n = pbase + 2 * i + kh;
         if (n >= p.npts) continue;
-        const int fb = (n / p.N) * p.N;
+        const int fbase = (n / p.N) * p.N;
         int nbr[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -428,12 +463,12 @@ att_pool_pm_kernel(const AttParams p)
             const int ch = c0 + j * 32 + l31;
             if (ch >= d) continue;
             const bool from_f = ch < p.c1;
-            const float* src = from_f ? p.f + ch : p.g + (ch - p.c1);
+            const T* src = from_f ? fb + ch : gb + (ch - p.c1);
             float fv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const size_t row = from_f ? (size_t)(fb + nbr[r]) * p.ldf : ((size_t)n * 16 + r) * p.ldg;
-                fv[r] = src[row];
+                const size_t row = from_f ? (size_t)(fbase + nbr[r]) * p.ldf : ((size_t)n * 16 + r) * p.ldg;
+                fv[r] = El<T>::ld(src + row);
             }
             float m = acc[i][j][0];
 #pragma unroll
@@ -445,27 +480,110 @@ att_pool_pm_kernel(const AttParams p)
                 den += e;
                 num = fmaf(fv[r], e, num);
             }
-            p.out[(size_t)n * p.ldo + ch] = num * __builtin_amdgcn_rcpf(den);
+            El<T>::st(ob + (size_t)n * p.ldo + ch, num * __builtin_amdgcn_rcpf(den));
         }
     }
 }
 
-template <int TM, int TN>
-void launch_att(AttParams& p, hipStream_t st)
-{
-    p.n_ct = (int)ceil_div(p.c1 + p.c2, 32 * TN);
-    p.n_pt = (int)ceil_div(p.npts, 2 * TM * 4);
-    hipLaunchKernelGGL((att_pool_pm_kernel<TM, TN>), dim3((unsigned)(ceil_div(p.n_pt, 8) * p.n_ct * 8)), dim3(BLK), 0, st, p);
-}
-
-template <int TM, int TN, int WM, int WN, bool KSPLIT>
+template <typename T, int TM, int TN, int WM, int WN, bool KSPLIT>
 void launch_pm(PmParams& p, hipStream_t st)
 {
     constexpr int BC = 32 * TM * (KSPLIT ? 1 : WM), BP = 32 * TN * (KSPLIT ? 1 : WN);
     p.n_ct = (int)ceil_div(p.cout, BC);
     p.n_pt = (int)ceil_div(p.rows, BP);
     const unsigned grid = (unsigned)(ceil_div(p.n_pt, 8) * p.n_ct * 8);
-    hipLaunchKernelGGL((mlp_pm_kernel<TM, TN, WM, WN, KSPLIT>), dim3(grid), dim3(BLK), 0, st, p);
+    hipLaunchKernelGGL((mlp_pm_kernel<T, TM, TN, WM, WN, KSPLIT>), dim3(grid), dim3(BLK), 0, st, p);
+}
+
+template <typename T, int TM, int TN>
+void launch_att(AttParams& p, hipStream_t st)
+{
+    p.n_ct = (int)ceil_div(p.c1 + p.c2, 32 * TN);
+    p.n_pt = (int)ceil_div(p.npts, 2 * TM * 4);
+    hipLaunchKernelGGL((att_pool_pm_kernel<T, TM, TN>), dim3((unsigned)(ceil_div(p.n_pt, 8) * p.n_ct * 8)), dim3(BLK), 0, st, p);
+}
+
+template <typename T>
+int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, int64_t ld1, const void* x1_idx,
+                int64_t x1_rows_per_frame, const void* x2, int64_t k2, int64_t ld2, const void* y, int64_t ldy, const void* y_idx,
+                int64_t y_rows_per_frame, int idx_bits, int64_t rows_per_frame, void* out, int64_t ldo, int64_t rows, int64_t cout,
+                int act, int tile_hint, ffb6d_stream_t stream)
+{
+    constexpr int SZ = El<T>::SZ;
+    constexpr int KSTEP = 32 / SZ;
+    FFB6D_REQUIRE(rows >= 0 && cout >= 1 && k1 >= KSTEP && k2 >= 0, "mlp_pm: bad shape");
+    FFB6D_REQUIRE(k1 % KSTEP == 0 && k2 % KSTEP == 0, "mlp_pm: k1 and k2 must be multiples of %d (got %lld, %lld): pad the rows",
+                  KSTEP, (long long)k1, (long long)k2);
+    FFB6D_REQUIRE(act >= 0 && act <= 3, "mlp_pm: act must be 0 (none), 1 (relu), 2 (leaky 0.2) or 3 (log_softmax over channels)");
+    if (rows == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(w && x1 && out, "mlp_pm: null pointer");
+    FFB6D_REQUIRE((k2 == 0) == (x2 == nullptr), "mlp_pm: x2 and k2 must come together");
+    FFB6D_REQUIRE(ld1 >= k1 && (k2 == 0 || ld2 >= k2) && ldo >= cout, "mlp_pm: row stride smaller than the row");
+    FFB6D_REQUIRE((ld1 * SZ) % 16 == 0 && (ld2 * SZ) % 16 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(w)) & 15) == 0,
+                  "mlp_pm: operand rows must be 16-byte aligned");
+    FFB6D_REQUIRE(!y_idx || y, "mlp_pm: gather indices without rows to gather");
+    const bool indexed = y_idx || x1_idx;
+    FFB6D_REQUIRE(!indexed || ((idx_bits == 32 || idx_bits == 64) && rows_per_frame >= 1 && rows % rows_per_frame == 0),
+                  "mlp_pm: index arrays need idx_bits 32/64 and rows_per_frame dividing rows");
+    FFB6D_REQUIRE((!y_idx || y_rows_per_frame >= 1) && (!x1_idx || x1_rows_per_frame >= 1), "mlp_pm: rows per frame of a gathered source");
+    FFB6D_REQUIRE(!y || ldy >= cout, "mlp_pm: ldy smaller than cout");
+    FFB6D_REQUIRE(act != 3 || (cout <= 64 && (cout & 3) == 0 && (ldo & 3) == 0 &&
+                               ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(y)) & (4 * SZ - 1)) == 0 &&
+                               (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
+                  "mlp_pm: log_softmax epilogue needs cout <= 64, cout %% 4 == 0 and aligned rows");
+    const int64_t K = k1 + k2;
+    const int64_t x1_rows = x1_idx ? rows / rows_per_frame * x1_rows_per_frame : rows;
+    FFB6D_REQUIRE((x1_rows + 256) * ld1 * SZ < (1LL << 31) && (rows + 256) * (ld2 > 0 ? ld2 : 1) * SZ < (1LL << 31) &&
+                  (cout + 128) * K * SZ < (1LL << 31), "mlp_pm: operand larger than the 2 GiB buffer addressing of one launch");
+    PmParams p;
+    p.w = w; p.bias = bias; p.x1 = x1; p.xidx = x1_idx; p.x2 = x2; p.y = y; p.gidx = y_idx; p.out = out;
+    p.rows = (int)rows; p.cout = (int)cout; p.k1 = (int)k1; p.k2 = (int)k2; p.ld1 = (int)ld1; p.ld2 = (int)(k2 ? ld2 : 16 / SZ);
+    p.ldy = (int)ldy; p.ldo = (int)ldo; p.P = (int)(indexed ? rows_per_frame : rows); p.py = (int)y_rows_per_frame;
+    p.px = (int)x1_rows_per_frame; p.act = act;
+    p.idx64 = idx_bits == 64;
+    hipStream_t st = as_stream(stream);
+    const int choice = tile_hint > 0 ? tile_hint : ffb6d_mlp_pm_tile(rows, cout, K, act);
+    switch (choice) {
+        case 1: launch_pm<T, 2, 2, 2, 2, false>(p, st); break;      // 128 ch x 128 pt
+        case 2: launch_pm<T, 2, 2, 1, 4, false>(p, st); break;      // 64 ch x 256 pt
+        case 3: launch_pm<T, 1, 2, 1, 4, false>(p, st); break;      // 32 ch x 256 pt
+        case 4: launch_pm<T, 1, 1, 2, 2, false>(p, st); break;      // 64 ch x 64 pt
+        case 5: launch_pm<T, 2, 1, 2, 2, true>(p, st); break;       // 64 ch x 32 pt, K over the 4 waves
+        default: return set_error(FFB6D_ERR_ARG, "mlp_pm: unknown tile_hint %d", tile_hint);
+    }
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+template <typename T>
+int att_pool_pm_impl(const void* w_fc, const void* f, int64_t c1, int64_t ldf, const void* nei, int idx_bits, const void* g,
+                     int64_t c2, int64_t ldg, void* out, int64_t ldo, int64_t B, int64_t N, int K, ffb6d_stream_t stream)
+{
+    constexpr int SZ = El<T>::SZ;
+    constexpr int KSTEP = 32 / SZ;
+    FFB6D_REQUIRE(K == 16, "att_pool_pm: K must be 16 (got %d)", K);
+    FFB6D_REQUIRE(idx_bits == 32 || idx_bits == 64, "att_pool_pm: idx_bits must be 32 or 64");
+    FFB6D_REQUIRE(B >= 0 && N >= 0 && c1 >= KSTEP && c2 >= KSTEP && c1 % KSTEP == 0 && c2 % KSTEP == 0,
+                  "att_pool_pm: c1 and c2 must be positive multiples of %d", KSTEP);
+    if (B == 0 || N == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(w_fc && f && nei && g && out, "att_pool_pm: null pointer");
+    FFB6D_REQUIRE(ldf >= c1 && ldg >= c2 && ldo >= c1 + c2 && (ldf * SZ) % 16 == 0 && (ldg * SZ) % 16 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(w_fc)) & 15) == 0,
+                  "att_pool_pm: rows must be 16-byte aligned and at least as long as their channel count");
+    const int64_t npts = B * N, d = c1 + c2;
+    FFB6D_REQUIRE((npts + 64) * ldf * SZ < (1LL << 31) && (npts + 64) * 16 * ldg * SZ < (1LL << 31) && (d + 128) * d * SZ < (1LL << 31),
+                  "att_pool_pm: operand larger than the 2 GiB buffer addressing of one launch");
+    AttParams p;
+    p.w = w_fc; p.f = f; p.nei = nei; p.g = g; p.out = out;
+    p.npts = (int)npts; p.N = (int)N; p.c1 = (int)c1; p.c2 = (int)c2; p.ldf = (int)ldf; p.ldg = (int)ldg; p.ldo = (int)ldo;
+    p.idx64 = idx_bits == 64;
+    hipStream_t st = as_stream(stream);
+    if (d <= 32) launch_att<T, 4, 1>(p, st);
+    else if (d <= 64) launch_att<T, 2, 2>(p, st);
+    else launch_att<T, 1, 4>(p, st);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
 }
 
 }  // namespace
@@ -488,79 +606,36 @@ extern "C" int ffb6d_mlp_pm_tile(int64_t rows, int64_t cout, int64_t K, int act)
     return 5;
 }
 
+#define FFB6D_MLP_PM_ARGS                                                                                                    \
+    bias, x1, k1, ld1, x1_idx, x1_rows_per_frame, x2, k2, ld2, y, ldy, y_idx, y_rows_per_frame, idx_bits, rows_per_frame, out, \
+        ldo, rows, cout, act, tile_hint, stream
+
 extern "C" int ffb6d_mlp_pm_f32(const float* w, const float* bias, const float* x1, int64_t k1, int64_t ld1, const void* x1_idx,
                                 int64_t x1_rows_per_frame, const float* x2, int64_t k2, int64_t ld2, const float* y, int64_t ldy,
                                 const void* y_idx, int64_t y_rows_per_frame, int idx_bits, int64_t rows_per_frame, float* out,
                                 int64_t ldo, int64_t rows, int64_t cout, int act, int tile_hint, ffb6d_stream_t stream)
 {
-    FFB6D_REQUIRE(rows >= 0 && cout >= 1 && k1 >= 8 && k2 >= 0, "mlp_pm: bad shape");
-    FFB6D_REQUIRE((k1 & 7) == 0 && (k2 & 7) == 0, "mlp_pm: k1 and k2 must be multiples of 8 (got %lld, %lld): pad the rows",
-                  (long long)k1, (long long)k2);
-    FFB6D_REQUIRE(act >= 0 && act <= 3, "mlp_pm: act must be 0 (none), 1 (relu), 2 (leaky 0.2) or 3 (log_softmax over channels)");
-    if (rows == 0) return FFB6D_OK;
-    FFB6D_REQUIRE(w && x1 && out, "mlp_pm: null pointer");
-    FFB6D_REQUIRE((k2 == 0) == (x2 == nullptr), "mlp_pm: x2 and k2 must come together");
-    FFB6D_REQUIRE(ld1 >= k1 && (k2 == 0 || ld2 >= k2) && ldo >= cout, "mlp_pm: row stride smaller than the row");
-    FFB6D_REQUIRE((ld1 & 3) == 0 && (ld2 & 3) == 0 &&
-                  ((reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(w)) & 15) == 0,
-                  "mlp_pm: operand rows must be 16-byte aligned");
-    FFB6D_REQUIRE(!y_idx || y, "mlp_pm: gather indices without rows to gather");
-    const bool indexed = y_idx || x1_idx;
-    FFB6D_REQUIRE(!indexed || ((idx_bits == 32 || idx_bits == 64) && rows_per_frame >= 1 && rows % rows_per_frame == 0),
-                  "mlp_pm: index arrays need idx_bits 32/64 and rows_per_frame dividing rows");
-    FFB6D_REQUIRE((!y_idx || y_rows_per_frame >= 1) && (!x1_idx || x1_rows_per_frame >= 1), "mlp_pm: rows per frame of a gathered source");
-    FFB6D_REQUIRE(!y || ldy >= cout, "mlp_pm: ldy smaller than cout");
-    FFB6D_REQUIRE(act != 3 || (cout <= 64 && (cout & 3) == 0 && (ldo & 3) == 0 &&
-                               ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0),
-                  "mlp_pm: log_softmax epilogue needs cout <= 64, cout %% 4 == 0 and 16-byte aligned rows");
-    const int64_t K = k1 + k2;
-    const int64_t x1_rows = x1_idx ? rows / rows_per_frame * x1_rows_per_frame : rows;
-    FFB6D_REQUIRE((x1_rows + 256) * ld1 * 4 < (1LL << 31) && (rows + 256) * (ld2 > 0 ? ld2 : 1) * 4 < (1LL << 31) &&
-                  (cout + 128) * K * 4 < (1LL << 31), "mlp_pm: operand larger than the 2 GiB buffer addressing of one launch");
-    PmParams p;
-    p.w = w; p.bias = bias; p.x1 = x1; p.xidx = x1_idx; p.x2 = x2; p.y = y; p.gidx = y_idx; p.out = out;
-    p.rows = (int)rows; p.cout = (int)cout; p.k1 = (int)k1; p.k2 = (int)k2; p.ld1 = (int)ld1; p.ld2 = (int)(k2 ? ld2 : 4);
-    p.ldy = (int)ldy; p.ldo = (int)ldo; p.P = (int)(indexed ? rows_per_frame : rows); p.py = (int)y_rows_per_frame;
-    p.px = (int)x1_rows_per_frame; p.act = act;
-    p.idx64 = idx_bits == 64;
-    hipStream_t st = as_stream(stream);
-    const int choice = tile_hint > 0 ? tile_hint : ffb6d_mlp_pm_tile(rows, cout, K, act);
-    switch (choice) {
-        case 1: launch_pm<2, 2, 2, 2, false>(p, st); break;      // 128 ch x 128 pt
-        case 2: launch_pm<2, 2, 1, 4, false>(p, st); break;      // 64 ch x 256 pt
-        case 3: launch_pm<1, 2, 1, 4, false>(p, st); break;      // 32 ch x 256 pt
-        case 4: launch_pm<1, 1, 2, 2, false>(p, st); break;      // 64 ch x 64 pt
-        case 5: launch_pm<2, 1, 2, 2, true>(p, st); break;       // 64 ch x 32 pt, K over the 4 waves
-        default: return set_error(FFB6D_ERR_ARG, "mlp_pm: unknown tile_hint %d", tile_hint);
-    }
-    FFB6D_LAUNCH_CHECK();
-    return FFB6D_OK;
+    return mlp_pm_impl<float>(w, FFB6D_MLP_PM_ARGS);
+}
+
+extern "C" int ffb6d_mlp_pm_bf16(const void* w, const float* bias, const void* x1, int64_t k1, int64_t ld1, const void* x1_idx,
+                                 int64_t x1_rows_per_frame, const void* x2, int64_t k2, int64_t ld2, const void* y, int64_t ldy,
+                                 const void* y_idx, int64_t y_rows_per_frame, int idx_bits, int64_t rows_per_frame, void* out,
+                                 int64_t ldo, int64_t rows, int64_t cout, int act, int tile_hint, ffb6d_stream_t stream)
+{
+    return mlp_pm_impl<__bf16>(w, FFB6D_MLP_PM_ARGS);
 }
 
 extern "C" int ffb6d_att_pool_pm_f32(const float* w_fc, const float* f, int64_t c1, int64_t ldf, const void* nei, int idx_bits,
                                      const float* g, int64_t c2, int64_t ldg, float* out, int64_t ldo, int64_t B, int64_t N, int K,
                                      ffb6d_stream_t stream)
 {
-    FFB6D_REQUIRE(K == 16, "att_pool_pm: K must be 16 (got %d)", K);
-    FFB6D_REQUIRE(idx_bits == 32 || idx_bits == 64, "att_pool_pm: idx_bits must be 32 or 64");
-    FFB6D_REQUIRE(B >= 0 && N >= 0 && c1 >= 8 && c2 >= 8 && (c1 & 7) == 0 && (c2 & 7) == 0,
-                  "att_pool_pm: c1 and c2 must be positive multiples of 8");
-    if (B == 0 || N == 0) return FFB6D_OK;
-    FFB6D_REQUIRE(w_fc && f && nei && g && out, "att_pool_pm: null pointer");
-    FFB6D_REQUIRE(ldf >= c1 && ldg >= c2 && ldo >= c1 + c2 && (ldf & 3) == 0 && (ldg & 3) == 0 &&
-                  ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(w_fc)) & 15) == 0,
-                  "att_pool_pm: rows must be 16-byte aligned and at least as long as their channel count");
-    const int64_t npts = B * N, d = c1 + c2;
-    FFB6D_REQUIRE((npts + 64) * ldf * 4 < (1LL << 31) && (npts + 64) * 16 * ldg * 4 < (1LL << 31) && (d + 128) * d * 4 < (1LL << 31),
-                  "att_pool_pm: operand larger than the 2 GiB buffer addressing of one launch");
-    AttParams p;
-    p.w = w_fc; p.f = f; p.nei = nei; p.g = g; p.out = out;
-    p.npts = (int)npts; p.N = (int)N; p.c1 = (int)c1; p.c2 = (int)c2; p.ldf = (int)ldf; p.ldg = (int)ldg; p.ldo = (int)ldo;
-    p.idx64 = idx_bits == 64;
-    hipStream_t st = as_stream(stream);
-    if (d <= 32) launch_att<4, 1>(p, st);
-    else if (d <= 64) launch_att<2, 2>(p, st);
-    else launch_att<1, 4>(p, st);
-    FFB6D_LAUNCH_CHECK();
-    return FFB6D_OK;
+    return att_pool_pm_impl<float>(w_fc, f, c1, ldf, nei, idx_bits, g, c2, ldg, out, ldo, B, N, K, stream);
+}
+
+extern "C" int ffb6d_att_pool_pm_bf16(const void* w_fc, const void* f, int64_t c1, int64_t ldf, const void* nei, int idx_bits,
+                                      const void* g, int64_t c2, int64_t ldg, void* out, int64_t ldo, int64_t B, int64_t N, int K,
+                                      ffb6d_stream_t stream)
+{
+    return att_pool_pm_impl<__bf16>(w_fc, f, c1, ldf, nei, idx_bits, g, c2, ldg, out, ldo, B, N, K, stream);
 }

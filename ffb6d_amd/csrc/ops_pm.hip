@@ -12,6 +12,9 @@
 // In the reference's channel-major layout a gathered point touches C different 64-byte sectors (one 4-byte element
 // each); here it is ONE contiguous read of 4*C bytes: lanes run along the channel axis (a float4 per lane), so every
 // load and store of these kernels is a full-width coalesced access and the index is read once per row.
+//
+// Every kernel is templated on the element type of the rows (float, or __bf16 for the mixed-precision configuration:
+// 16-byte units of 4 or 8 channels per lane, arithmetic in fp32, stores rounded to nearest even).
 #include <cfloat>
 
 #include "common.h"
@@ -22,89 +25,142 @@ namespace {
 
 constexpr int BLK = 256;
 
+// a 16-byte unit of a row: VL consecutive channels, held as fp32 in registers
+template <typename T> struct Unit;
+template <> struct Unit<float> {
+    static constexpr int VL = 4;
+    float v[4];
+    static __device__ __forceinline__ Unit load(const void* base, size_t unit)
+    {
+        const float4 f = static_cast<const float4*>(base)[unit];
+        Unit u; u.v[0] = f.x; u.v[1] = f.y; u.v[2] = f.z; u.v[3] = f.w;
+        return u;
+    }
+    __device__ __forceinline__ void store(void* base, size_t unit) const
+    {
+        static_cast<float4*>(base)[unit] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Unit<__bf16> {
+    static constexpr int VL = 8;
+    float v[8];
+    static __device__ __forceinline__ Unit load(const void* base, size_t unit)
+    {
+        const uint4 w = static_cast<const uint4*>(base)[unit];
+        const unsigned int x[4] = {w.x, w.y, w.z, w.w};
+        Unit u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { u.v[2 * i] = __uint_as_float(x[i] << 16); u.v[2 * i + 1] = __uint_as_float(x[i] & 0xffff0000u); }
+        return u;
+    }
+    __device__ __forceinline__ void store(void* base, size_t unit) const
+    {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        bf16x8 b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = (__bf16)v[i];
+        static_cast<bf16x8*>(base)[unit] = b;
+    }
+};
+// fp32 per-channel parameters (BatchNorm scale / shift) of a unit's VL channels
+template <int VL>
+__device__ __forceinline__ void load_params(const float* p, int unit, float (&out)[VL])
+{
+#pragma unroll
+    for (int i = 0; i < VL; i += 4) {
+        const float4 f = *reinterpret_cast<const float4*>(p + (size_t)unit * VL + i);
+        out[i] = f.x; out[i + 1] = f.y; out[i + 2] = f.z; out[i + 3] = f.w;
+    }
+}
+
 __device__ __forceinline__ float max_nan(float m, float v)   // torch.max semantics: NaN propagates
 {
     return (v > m || v != v) ? v : m;
 }
 
 // ------------------------------------------------------------------------------------------------
-// random_sample: out[b, n, :] = max_k F[b, idx[b, n, k], :]      (C % 4 == 0; lanes = float4 of a row)
-// a row of q = C/4 lanes owns one output point; K loads in flight per lane
+// random_sample: out[b, n, :] = max_k F[b, idx[b, n, k], :]      (lanes = 16-byte units of a row)
+// a group of q lanes owns one output point; K loads in flight per lane
 // ------------------------------------------------------------------------------------------------
-template <typename IdxT, int K>
+template <typename T, typename IdxT, int K>
 __global__ void __launch_bounds__(BLK)
-random_sample_pm_kernel(const float4* __restrict__ feat, const IdxT* __restrict__ idx, float4* __restrict__ out,
-                        int q /* C/4 */, int M, int Np, size_t total /* B*Np*q */)
+random_sample_pm_kernel(const void* __restrict__ feat, const IdxT* __restrict__ idx, void* __restrict__ out,
+                        int q, int M, int Np, size_t total /* B*Np*q */)
 {
+    using U = Unit<T>;
     const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
     if (t >= total) return;
     const size_t pt = t / q;                 // b*Np + n
-    const int c4 = (int)(t - pt * q);
+    const int c = (int)(t - pt * q);
     const size_t b = pt / Np;
     const IdxT* ip = idx + pt * K;
-    const float4* base = feat + b * (size_t)M * q + c4;
-    float4 v[K];
+    const size_t base = b * (size_t)M * q + c;
+    U v[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = base[(size_t)ip[k] * q];
-    float4 m = v[0];
+    for (int k = 0; k < K; ++k) v[k] = U::load(feat, base + (size_t)ip[k] * q);
+    U m = v[0];
 #pragma unroll
-    for (int k = 1; k < K; ++k) {
-        m.x = max_nan(m.x, v[k].x); m.y = max_nan(m.y, v[k].y); m.z = max_nan(m.z, v[k].z); m.w = max_nan(m.w, v[k].w);
-    }
-    out[t] = m;
+    for (int k = 1; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < U::VL; ++e) m.v[e] = max_nan(m.v[e], v[k].v[e]);
+    m.store(out, t);
 }
 
-template <typename IdxT>
+template <typename T, typename IdxT>
 __global__ void __launch_bounds__(BLK)
-random_sample_pm_anyk_kernel(const float4* __restrict__ feat, const IdxT* __restrict__ idx, float4* __restrict__ out,
+random_sample_pm_anyk_kernel(const void* __restrict__ feat, const IdxT* __restrict__ idx, void* __restrict__ out,
                              int q, int M, int Np, int K, size_t total)
 {
+    using U = Unit<T>;
     const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
     if (t >= total) return;
     const size_t pt = t / q;
-    const int c4 = (int)(t - pt * q);
+    const int c = (int)(t - pt * q);
     const size_t b = pt / Np;
     const IdxT* ip = idx + pt * K;
-    const float4* base = feat + b * (size_t)M * q + c4;
-    float4 m = base[(size_t)ip[0] * q];
+    const size_t base = b * (size_t)M * q + c;
+    U m = U::load(feat, base + (size_t)ip[0] * q);
     for (int k = 1; k < K; ++k) {
-        const float4 v = base[(size_t)ip[k] * q];
-        m.x = max_nan(m.x, v.x); m.y = max_nan(m.y, v.y); m.z = max_nan(m.z, v.z); m.w = max_nan(m.w, v.w);
+        const U v = U::load(feat, base + (size_t)ip[k] * q);
+#pragma unroll
+        for (int e = 0; e < U::VL; ++e) m.v[e] = max_nan(m.v[e], v.v[e]);
     }
-    out[t] = m;
+    m.store(out, t);
 }
 
 // ------------------------------------------------------------------------------------------------
-// gather_rows: out[b, u, :] = F[b, idx[b, u], :]
+// gather_rows: out[b, u, :] = F[b, idx[b, u], :]   (16-byte units are copied as they are)
 // ------------------------------------------------------------------------------------------------
 template <typename IdxT>
 __global__ void __launch_bounds__(BLK)
-gather_rows_pm_kernel(const float4* __restrict__ feat, const IdxT* __restrict__ idx, float4* __restrict__ out, int q, int M,
+gather_rows_pm_kernel(const uint4* __restrict__ feat, const IdxT* __restrict__ idx, uint4* __restrict__ out, int q, int M,
                       int U, size_t total /* B*U*q */)
 {
     const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
     if (t >= total) return;
     const size_t row = t / q;                // b*U + u
-    const int c4 = (int)(t - row * q);
+    const int c = (int)(t - row * q);
     const size_t b = row / U;
-    out[t] = feat[(b * M + (size_t)idx[row]) * q + c4];
+    out[t] = feat[(b * M + (size_t)idx[row]) * q + c];
 }
 
 // ------------------------------------------------------------------------------------------------
-// relative_pos_encoding, rows padded to 16 floats: out[b, n, k, 0:10] = [|p-q|, p-q, p, q], out[.., 10:16] = 0
+// relative_pos_encoding, rows padded to 16 channels: out[b, n, k, 0:10] = [|p-q|, p-q, p, q], out[.., 10:16] = 0
 // (the padding makes the row a legal K of the point-major shared MLP: lfa.mlp1's weight gets 6 zero columns).
-// Four lanes per (n, k) pair, one float4 each: a wave stores 1 KiB contiguous per instruction.
-// Arithmetic as RandLANet.py:216-223 / csrc/neighbour_ops.hip: separately rounded products and sums, IEEE sqrt.
+// One lane per 16-byte unit of a pair's row (4 units in fp32, 2 in bf16): a wave stores 1 KiB contiguous per instruction.
+// Arithmetic as RandLANet.py:216-223 / csrc/neighbour_ops.hip: separately rounded products and sums, IEEE sqrt (fp32).
 // ------------------------------------------------------------------------------------------------
-template <typename IdxT>
+template <typename T, typename IdxT>
 __global__ void __launch_bounds__(BLK)
-rel_pos_enc_pm_kernel(const float* __restrict__ xyz, const IdxT* __restrict__ idx, float4* __restrict__ out, int N, int K,
-                      size_t total /* B*N*K*4 */)
+rel_pos_enc_pm_kernel(const float* __restrict__ xyz, const IdxT* __restrict__ idx, void* __restrict__ out, int N, int K,
+                      size_t total /* B*N*K*units */)
 {
+    using U = Unit<T>;
+    constexpr int UNITS = 16 / U::VL;
     const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
     if (t >= total) return;
-    const size_t pair = t >> 2;
-    const int part = (int)(t & 3);
+    const size_t pair = t / UNITS;
+    const int part = (int)(t - pair * UNITS);
     const size_t pn = pair / K;              // b*N + n
     const size_t b = pn / N;
     const int j = (int)idx[pair];
@@ -113,49 +169,59 @@ rel_pos_enc_pm_kernel(const float* __restrict__ xyz, const IdxT* __restrict__ id
     const float px = p[0], py = p[1], pz = p[2];
     const float qx = q[0], qy = q[1], qz = q[2];
     const float dx = __fsub_rn(px, qx), dy = __fsub_rn(py, qy), dz = __fsub_rn(pz, qz);
-    float4 v;
-    if (part == 0) {
-        const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        v = make_float4(__fsqrt_rn(s), dx, dy, dz);
-    } else if (part == 1) {
-        v = make_float4(px, py, pz, qx);
-    } else if (part == 2) {
-        v = make_float4(qy, qz, 0.f, 0.f);
-    } else {
-        v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    const float row[16] = {__fsqrt_rn(s), dx, dy, dz, px, py, pz, qx, qy, qz, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    U u;
+#pragma unroll
+    for (int e = 0; e < U::VL; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < UNITS; ++w) v = part == w ? row[w * U::VL + e] : v;
+        u.v[e] = v;
     }
-    out[t] = v;
+    u.store(out, t);
 }
 
 // ------------------------------------------------------------------------------------------------
 // per-channel affine + residual + activation on [rows, C]:
 //     out = act( scale[c]*x + shift[c] + (res ? rscale[c]*res + rshift[c] : 0) ),   act(v) = max(v, slope*v)
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(BLK)
-affine_act_pm_kernel(const float4* __restrict__ x, const float4* __restrict__ scale, const float4* __restrict__ shift,
-                     const float4* __restrict__ res, const float4* __restrict__ rscale, const float4* __restrict__ rshift,
-                     float4* __restrict__ out, int q /* C/4 */, size_t total4, float slope)
+affine_act_pm_kernel(const void* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                     const void* __restrict__ res, const float* __restrict__ rscale, const float* __restrict__ rshift,
+                     void* __restrict__ out, int q /* units per row */, size_t total, float slope)
 {
+    using U = Unit<T>;
     const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
-    if (t >= total4) return;
-    const int c4 = (int)(t % q);
-    const float4 s = scale[c4], b = shift[c4];
-    float4 v = x[t];
-    v.x = v.x * s.x + b.x; v.y = v.y * s.y + b.y; v.z = v.z * s.z + b.z; v.w = v.w * s.w + b.w;
+    if (t >= total) return;
+    const int c = (int)(t % q);
+    float s[U::VL], b[U::VL];
+    load_params<U::VL>(scale, c, s);
+    load_params<U::VL>(shift, c, b);
+    U v = U::load(x, t);
+#pragma unroll
+    for (int e = 0; e < U::VL; ++e) v.v[e] = v.v[e] * s[e] + b[e];
     if (res) {
-        const float4 r = res[t];
+        const U r = U::load(res, t);
         if (rscale) {
-            const float4 rs = rscale[c4], rb = rshift[c4];
-            v.x += r.x * rs.x + rb.x; v.y += r.y * rs.y + rb.y; v.z += r.z * rs.z + rb.z; v.w += r.w * rs.w + rb.w;
+            float rs[U::VL], rb[U::VL];
+            load_params<U::VL>(rscale, c, rs);
+            load_params<U::VL>(rshift, c, rb);
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) v.v[e] += r.v[e] * rs[e] + rb[e];
         } else {
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) v.v[e] += r.v[e];
         }
     }
-    out[t] = make_float4(fmaxf(v.x, slope * v.x), fmaxf(v.y, slope * v.y), fmaxf(v.z, slope * v.z), fmaxf(v.w, slope * v.w));
+#pragma unroll
+    for (int e = 0; e < U::VL; ++e) v.v[e] = fmaxf(v.v[e], slope * v.v[e]);
+    v.store(out, t);
 }
 
 // ------------------------------------------------------------------------------------------------
-// bilinear resize of [B, IH, IW, C] -> [B, OH, OW, C]; lane = float4 of channels of one output pixel;
+// bilinear resize of [B, IH, IW, C] -> [B, OH, OW, C]; lane = one 16-byte unit of one output pixel;
 // ATen's upsample_bilinear2d arithmetic (area_pixel_compute_source_index + the lambda blend), as csrc/resize.hip
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float src_index(float scale, int dst, bool align_corners)
@@ -166,11 +232,13 @@ __device__ __forceinline__ float src_index(float scale, int dst, bool align_corn
 }
 
 // blockIdx.y = output row (b, oy): the two source rows and the vertical weights are wave-uniform scalars;
-// blockIdx.x * 256 + thread = (output column, channel quad) of that row, one float4 per thread
+// blockIdx.x * 256 + thread = (output column, unit) of that row
+template <typename T>
 __global__ void __launch_bounds__(BLK)
-bilinear_pm_kernel(const float4* __restrict__ in, float4* __restrict__ out, int IH, int IW, int OH, int OW, int q, int qshift,
+bilinear_pm_kernel(const void* __restrict__ in, void* __restrict__ out, int IH, int IW, int OH, int OW, int q, int qshift,
                    float rh, float rw, int align_corners)
 {
+    using U = Unit<T>;
     const int row = blockIdx.y;                  // b*OH + oy
     const int oy = row % OH, b = row / OH;
     const int t = blockIdx.x * BLK + threadIdx.x;
@@ -179,65 +247,71 @@ bilinear_pm_kernel(const float4* __restrict__ in, float4* __restrict__ out, int 
     const int h1 = (int)h1r;
     const int h1p = (h1 < IH - 1) ? 1 : 0;
     const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
-    const float4* r0 = in + ((size_t)b * IH + h1) * IW * q;
-    const float4* r1 = r0 + (size_t)h1p * IW * q;
+    const size_t r0 = ((size_t)b * IH + h1) * IW * q;
+    const size_t r1 = r0 + (size_t)h1p * IW * q;
     const int ox = qshift >= 0 ? (t >> qshift) : t / q;
-    const int c4 = t - ox * q;
+    const int c = t - ox * q;
     const float w1r = src_index(rw, ox, align_corners);
     const int w1 = (int)w1r;
     const int w1p = (w1 < IW - 1) ? 1 : 0;
     const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-    const int i0 = w1 * q + c4, i1 = i0 + w1p * q;
-    const float4 a = r0[i0], bq = r0[i1], c = r1[i0], d = r1[i1];
-    float4 v;
-    v.x = h0l * (w0l * a.x + w1l * bq.x) + h1l * (w0l * c.x + w1l * d.x);
-    v.y = h0l * (w0l * a.y + w1l * bq.y) + h1l * (w0l * c.y + w1l * d.y);
-    v.z = h0l * (w0l * a.z + w1l * bq.z) + h1l * (w0l * c.z + w1l * d.z);
-    v.w = h0l * (w0l * a.w + w1l * bq.w) + h1l * (w0l * c.w + w1l * d.w);
-    out[(size_t)row * OW * q + t] = v;
+    const int i0 = w1 * q + c, i1 = i0 + w1p * q;
+    const U a = U::load(in, r0 + i0), bq = U::load(in, r0 + i1), cc = U::load(in, r1 + i0), d = U::load(in, r1 + i1);
+    U v;
+#pragma unroll
+    for (int e = 0; e < U::VL; ++e) v.v[e] = h0l * (w0l * a.v[e] + w1l * bq.v[e]) + h1l * (w0l * cc.v[e] + w1l * d.v[e]);
+    v.store(out, (size_t)row * OW * q + t);
 }
 
 // ------------------------------------------------------------------------------------------------
-// pyramid pooling helpers (pspnet.py:7-31 rewritten as  W_x x + b + sum_i up_i((W_b,i W_i) pool_i(x)), model.py)
-//   psp_pool       all adaptive average pools of [B,H,W,C] in one launch -> [B, bins, C]: a workgroup per (frame, bin),
-//                  lanes = float4 of channels x pixel groups, partial sums meet in LDS
-//   psp_prior_sum  out[b,y,x,:] = sum_levels bilinear(z_level)[b,y,x,:] for z [B, bins, M] (align_corners=False)
+// pyramid pooling helpers (pspnet.py:7-31 rewritten as  W_x x + b + sum_i up_i((W_b,i W_i) pool_i(x)), forward_pm.py)
+//   psp_pool       all adaptive average pools of [B,H,W,C] -> fp32 [B, bins, C] (two passes through fp32 partial sums)
+//   psp_prior_sum  out[b,y,x,:] = sum_levels bilinear(z_level)[b,y,x,:] for fp32 z [B, bins, M] (align_corners=False)
 // ------------------------------------------------------------------------------------------------
 constexpr int PSP_MAX = 4;
 struct PspSizes { int n; int s[PSP_MAX]; int off[PSP_MAX + 1]; };
 
 // Pass 1: a workgroup per (frame, image row) reads that row once and leaves, for every level, the row's partial sum of
-// each horizontal bin: part[b, y, xbin, :], xbin running over the sum(s) horizontal bins of all levels.  Pass 2: a
+// each horizontal bin: part[b, y, xbin, :] (fp32), xbin running over the sum(s) horizontal bins of all levels.  Pass 2: a
 // workgroup per (frame, bin) adds the rows of its vertical extent.  (One workgroup per bin cannot pull the 1x1 level's
 // 10 MB through a single CU in reasonable time; this way the map is streamed once by H*B workgroups.)
+template <typename T>
 __global__ void __launch_bounds__(BLK)
-psp_rowsum_pm_kernel(const float4* __restrict__ x, float4* __restrict__ part, int H, int W, int q, int nx, PspSizes sz)
+psp_rowsum_pm_kernel(const void* __restrict__ x, float* __restrict__ part, int H, int W, int q, int nx, PspSizes sz)
 {
+    using U = Unit<T>;
     const int by = blockIdx.x;                               // b*H + y
-    const float4* src = x + (size_t)by * W * q;
-    for (int c4 = threadIdx.x; c4 < q; c4 += BLK) {
+    const size_t src = (size_t)by * W * q;
+    for (int c = threadIdx.x; c < q; c += BLK) {
         int slot = 0;
         for (int l = 0; l < sz.n; ++l) {
             const int s = sz.s[l];
             for (int j = 0; j < s; ++j, ++slot) {
                 const int x0 = (j * W) / s, x1 = ((j + 1) * W + s - 1) / s;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int xx = x0; xx < x1; xx += 8) {          // 8 independent loads in flight, surplus ones are dropped
-                    float4 v[8];
+                float acc[U::VL];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(xx + u, x1 - 1) * q + c4];
+                for (int e = 0; e < U::VL; ++e) acc[e] = 0.f;
+                for (int xx = x0; xx < x1; xx += 8) {          // 8 independent loads in flight, surplus ones are dropped
+                    U v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = U::load(x, src + (size_t)min(xx + u, x1 - 1) * q + c);
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (xx + u < x1) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                        if (xx + u < x1) {
+#pragma unroll
+                            for (int e = 0; e < U::VL; ++e) acc[e] += v[u].v[e];
+                        }
                 }
-                part[((size_t)by * nx + slot) * q + c4] = acc;
+                float* dst = part + (((size_t)by * nx + slot) * q + c) * U::VL;
+#pragma unroll
+                for (int e = 0; e < U::VL; ++e) dst[e] = acc[e];
             }
         }
     }
 }
 
 __global__ void __launch_bounds__(BLK)
-psp_binsum_pm_kernel(const float4* __restrict__ part, float4* __restrict__ out, int H, int W, int q, int nx, PspSizes sz)
+psp_binsum_pm_kernel(const float* __restrict__ part, float* __restrict__ out, int H, int W, int C, int nx, PspSizes sz)
 {
     const int total = sz.off[sz.n];
     const int b = blockIdx.x / total, bin = blockIdx.x % total;
@@ -249,34 +323,36 @@ psp_binsum_pm_kernel(const float4* __restrict__ part, float4* __restrict__ out, 
     const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s;
     const int x0 = (bxi * W) / s, x1 = ((bxi + 1) * W + s - 1) / s;
     const float inv = (float)((y1 - y0) * (x1 - x0));
-    for (int c4 = threadIdx.x; c4 < q; c4 += BLK) {
-        const float4* src = part + ((size_t)b * H * nx + xoff + bxi) * q + c4;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int y = y0; y < y1; ++y) {
-            const float4 v = src[(size_t)y * nx * q];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-        out[((size_t)b * total + bin) * q + c4] = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
+    for (int c = threadIdx.x; c < C; c += BLK) {
+        const float* src = part + ((size_t)b * H * nx + xoff + bxi) * C + c;
+        float acc = 0.f;
+        for (int y = y0; y < y1; ++y) acc += src[(size_t)y * nx * C];
+        out[((size_t)b * total + bin) * C + c] = acc / inv;
     }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(BLK)
-psp_prior_sum_pm_kernel(const float4* __restrict__ z, float4* __restrict__ out, int H, int W, int q, PspSizes sz,
+psp_prior_sum_pm_kernel(const float* __restrict__ z, void* __restrict__ out, int H, int W, int q, PspSizes sz,
                         size_t total /* B*H*W*q */)
 {
+    using U = Unit<T>;
     const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
     if (t >= total) return;
     const size_t pix = t / q;
-    const int c4 = (int)(t - pix * q);
+    const int c = (int)(t - pix * q);
     const int ox = (int)(pix % W);
     const size_t row = pix / W;
     const int oy = (int)(row % H);
     const size_t b = row / H;
-    const float4* zb = z + b * (size_t)sz.off[sz.n] * q + c4;
-    float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int M = q * U::VL;
+    const float* zb = z + b * (size_t)sz.off[sz.n] * M + (size_t)c * U::VL;
+    U res;
+#pragma unroll
+    for (int e = 0; e < U::VL; ++e) res.v[e] = 0.f;
     for (int l = 0; l < sz.n; ++l) {
         const int s = sz.s[l];
-        const float4* m = zb + (size_t)sz.off[l] * q;
+        const float* m = zb + (size_t)sz.off[l] * M;
         const float rh = (float)s / (float)H, rw = (float)s / (float)W;
         const float h1r = src_index(rh, oy, false);
         const int h1 = (int)h1r;
@@ -286,14 +362,14 @@ psp_prior_sum_pm_kernel(const float4* __restrict__ z, float4* __restrict__ out, 
         const int w1 = (int)w1r;
         const int w1p = (w1 < s - 1) ? 1 : 0;
         const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-        const float4 a = m[(size_t)(h1 * s + w1) * q], bq = m[(size_t)(h1 * s + w1 + w1p) * q];
-        const float4 c = m[(size_t)((h1 + h1p) * s + w1) * q], d = m[(size_t)((h1 + h1p) * s + w1 + w1p) * q];
-        res.x += h0l * (w0l * a.x + w1l * bq.x) + h1l * (w0l * c.x + w1l * d.x);
-        res.y += h0l * (w0l * a.y + w1l * bq.y) + h1l * (w0l * c.y + w1l * d.y);
-        res.z += h0l * (w0l * a.z + w1l * bq.z) + h1l * (w0l * c.z + w1l * d.z);
-        res.w += h0l * (w0l * a.w + w1l * bq.w) + h1l * (w0l * c.w + w1l * d.w);
+        const float* a = m + (size_t)(h1 * s + w1) * M;
+        const float* bq = m + (size_t)(h1 * s + w1 + w1p) * M;
+        const float* cc = m + (size_t)((h1 + h1p) * s + w1) * M;
+        const float* d = m + (size_t)((h1 + h1p) * s + w1 + w1p) * M;
+#pragma unroll
+        for (int e = 0; e < U::VL; ++e) res.v[e] += h0l * (w0l * a[e] + w1l * bq[e]) + h1l * (w0l * cc[e] + w1l * d[e]);
     }
-    out[t] = res;
+    res.store(out, t);
 }
 
 int fill_sizes(PspSizes& sz, const int* sizes, int n)
@@ -311,6 +387,8 @@ int fill_sizes(PspSizes& sz, const int* sizes, int n)
 
 bool bits_ok(int bits) { return bits == 32 || bits == 64; }
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool dt_ok(int dtype) { return dtype == 0 || dtype == 1; }
+int vl_of(int dtype) { return dtype ? 8 : 4; }
 
 }  // namespace
 }  // namespace ffb6d
@@ -320,89 +398,99 @@ using namespace ffb6d;
 #define DISPATCH_IDX(bits, IdxT, ...)                       \
     if ((bits) == 64) { using IdxT = int64_t; __VA_ARGS__ } \
     else { using IdxT = int32_t; __VA_ARGS__ }
+#define DISPATCH_DT(dtype, T, ...)                   \
+    if ((dtype) == 1) { using T = __bf16; __VA_ARGS__ } \
+    else { using T = float; __VA_ARGS__ }
 
 extern "C" {
 
-int ffb6d_random_sample_pm_f32(const float* feat, const void* idx, int idx_bits, float* out, int64_t B, int64_t M, int64_t C,
-                               int64_t Np, int K, ffb6d_stream_t stream)
+/* dtype of the row elements: 0 = float32, 1 = bfloat16 (channel counts must be multiples of 4 resp. 8) */
+
+int ffb6d_random_sample_pm(int dtype, const void* feat, const void* idx, int idx_bits, void* out, int64_t B, int64_t M, int64_t C,
+                           int64_t Np, int K, ffb6d_stream_t stream)
 {
-    FFB6D_REQUIRE(bits_ok(idx_bits), "random_sample_pm: idx_bits must be 32 or 64");
-    FFB6D_REQUIRE(B >= 0 && C >= 4 && (C & 3) == 0 && Np >= 0 && M >= 1 && K >= 1, "random_sample_pm: bad shape (C %% 4 == 0)");
+    FFB6D_REQUIRE(dt_ok(dtype) && bits_ok(idx_bits), "random_sample_pm: dtype must be 0/1, idx_bits 32 or 64");
+    const int VL = vl_of(dtype);
+    FFB6D_REQUIRE(B >= 0 && C >= VL && C % VL == 0 && Np >= 0 && M >= 1 && K >= 1, "random_sample_pm: bad shape (C %% %d == 0)", VL);
     if (B == 0 || Np == 0) return FFB6D_OK;
     FFB6D_REQUIRE(feat && idx && out && al16(feat) && al16(out), "random_sample_pm: null or unaligned pointer");
-    const int q = (int)(C / 4);
+    const int q = (int)(C / VL);
     const size_t total = (size_t)B * Np * q;
     const dim3 grid((unsigned)ceil_div((int64_t)total, BLK));
     hipStream_t st = as_stream(stream);
-    const float4* f4 = reinterpret_cast<const float4*>(feat);
-    float4* o4 = reinterpret_cast<float4*>(out);
-    DISPATCH_IDX(idx_bits, IdxT, {
+    DISPATCH_DT(dtype, T, DISPATCH_IDX(idx_bits, IdxT, {
         const IdxT* ip = static_cast<const IdxT*>(idx);
         if (K == 16)
-            hipLaunchKernelGGL((random_sample_pm_kernel<IdxT, 16>), grid, dim3(BLK), 0, st, f4, ip, o4, q, (int)M, (int)Np, total);
+            hipLaunchKernelGGL((random_sample_pm_kernel<T, IdxT, 16>), grid, dim3(BLK), 0, st, feat, ip, out, q, (int)M, (int)Np, total);
         else
-            hipLaunchKernelGGL((random_sample_pm_anyk_kernel<IdxT>), grid, dim3(BLK), 0, st, f4, ip, o4, q, (int)M, (int)Np, K, total);
-    })
+            hipLaunchKernelGGL((random_sample_pm_anyk_kernel<T, IdxT>), grid, dim3(BLK), 0, st, feat, ip, out, q, (int)M, (int)Np, K, total);
+    }))
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
 
-int ffb6d_gather_rows_pm_f32(const float* feat, const void* idx, int idx_bits, float* out, int64_t B, int64_t M, int64_t C,
-                             int64_t U, ffb6d_stream_t stream)
+int ffb6d_gather_rows_pm(int dtype, const void* feat, const void* idx, int idx_bits, void* out, int64_t B, int64_t M, int64_t C,
+                         int64_t U, ffb6d_stream_t stream)
 {
-    FFB6D_REQUIRE(bits_ok(idx_bits), "gather_rows_pm: idx_bits must be 32 or 64");
-    FFB6D_REQUIRE(B >= 0 && C >= 4 && (C & 3) == 0 && U >= 0 && M >= 1, "gather_rows_pm: bad shape (C %% 4 == 0)");
+    FFB6D_REQUIRE(dt_ok(dtype) && bits_ok(idx_bits), "gather_rows_pm: dtype must be 0/1, idx_bits 32 or 64");
+    const int VL = vl_of(dtype);
+    FFB6D_REQUIRE(B >= 0 && C >= VL && C % VL == 0 && U >= 0 && M >= 1, "gather_rows_pm: bad shape (C %% %d == 0)", VL);
     if (B == 0 || U == 0) return FFB6D_OK;
     FFB6D_REQUIRE(feat && idx && out && al16(feat) && al16(out), "gather_rows_pm: null or unaligned pointer");
-    const int q = (int)(C / 4);
+    const int q = (int)(C / VL);
     const size_t total = (size_t)B * U * q;
     DISPATCH_IDX(idx_bits, IdxT, {
         hipLaunchKernelGGL((gather_rows_pm_kernel<IdxT>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0,
-                           as_stream(stream), reinterpret_cast<const float4*>(feat), static_cast<const IdxT*>(idx),
-                           reinterpret_cast<float4*>(out), q, (int)M, (int)U, total);
+                           as_stream(stream), static_cast<const uint4*>(feat), static_cast<const IdxT*>(idx),
+                           static_cast<uint4*>(out), q, (int)M, (int)U, total);
     })
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
 
-int ffb6d_relative_pos_encoding_pm_f32(const float* xyz, const void* idx, int idx_bits, float* out, int64_t B, int64_t N, int K,
-                                       ffb6d_stream_t stream)
+int ffb6d_relative_pos_encoding_pm(int dtype, const float* xyz, const void* idx, int idx_bits, void* out, int64_t B, int64_t N, int K,
+                                   ffb6d_stream_t stream)
 {
-    FFB6D_REQUIRE(bits_ok(idx_bits), "relative_pos_encoding_pm: idx_bits must be 32 or 64");
+    FFB6D_REQUIRE(dt_ok(dtype) && bits_ok(idx_bits), "relative_pos_encoding_pm: dtype must be 0/1, idx_bits 32 or 64");
     FFB6D_REQUIRE(B >= 0 && N >= 0 && K >= 1, "relative_pos_encoding_pm: bad shape");
     if (B == 0 || N == 0) return FFB6D_OK;
     FFB6D_REQUIRE(xyz && idx && out && al16(out), "relative_pos_encoding_pm: null or unaligned pointer");
-    const size_t total = (size_t)B * N * K * 4;
-    DISPATCH_IDX(idx_bits, IdxT, {
-        hipLaunchKernelGGL((rel_pos_enc_pm_kernel<IdxT>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0,
-                           as_stream(stream), xyz, static_cast<const IdxT*>(idx), reinterpret_cast<float4*>(out), (int)N, K, total);
-    })
+    const size_t total = (size_t)B * N * K * (16 / vl_of(dtype));
+    DISPATCH_DT(dtype, T, DISPATCH_IDX(idx_bits, IdxT, {
+        hipLaunchKernelGGL((rel_pos_enc_pm_kernel<T, IdxT>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0,
+                           as_stream(stream), xyz, static_cast<const IdxT*>(idx), out, (int)N, K, total);
+    }))
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
 
-int ffb6d_affine_act_pm_f32(const float* x, const float* scale, const float* shift, const float* res, const float* rscale,
-                            const float* rshift, float* out, int64_t rows, int64_t C, int act, float slope, ffb6d_stream_t stream)
+int ffb6d_affine_act_pm(int dtype, const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
+                        const float* rshift, void* out, int64_t rows, int64_t C, int act, float slope, ffb6d_stream_t stream)
 {
-    FFB6D_REQUIRE(rows >= 0 && C >= 4 && (C & 3) == 0, "affine_act_pm: C must be a positive multiple of 4");
+    FFB6D_REQUIRE(dt_ok(dtype), "affine_act_pm: dtype must be 0 (f32) or 1 (bf16)");
+    const int VL = vl_of(dtype);
+    FFB6D_REQUIRE(rows >= 0 && C >= VL && C % VL == 0, "affine_act_pm: C must be a positive multiple of %d", VL);
     FFB6D_REQUIRE(act >= 0 && act <= 2, "affine_act_pm: act must be 0 (none), 1 (relu) or 2 (leaky/prelu with slope)");
     if (rows == 0) return FFB6D_OK;
     FFB6D_REQUIRE(x && scale && shift && out && (rscale == nullptr) == (rshift == nullptr), "affine_act_pm: null pointer");
     FFB6D_REQUIRE(al16(x) && al16(out) && al16(res) && al16(scale) && al16(shift) && al16(rscale) && al16(rshift),
                   "affine_act_pm: 16-byte aligned pointers expected");
-    const size_t total4 = (size_t)rows * (C / 4);
+    const size_t total = (size_t)rows * (C / VL);
     const float sl = act == 0 ? 1.f : (act == 1 ? 0.f : slope);
-    auto f4 = [](const float* p) { return reinterpret_cast<const float4*>(p); };
-    hipLaunchKernelGGL(affine_act_pm_kernel, dim3((unsigned)ceil_div((int64_t)total4, BLK)), dim3(BLK), 0, as_stream(stream), f4(x),
-                       f4(scale), f4(shift), f4(res), f4(rscale), f4(rshift), reinterpret_cast<float4*>(out), (int)(C / 4), total4, sl);
+    DISPATCH_DT(dtype, T, {
+        hipLaunchKernelGGL((affine_act_pm_kernel<T>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, as_stream(stream), x,
+                           scale, shift, res, rscale, rshift, out, (int)(C / VL), total, sl);
+    })
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
 
-int ffb6d_bilinear_resize_pm_f32(const float* in, float* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int64_t C,
-                                 int align_corners, ffb6d_stream_t stream)
+int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW, int64_t C,
+                             int align_corners, ffb6d_stream_t stream)
 {
-    FFB6D_REQUIRE(B >= 0 && IH >= 1 && IW >= 1 && OH >= 1 && OW >= 1 && C >= 4 && (C & 3) == 0, "bilinear_resize_pm: bad shape");
+    FFB6D_REQUIRE(dt_ok(dtype), "bilinear_resize_pm: dtype must be 0 (f32) or 1 (bf16)");
+    const int VL = vl_of(dtype);
+    FFB6D_REQUIRE(B >= 0 && IH >= 1 && IW >= 1 && OH >= 1 && OW >= 1 && C >= VL && C % VL == 0, "bilinear_resize_pm: bad shape");
     FFB6D_REQUIRE(IH < (1 << 24) && IW < (1 << 24) && OH < (1 << 24) && OW < (1 << 24), "bilinear_resize_pm: too large");
     if (B == 0) return FFB6D_OK;
     FFB6D_REQUIRE(in && out && al16(in) && al16(out), "bilinear_resize_pm: null or unaligned pointer");
@@ -414,14 +502,14 @@ int ffb6d_bilinear_resize_pm_f32(const float* in, float* out, int64_t B, int64_t
         rh = (float)IH / (float)OH;
         rw = (float)IW / (float)OW;
     }
-    FFB6D_REQUIRE(B * OH < (1LL << 31) && OW * (C / 4) < (1LL << 31), "bilinear_resize_pm: too large");
-    const int q = (int)(C / 4);
+    const int q = (int)(C / VL);
     int qshift = -1;
     if ((q & (q - 1)) == 0) for (qshift = 0; (1 << qshift) < q; ++qshift) {}
     FFB6D_REQUIRE(B * OH < 65536, "bilinear_resize_pm: B * OH must stay below 65536 (grid y)");
-    hipLaunchKernelGGL(bilinear_pm_kernel, dim3((unsigned)ceil_div(OW * (int64_t)q, BLK), (unsigned)(B * OH)), dim3(BLK), 0,
-                       as_stream(stream), reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), (int)IH, (int)IW,
-                       (int)OH, (int)OW, q, qshift, rh, rw, align_corners);
+    DISPATCH_DT(dtype, T, {
+        hipLaunchKernelGGL((bilinear_pm_kernel<T>), dim3((unsigned)ceil_div(OW * (int64_t)q, BLK), (unsigned)(B * OH)), dim3(BLK), 0,
+                           as_stream(stream), in, out, (int)IH, (int)IW, (int)OH, (int)OW, q, qshift, rh, rw, align_corners);
+    })
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
@@ -435,12 +523,14 @@ size_t ffb6d_psp_pool_pm_workspace_bytes(int64_t B, int64_t H, int64_t C, const 
     return (size_t)B * H * nx * C * sizeof(float);
 }
 
-int ffb6d_psp_pool_pm_f32(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, const int* sizes, int nsizes,
-                          void* workspace, size_t workspace_bytes, ffb6d_stream_t stream)
+int ffb6d_psp_pool_pm(int dtype, const void* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, const int* sizes, int nsizes,
+                      void* workspace, size_t workspace_bytes, ffb6d_stream_t stream)
 {
     PspSizes sz;
+    FFB6D_REQUIRE(dt_ok(dtype), "psp_pool_pm: dtype must be 0 (f32) or 1 (bf16)");
+    const int VL = vl_of(dtype);
     FFB6D_REQUIRE(fill_sizes(sz, sizes, nsizes) == 0, "psp_pool_pm: 1..4 pool sizes in [1,64] expected");
-    FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && C >= 4 && (C & 3) == 0, "psp_pool_pm: bad shape");
+    FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && C >= VL && C % VL == 0, "psp_pool_pm: bad shape");
     if (B == 0) return FFB6D_OK;
     FFB6D_REQUIRE(x && out && al16(x) && al16(out), "psp_pool_pm: null or unaligned pointer");
     const size_t need = ffb6d_psp_pool_pm_workspace_bytes(B, H, C, sizes, nsizes);
@@ -449,27 +539,33 @@ int ffb6d_psp_pool_pm_f32(const float* x, float* out, int64_t B, int64_t H, int6
                          workspace ? workspace_bytes : (size_t)0);
     int nx = 0;
     for (int i = 0; i < sz.n; ++i) nx += sz.s[i];
-    const int q = (int)(C / 4);
+    const int q = (int)(C / VL);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(psp_rowsum_pm_kernel, dim3((unsigned)(B * H)), dim3(BLK), 0, st, reinterpret_cast<const float4*>(x),
-                       static_cast<float4*>(workspace), (int)H, (int)W, q, nx, sz);
+    DISPATCH_DT(dtype, T, {
+        hipLaunchKernelGGL((psp_rowsum_pm_kernel<T>), dim3((unsigned)(B * H)), dim3(BLK), 0, st, x, static_cast<float*>(workspace),
+                           (int)H, (int)W, q, nx, sz);
+    })
     hipLaunchKernelGGL(psp_binsum_pm_kernel, dim3((unsigned)(B * sz.off[sz.n])), dim3(BLK), 0, st,
-                       static_cast<const float4*>(workspace), reinterpret_cast<float4*>(out), (int)H, (int)W, q, nx, sz);
+                       static_cast<const float*>(workspace), out, (int)H, (int)W, (int)C, nx, sz);
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
 
-int ffb6d_psp_prior_sum_pm_f32(const float* z, float* out, int64_t B, int64_t H, int64_t W, int64_t M, const int* sizes, int nsizes,
-                               ffb6d_stream_t stream)
+int ffb6d_psp_prior_sum_pm(int dtype, const float* z, void* out, int64_t B, int64_t H, int64_t W, int64_t M, const int* sizes,
+                           int nsizes, ffb6d_stream_t stream)
 {
     PspSizes sz;
+    FFB6D_REQUIRE(dt_ok(dtype), "psp_prior_sum_pm: dtype must be 0 (f32) or 1 (bf16)");
+    const int VL = vl_of(dtype);
     FFB6D_REQUIRE(fill_sizes(sz, sizes, nsizes) == 0, "psp_prior_sum_pm: 1..4 pool sizes in [1,64] expected");
-    FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && M >= 4 && (M & 3) == 0, "psp_prior_sum_pm: bad shape");
+    FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && M >= VL && M % VL == 0, "psp_prior_sum_pm: bad shape");
     if (B == 0) return FFB6D_OK;
-    FFB6D_REQUIRE(z && out && al16(z) && al16(out), "psp_prior_sum_pm: null or unaligned pointer");
-    const size_t total = (size_t)B * H * W * (M / 4);
-    hipLaunchKernelGGL(psp_prior_sum_pm_kernel, dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, as_stream(stream),
-                       reinterpret_cast<const float4*>(z), reinterpret_cast<float4*>(out), (int)H, (int)W, (int)(M / 4), sz, total);
+    FFB6D_REQUIRE(z && out && al16(out), "psp_prior_sum_pm: bad pointer");
+    const size_t total = (size_t)B * H * W * (M / VL);
+    DISPATCH_DT(dtype, T, {
+        hipLaunchKernelGGL((psp_prior_sum_pm_kernel<T>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, as_stream(stream),
+                           z, out, (int)H, (int)W, (int)(M / VL), sz, total);
+    })
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }

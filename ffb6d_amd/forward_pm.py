@@ -60,8 +60,12 @@ def mlp_sources(m):
     return src
 
 
-def folded(m, pad_k=None):
-    """(W [Cout, Cin(padded)], b [Cout]) of a model.SharedMLP: conv weight layout, eval-mode BatchNorm absorbed."""
+F32 = torch.float32
+
+
+def folded(m, pad_k=None, dt=F32):
+    """(W [Cout, Cin(padded)] of dtype `dt`, b [Cout] float32) of a model.SharedMLP: conv weight layout, eval-mode
+    BatchNorm absorbed (folded in fp32, rounded once when dt is bfloat16)."""
     def build():
         w = m.conv.weight.detach().reshape(m.conv.weight.shape[0], -1)
         if m.has_bn:
@@ -71,26 +75,26 @@ def folded(m, pad_k=None):
             b = bn.bias.detach() - bn.running_mean * scale
         else:
             b = m.conv.bias.detach()
-        return _pad_k(w, pad_k or w.shape[1]), b.contiguous()
-    return cached(m, "folded%s" % (pad_k or ""), mlp_sources(m), build)
+        return _pad_k(w, pad_k or w.shape[1]).to(dt), b.float().contiguous()
+    return cached(m, "folded%s%s" % (pad_k or "", dt), mlp_sources(m), build)
 
 
-def split(m, k1):
+def split(m, k1, dt=F32):
     """(W_a [Cout,k1], W_b [Cout,Cin-k1], b) for conv(cat(a, gather(b))) == W_a a + gather(W_b b)."""
     def build():
-        w, b = folded(m)
+        w, b = folded(m, dt=dt)
         return w[:, :k1].contiguous(), w[:, k1:].contiguous(), b
-    return cached(m, "split%d" % k1, mlp_sources(m), build)
+    return cached(m, "split%d%s" % (k1, dt), mlp_sources(m), build)
 
 
 def mlp(m, x1, x2=None, pad_k=None, **kw):
-    w, b = folded(m, pad_k)
+    w, b = folded(m, pad_k, x1.dtype)
     return ops_pm.mlp(x1, w, b, m.act_code, x2=x2, **kw)
 
 
-def fc_weight(att):
+def fc_weight(att, dt=F32):
     w = att.fc.weight
-    return cached(att, "fc", [w], lambda: w.detach().reshape(w.shape[0], -1).contiguous())
+    return cached(att, "fc%s" % dt, [w], lambda: w.detach().reshape(w.shape[0], -1).to(dt).contiguous())
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -98,29 +102,32 @@ def fc_weight(att):
 # ----------------------------------------------------------------------------------------------------
 def building_block(bb, xyz, f_pc, nei):
     """RandLANet.py:196-214 (Building_block.forward): f_pc [B,N,d/2] -> [B,N,d]."""
-    enc = ops_pm.relative_pos_encoding(xyz, nei)                             # [B,N,16,16] (10 used)
-    f_xyz = mlp(bb.mlp1, enc, pad_k=16)                                       # [B,N,16,d/2]
-    pooled = ops_pm.att_pool(f_pc, nei, f_xyz, fc_weight(bb.att_pooling_1))   # [B,N,d]
-    f_agg = mlp(bb.att_pooling_1.mlp, pooled)                                 # [B,N,d/2]
+    dt = f_pc.dtype
+    enc = ops_pm.relative_pos_encoding(xyz, nei, dtype=dt)                        # [B,N,16,16] (10 used)
+    f_xyz = mlp(bb.mlp1, enc, pad_k=16)                                            # [B,N,16,d/2]
+    pooled = ops_pm.att_pool(f_pc, nei, f_xyz, fc_weight(bb.att_pooling_1, dt))    # [B,N,d]
+    f_agg = mlp(bb.att_pooling_1.mlp, pooled)                                      # [B,N,d/2]
     f_xyz = mlp(bb.mlp2, f_xyz)
-    pooled = ops_pm.att_pool(f_agg, nei, f_xyz, fc_weight(bb.att_pooling_2))
+    pooled = ops_pm.att_pool(f_agg, nei, f_xyz, fc_weight(bb.att_pooling_2, dt))
     return mlp(bb.att_pooling_2.mlp, pooled)                                  # [B,N,d]
 
 
 def dilated_res_block(rb, feature, xyz, nei):
-    """RandLANet.py:179-184: leaky(mlp2(lfa(mlp1(f))) + shortcut(f)) with the sum as ONE GEMM over K = [lfa | f]."""
-    f = building_block(rb.lfa, xyz, mlp(rb.mlp1, feature), nei)
+    """RandLANet.py:179-184: leaky(mlp2(lfa(mlp1(f))) + shortcut(f)) with the sum as ONE GEMM over K = [lfa | f].
+    `feature` may carry zero-padded channels (the 8-channel stem output is stored 16 wide): weights are padded to match."""
+    kin, dt = feature.shape[-1], feature.dtype
+    f = building_block(rb.lfa, xyz, mlp(rb.mlp1, feature, pad_k=kin), nei)
 
     def build():
-        (w2, b2), (ws, bs) = folded(rb.mlp2), folded(rb.shortcut)
-        return torch.cat([w2, ws], dim=1).contiguous(), (b2 + bs).contiguous()
-    w, b = cached(rb, "res", mlp_sources(rb.mlp2) + mlp_sources(rb.shortcut), build)
+        (w2, b2), (ws, bs) = folded(rb.mlp2), folded(rb.shortcut, pad_k=kin)
+        return torch.cat([w2, ws], dim=1).to(dt).contiguous(), (b2 + bs).contiguous()
+    w, b = cached(rb, "res%d%s" % (kin, dt), mlp_sources(rb.mlp2) + mlp_sources(rb.shortcut), build)
     return ops_pm.mlp(f, w, b, ops.ACT_LEAKY, x2=feature)
 
 
 def decode(stage, skip, p_emb, interp_idx):
     """conv(cat(skip, interp(p))) (ffb6d.py:273-279,302-307) = W_a skip + gather(W_b p)."""
-    wa, wb, bias = split(stage, skip.shape[-1])
+    wa, wb, bias = split(stage, skip.shape[-1], skip.dtype)
     y = ops_pm.mlp(p_emb, wb)
     return ops_pm.mlp(skip, wa, bias, stage.act_code, gather=(y, interp_idx.reshape(interp_idx.shape[0], -1)))
 
@@ -130,7 +137,8 @@ def decode(stage, skip, p_emb, interp_idx):
 # ----------------------------------------------------------------------------------------------------
 def conv(x, c):
     """Dense convolution of a [B,H,W,C] map through MIOpen's NHWC path; returns [B,H',W',C']."""
-    w = cached(c, "cl", [c.weight], lambda: c.weight.detach().contiguous(memory_format=torch.channels_last))
+    w = cached(c, "cl%s" % x.dtype, [c.weight],
+               lambda: c.weight.detach().to(x.dtype).contiguous(memory_format=torch.channels_last))
     y = F.conv2d(x.permute(0, 3, 1, 2), w, None, c.stride, c.padding, c.dilation, c.groups)
     y = y.permute(0, 2, 3, 1)
     return y if y.is_contiguous() else y.contiguous()
@@ -159,13 +167,14 @@ def pyramid_pooling(pp, x):
                  for i, st in enumerate(pp.stages)]                                           # each [1024, 512]
         return prods, wb[:, len(pp.stages) * ch:].contiguous()
     prods, wx = cached(pp, "fold", [bw] + [st[1].weight for st in pp.stages], build)
-    pooled = ops_pm.psp_pool(x, sizes)                                                        # [B,50,512]
+    pooled = ops_pm.psp_pool(x, sizes)                                                        # [B,50,512] fp32
     zs, off = [], 0
-    for s, wl in zip(sizes, prods):
+    for s, wl in zip(sizes, prods):                                                           # 50 columns: fp32 in both precisions
         zs.append(ops_pm.mlp(pooled[:, off:off + s * s].contiguous(), wl))
         off += s * s
-    prior = ops_pm.psp_prior_sum(torch.cat(zs, dim=1), sizes, (h, w_))                        # [B,h,w,1024]
-    return ops_pm.mlp(x, wx, pp.bottleneck.bias.detach(), ops.ACT_RELU, add=prior)
+    prior = ops_pm.psp_prior_sum(torch.cat(zs, dim=1), sizes, (h, w_), dtype=x.dtype)         # [B,h,w,1024]
+    wx = cached(pp, "wx%s" % x.dtype, [bw], lambda: wx.to(x.dtype))
+    return ops_pm.mlp(x, wx, pp.bottleneck.bias.detach().float(), ops.ACT_RELU, add=prior)
 
 
 def up_block(ub, x):
@@ -187,8 +196,8 @@ def up_block(ub, x):
 def final_head(fh, x):
     """pspnet.py:108-112 `final`: Conv2d(64,64,1) + LogSoftmax(dim=1) as one GEMM with a log-softmax epilogue."""
     cv = fh[0]
-    w = cached(fh, "w", [cv.weight], lambda: cv.weight.detach().reshape(cv.out_channels, -1).contiguous())
-    return ops_pm.mlp(x, w, cv.bias.detach(), ops_pm.ACT_LOG_SOFTMAX)
+    w = cached(fh, "w%s" % x.dtype, [cv.weight], lambda: cv.weight.detach().reshape(cv.out_channels, -1).to(x.dtype).contiguous())
+    return ops_pm.mlp(x, w, cv.bias.detach().float(), ops_pm.ACT_LOG_SOFTMAX)
 
 
 def cnn_stage(stage, x):
@@ -225,6 +234,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
     """taps: optional dict that receives the two embeddings after every fusion stage (`rgb_emb_ds{i}`, `p_emb_ds{i}`,
     `rgb_emb_up{i}`, `p_emb_up{i}`), converted to the reference layout -- diagnostics / stage-level parity tests."""
     dev = inputs['rgb'].device
+    dt = torch.bfloat16 if getattr(net, "precision", "fp32") == "bf16" else torch.float32
     main = torch.cuda.current_stream(dev)
     side = net._side_stream(dev) if two_streams else main
     if two_streams:
@@ -251,7 +261,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
             p2r_idx.record_stream(main)
         # p2r on main: conv(cat(rgb0, interp(e))) = W_a rgb0 + gather(W_b e)
         e = mlp(pre_p2r[i], p0)
-        wa, wb, bias = split(fuse_p2r[i], c)
+        wa, wb, bias = split(fuse_p2r[i], c, dt)
         y = ops_pm.mlp(e, wb)
         rgb = ops_pm.mlp(rgb0, wa, bias, fuse_p2r[i].act_code, gather=(y, p2r_idx.reshape(B, -1)))
         with on_side():     # r2p: max over the 16 nearest pixels, then conv(cat(p0, pre(.))) as a two-source GEMM
@@ -260,14 +270,17 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
         return rgb, p
 
     # ---- stems ----
-    rgb = inputs['rgb'].contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)       # [B,H,W,3] view
+    rgb = inputs['rgb'].to(dt).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)   # [B,H,W,3] view
     y = ops_pm.affine_act_(conv(rgb, net.cnn_pre_stages[0]), *ops.bn_fold(net.cnn_pre_stages[1]), act=ops.ACT_RELU)
     rgb_emb = net.cnn_pre_stages[3](y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)                  # max pool, stays NHWC
     with on_side():
         raw = inputs['cld_rgb_nrm']                                                              # [B,9,N]
-        x0 = raw.new_zeros(raw.shape[0], raw.shape[2], (raw.shape[1] + 7) // 8 * 8)
+        x0 = torch.zeros(raw.shape[0], raw.shape[2], (raw.shape[1] + 15) // 16 * 16, dtype=dt, device=dev)
         x0[..., :raw.shape[1]] = raw.transpose(1, 2)
-        p_emb = mlp(net.rndla_pre_stages, x0, pad_k=x0.shape[-1])                                # [B,N,8]
+        # the 8-channel stem output is stored 16 wide (zero padding): a legal K for both precisions
+        c_pre = net.rndla_pre_stages.conv.weight.shape[0]
+        p_emb = torch.zeros(raw.shape[0], raw.shape[2], (c_pre + 15) // 16 * 16, dtype=dt, device=dev)
+        mlp(net.rndla_pre_stages, x0, pad_k=x0.shape[-1], out=p_emb[..., :c_pre])
 
     # ---- encoder ----
     ds_emb = []
@@ -284,7 +297,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
         ds_emb.append(p_emb)
         if taps is not None:
             torch.cuda.synchronize(dev)
-            taps['rgb_emb_ds%d' % i], taps['p_emb_ds%d' % i] = rgb_emb.permute(0, 3, 1, 2), p_emb.transpose(1, 2).unsqueeze(3)
+            taps['rgb_emb_ds%d' % i], taps['p_emb_ds%d' % i] = rgb_emb.permute(0, 3, 1, 2).float(), p_emb.transpose(1, 2).unsqueeze(3).float()
 
     # ---- decoder ----
     n_up = len(net.rndla_up_stages)
@@ -297,7 +310,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
                               inputs['r2p_up_nei_idx%d' % i])
         if taps is not None:
             torch.cuda.synchronize(dev)
-            taps['rgb_emb_up%d' % i], taps['p_emb_up%d' % i] = rgb_emb.permute(0, 3, 1, 2), p_emb.transpose(1, 2).unsqueeze(3)
+            taps['rgb_emb_up%d' % i], taps['p_emb_up%d' % i] = rgb_emb.permute(0, 3, 1, 2).float(), p_emb.transpose(1, 2).unsqueeze(3).float()
     rgb_emb = cnn_stage(net.cnn_up_stages[n_up - 1], rgb_emb)
     with on_side():
         p_emb = decode(net.rndla_up_stages[n_up - 1], ds_emb[0], p_emb, inputs['cld_interp_idx0'])
@@ -315,7 +328,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
         return y
 
     n = p_emb.shape[1]
-    end_points['pred_rgbd_segs'] = head(net.rgbd_seg_layer).transpose(1, 2).contiguous()                   # [B,n_cls,N]
-    end_points['pred_kp_ofs'] = head(net.kp_ofst_layer).view(B, n, net.n_kps, 3).permute(0, 2, 1, 3).contiguous()
-    end_points['pred_ctr_ofs'] = head(net.ctr_ofst_layer).view(B, n, 1, 3).permute(0, 2, 1, 3).contiguous()
+    end_points['pred_rgbd_segs'] = head(net.rgbd_seg_layer).float().transpose(1, 2).contiguous()           # [B,n_cls,N]
+    end_points['pred_kp_ofs'] = head(net.kp_ofst_layer).float().view(B, n, net.n_kps, 3).permute(0, 2, 1, 3).contiguous()
+    end_points['pred_ctr_ofs'] = head(net.ctr_ofst_layer).float().view(B, n, 1, 3).permute(0, 2, 1, 3).contiguous()
     return end_points

@@ -474,6 +474,9 @@ class FFB6D(nn.Module):
     # activation layout of the fused inference path: "pm" = point-major / pixel-major rows (forward_pm.py, default),
     # "cm" = the reference's channel-major layout on the first-generation kernels (kept for A/B measurements)
     layout = "pm"
+    # arithmetic of the fused point-major path: "fp32" (default, BASELINE configurations 2-4) or "bf16" (configuration 5:
+    # bfloat16 activations and weights, fp32 accumulation / BatchNorm / softmax arithmetic, fp32 end_points)
+    precision = "fp32"
 
     def _side_stream(self, device):
         st = getattr(self, "_side", None)

@@ -10,11 +10,19 @@ from . import _lib
 from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU, _idx, _need_gpu, _stream  # noqa: F401
 
 
+def _dt(*ts):
+    """dtype code of the row elements (0 = float32, 1 = bfloat16), the same for every tensor given."""
+    dts = {t.dtype for t in ts if t is not None}
+    if len(dts) != 1 or next(iter(dts)) not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"row operands must all be float32 or all bfloat16, got {sorted(map(str, dts))}")
+    return 1 if next(iter(dts)) == torch.bfloat16 else 0
+
+
 def rows_view(x):
     """[..., C] tensor whose leading dims are row-regular -> (2-d view [rows, C], row stride in floats)."""
     C = x.shape[-1]
     x2 = x.reshape(-1, C)
-    if x2.stride(1) != 1 or x2.data_ptr() % 16 or (x2.shape[0] > 1 and x2.stride(0) % 4):
+    if x2.stride(1) != 1 or x2.data_ptr() % 16 or (x2.shape[0] > 1 and (x2.stride(0) * x2.element_size()) % 16):
         x2 = x2.contiguous()
     return x2, (x2.stride(0) if x2.shape[0] > 1 else C)
 
@@ -33,8 +41,11 @@ def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gathe
     Returns [..., Cout] (or writes `out`, which may be a channel slice of a wider row buffer)."""
     _need_gpu(x1, w)
     lib = _lib.load()
-    if x1.dtype != torch.float32 or w.dtype != torch.float32:
-        raise TypeError("float32 expected")
+    dt = _dt(x1, w, x2, add, gather[0] if gather is not None else None, out)
+    tdt = x1.dtype
+    esz = x1.element_size()
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("bias stays float32 in both precisions")
     a, ld1 = rows_view(x1.detach())
     K1 = a.shape[1]
     xi, px, bits = None, 0, 0
@@ -77,20 +88,20 @@ def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gathe
         if y.shape[0] != rows or y.shape[1] != Cout:
             raise ValueError(f"add {tuple(add.shape)} does not match the output [{rows}, {Cout}]")
     if out is None:
-        out = torch.empty(tuple(lead) + (Cout,), dtype=torch.float32, device=x1.device)
+        out = torch.empty(tuple(lead) + (Cout,), dtype=tdt, device=x1.device)
     if out.stride(-1) != 1 or out.numel() != rows * Cout:
         raise ValueError("out must be [..., Cout] with contiguous channels")
     ldo = out.stride(-2) if out.dim() >= 2 and rows > 1 else Cout
     if out.dim() > 2 and any(out.stride(i) != out.stride(i + 1) * out.shape[i + 1] for i in range(out.dim() - 2)):
         raise ValueError("out must be row-regular (a channel slice of a contiguous row buffer is fine)")
-    nbytes = 4 * ((K1 + K2) * Cout + rows * (K1 + K2) + rows * Cout) + rows * (bits // 8) * ((gi is not None) + (xi is not None)) + \
-        (4 * (y.shape[0] if gi is None else rows) * Cout if y is not None else 0)
+    nbytes = esz * ((K1 + K2) * Cout + rows * (K1 + K2) + rows * Cout) + rows * (bits // 8) * ((gi is not None) + (xi is not None)) + \
+        (esz * (y.shape[0] if gi is None else rows) * Cout if y is not None else 0)
     if _lib.TRACER is not None:      # tag = the kernel instantiation a profile lists this launch under
         tile = int(tile_hint) if tile_hint > 0 else lib.ffb6d_mlp_pm_tile(rows, Cout, K1 + K2, int(act))
     else:
         tile = 0
-    with torch.cuda.device(x1.device), _lib.traced("mlp_pm", nbytes, (K1 + K2, Cout, rows, tile)):
-        rc = lib.ffb6d_mlp_pm_f32(w.data_ptr(), bias.data_ptr() if bias is not None else None,
+    with torch.cuda.device(x1.device), _lib.traced("mlp_pm", nbytes, (K1 + K2, Cout, rows, tile, dt)):
+        rc = (lib.ffb6d_mlp_pm_bf16 if dt else lib.ffb6d_mlp_pm_f32)(w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                   a.data_ptr(), K1, ld1, xi.data_ptr() if xi is not None else None, px,
                                   b.data_ptr() if b is not None else None, K2, ld2,
                                   y.data_ptr() if y is not None else None, ldy,
@@ -110,15 +121,16 @@ def att_pool(f, nei_idx, g, w_fc, out=None):
     K, C2 = g.shape[2], g.shape[3]
     if g.shape[:2] != (B, N) or nei_idx.shape != (B, N, K) or w_fc.shape != (C1 + C2, C1 + C2) or not w_fc.is_contiguous():
         raise ValueError(f"bad shapes {tuple(f.shape)} / {tuple(nei_idx.shape)} / {tuple(g.shape)} / {tuple(w_fc.shape)}")
+    dt = _dt(f, g, w_fc, out)
     f2, ldf = rows_view(f.detach())
     g2, ldg = rows_view(g.detach())
     idx, bits = _idx(nei_idx)
     d = C1 + C2
     if out is None:
-        out = torch.empty((B, N, d), dtype=torch.float32, device=f.device)
-    nbytes = 4 * (d * d + B * N * C1 + B * N * K * C2 + B * N * d) + (bits // 8) * B * N * K
-    with torch.cuda.device(f.device), _lib.traced("att_pool_pm", nbytes, (d, N)):
-        rc = lib.ffb6d_att_pool_pm_f32(w_fc.data_ptr(), f2.data_ptr(), C1, ldf, idx.data_ptr(), bits, g2.data_ptr(), C2, ldg,
+        out = torch.empty((B, N, d), dtype=f.dtype, device=f.device)
+    nbytes = f.element_size() * (d * d + B * N * C1 + B * N * K * C2 + B * N * d) + (bits // 8) * B * N * K
+    with torch.cuda.device(f.device), _lib.traced("att_pool_pm", nbytes, (d, N, dt)):
+        rc = (lib.ffb6d_att_pool_pm_bf16 if dt else lib.ffb6d_att_pool_pm_f32)(w_fc.data_ptr(), f2.data_ptr(), C1, ldf, idx.data_ptr(), bits, g2.data_ptr(), C2, ldg,
                                        out.data_ptr(), out.stride(-2), B, N, K, _stream(f))
     _lib.check(rc, "ffb6d_att_pool_pm_f32")
     return out
@@ -133,10 +145,10 @@ def random_sample(feature, pool_idx):
     B, M, C = f.shape
     Np, K = pool_idx.shape[1], pool_idx.shape[2]
     idx, bits = _idx(pool_idx)
-    out = torch.empty((B, Np, C), dtype=torch.float32, device=f.device)
-    nbytes = 4 * B * C * M + (bits // 8) * B * Np * K + 4 * B * C * Np
+    out = torch.empty((B, Np, C), dtype=f.dtype, device=f.device)
+    nbytes = f.element_size() * (B * C * M + B * C * Np) + (bits // 8) * B * Np * K
     with torch.cuda.device(f.device), _lib.traced("random_sample_pm", nbytes, (C, M, Np)):
-        rc = lib.ffb6d_random_sample_pm_f32(f.data_ptr(), idx.data_ptr(), bits, out.data_ptr(), B, M, C, Np, K, _stream(f))
+        rc = lib.ffb6d_random_sample_pm(_dt(f), f.data_ptr(), idx.data_ptr(), bits, out.data_ptr(), B, M, C, Np, K, _stream(f))
     _lib.check(rc, "ffb6d_random_sample_pm_f32")
     return out
 
@@ -151,26 +163,26 @@ def gather_rows(feature, idx):
     B, M, C = f.shape
     i, bits = _idx(idx.reshape(B, -1))
     U = i.shape[1]
-    out = torch.empty((B, U, C), dtype=torch.float32, device=f.device)
-    nbytes = 4 * B * C * M + (bits // 8) * B * U + 4 * B * C * U
+    out = torch.empty((B, U, C), dtype=f.dtype, device=f.device)
+    nbytes = f.element_size() * (B * C * M + B * C * U) + (bits // 8) * B * U
     with torch.cuda.device(f.device), _lib.traced("gather_rows_pm", nbytes, (C, M, U)):
-        rc = lib.ffb6d_gather_rows_pm_f32(f.data_ptr(), i.data_ptr(), bits, out.data_ptr(), B, M, C, U, _stream(f))
+        rc = lib.ffb6d_gather_rows_pm(_dt(f), f.data_ptr(), i.data_ptr(), bits, out.data_ptr(), B, M, C, U, _stream(f))
     _lib.check(rc, "ffb6d_gather_rows_pm_f32")
     return out
 
 
-def relative_pos_encoding(xyz, neigh_idx):
-    """relative_pos_encoding (RandLANet.py:216-223) as rows of 16 floats [dis, p-q, p, q, 0*6]: xyz [B,N,3],
-    neigh_idx [B,N,K] -> [B,N,K,16] (the zero padding makes the row a legal K of the point-major shared MLP)."""
+def relative_pos_encoding(xyz, neigh_idx, dtype=torch.float32):
+    """relative_pos_encoding (RandLANet.py:216-223) as rows of 16 channels [dis, p-q, p, q, 0*6]: xyz [B,N,3] float32,
+    neigh_idx [B,N,K] -> [B,N,K,16] of `dtype` (the zero padding makes the row a legal K of the point-major shared MLP)."""
     _need_gpu(xyz, neigh_idx)
     lib = _lib.load()
     x = xyz.detach().contiguous()
     idx, bits = _idx(neigh_idx)
     B, N, K = idx.shape
-    out = torch.empty((B, N, K, 16), dtype=torch.float32, device=x.device)
-    nbytes = 12 * B * N + (bits // 8) * B * N * K + 64 * B * N * K
+    out = torch.empty((B, N, K, 16), dtype=dtype, device=x.device)
+    nbytes = 12 * B * N + (bits // 8) * B * N * K + 16 * out.element_size() * B * N * K
     with torch.cuda.device(x.device), _lib.traced("relative_pos_encoding_pm", nbytes, (N,)):
-        rc = lib.ffb6d_relative_pos_encoding_pm_f32(x.data_ptr(), idx.data_ptr(), bits, out.data_ptr(), B, N, K, _stream(x))
+        rc = lib.ffb6d_relative_pos_encoding_pm(_dt(out), x.data_ptr(), idx.data_ptr(), bits, out.data_ptr(), B, N, K, _stream(x))
     _lib.check(rc, "ffb6d_relative_pos_encoding_pm_f32")
     return out
 
@@ -180,8 +192,9 @@ def affine_act_(x, scale, shift, act=ACT_NONE, slope=0.0, residual=None, res_aff
     BatchNorm / ReLU / PReLU / residual glue of the colour branch, extractors.py:49-63, pspnet.py:34-45)."""
     _need_gpu(x)
     lib = _lib.load()
-    if not x.is_contiguous() or x.dtype != torch.float32:
-        raise ValueError("affine_act_ needs a contiguous float32 tensor")
+    if not x.is_contiguous():
+        raise ValueError("affine_act_ needs a contiguous tensor")
+    dt = _dt(x, residual)
     C = x.shape[-1]
     rows = x.numel() // C
     r = rs = rb = None
@@ -191,9 +204,9 @@ def affine_act_(x, scale, shift, act=ACT_NONE, slope=0.0, residual=None, res_aff
             raise ValueError("residual shape mismatch")
         if res_affine is not None:
             rs, rb = res_affine
-    nbytes = 4 * x.numel() * (3 if r is not None else 2)
+    nbytes = x.element_size() * x.numel() * (3 if r is not None else 2)
     with torch.cuda.device(x.device), _lib.traced("affine_act_pm", nbytes, (C, rows)):
-        rc = lib.ffb6d_affine_act_pm_f32(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+        rc = lib.ffb6d_affine_act_pm(dt, x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                          r.data_ptr() if r is not None else None,
                                          rs.data_ptr() if rs is not None else None,
                                          rb.data_ptr() if rb is not None else None,
@@ -210,10 +223,10 @@ def bilinear_resize(x, size, align_corners):
     xc = xc if xc.is_contiguous() else xc.contiguous()
     B, IH, IW, C = xc.shape
     OH, OW = int(size[0]), int(size[1])
-    out = torch.empty((B, OH, OW, C), dtype=torch.float32, device=x.device)
-    nbytes = 4 * B * C * (IH * IW + OH * OW)
+    out = torch.empty((B, OH, OW, C), dtype=x.dtype, device=x.device)
+    nbytes = x.element_size() * B * C * (IH * IW + OH * OW)
     with torch.cuda.device(x.device), _lib.traced("bilinear_resize_pm", nbytes, (C, OH, OW)):
-        rc = lib.ffb6d_bilinear_resize_pm_f32(xc.data_ptr(), out.data_ptr(), B, IH, IW, OH, OW, C,
+        rc = lib.ffb6d_bilinear_resize_pm(_dt(xc), xc.data_ptr(), out.data_ptr(), B, IH, IW, OH, OW, C,
                                               1 if align_corners else 0, _stream(xc))
     _lib.check(rc, "ffb6d_bilinear_resize_pm_f32")
     return out
@@ -225,7 +238,7 @@ def _int_array(values):
 
 
 def psp_pool(x, sizes):
-    """All adaptive average pools of `sizes` of x [B,H,W,C] in one launch -> [B, sum(s*s), C]."""
+    """All adaptive average pools of `sizes` of x [B,H,W,C] (float32 or bfloat16) -> float32 [B, sum(s*s), C]."""
     _need_gpu(x)
     lib = _lib.load()
     xc = x.detach()
@@ -236,23 +249,24 @@ def psp_pool(x, sizes):
     sz = _int_array(sizes)
     wbytes = lib.ffb6d_psp_pool_pm_workspace_bytes(B, H, C, sz, len(sizes))
     ws = torch.empty((wbytes,), dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device), _lib.traced("psp_pool_pm", 4 * xc.numel() + 4 * out.numel(), (C, H * W)):
-        rc = lib.ffb6d_psp_pool_pm_f32(xc.data_ptr(), out.data_ptr(), B, H, W, C, sz, len(sizes), ws.data_ptr(), wbytes,
+    with torch.cuda.device(x.device), _lib.traced("psp_pool_pm", xc.element_size() * xc.numel() + 4 * out.numel(), (C, H * W)):
+        rc = lib.ffb6d_psp_pool_pm(_dt(xc), xc.data_ptr(), out.data_ptr(), B, H, W, C, sz, len(sizes), ws.data_ptr(), wbytes,
                                        _stream(xc))
     _lib.check(rc, "ffb6d_psp_pool_pm_f32")
     return out
 
 
-def psp_prior_sum(z, sizes, size):
-    """z [B, sum(s*s), M] -> [B,H,W,M] = sum over levels of the bilinear (align_corners=False) up-sampling to (H,W)."""
+def psp_prior_sum(z, sizes, size, dtype=torch.float32):
+    """float32 z [B, sum(s*s), M] -> [B,H,W,M] of `dtype` = sum over levels of the bilinear (align_corners=False)
+    up-sampling to (H,W)."""
     _need_gpu(z)
     lib = _lib.load()
-    zc = z.detach()
+    zc = z.detach().float()
     zc = zc if zc.is_contiguous() else zc.contiguous()
     B, _, M = zc.shape
     H, W = int(size[0]), int(size[1])
-    out = torch.empty((B, H, W, M), dtype=torch.float32, device=z.device)
-    with torch.cuda.device(z.device), _lib.traced("psp_prior_sum_pm", 4 * zc.numel() + 4 * out.numel(), (M, H * W)):
-        rc = lib.ffb6d_psp_prior_sum_pm_f32(zc.data_ptr(), out.data_ptr(), B, H, W, M, _int_array(sizes), len(sizes), _stream(zc))
+    out = torch.empty((B, H, W, M), dtype=dtype, device=z.device)
+    with torch.cuda.device(z.device), _lib.traced("psp_prior_sum_pm", 4 * zc.numel() + out.element_size() * out.numel(), (M, H * W)):
+        rc = lib.ffb6d_psp_prior_sum_pm(_dt(out), zc.data_ptr(), out.data_ptr(), B, H, W, M, _int_array(sizes), len(sizes), _stream(zc))
     _lib.check(rc, "ffb6d_psp_prior_sum_pm_f32")
     return out

@@ -150,31 +150,44 @@ int ffb6d_att_pool_pm_f32(const float* w_fc, const float* f, int64_t c1, int64_t
                           const float* g, int64_t c2, int64_t ldg, float* out, int64_t ldo, int64_t B, int64_t N, int K,
                           ffb6d_stream_t stream);
 
-/* FFB6D.random_sample (ffb6d.py:159-177): out[b,n,:] = max_k feat[b, idx[b,n,k], :]; feat [B,M,C], idx [B,Np,K], C % 4 == 0. */
-int ffb6d_random_sample_pm_f32(const float* feat, const void* idx, int idx_bits, float* out, int64_t B, int64_t M, int64_t C,
-                               int64_t Np, int K, ffb6d_stream_t stream);
+/* bf16 twins of the two GEMM-shaped operators (BASELINE.json configuration 5, mixed precision): activations, weights
+ * and the epilogue rows y are bfloat16, bias stays float32, accumulation and all epilogue arithmetic are fp32
+ * (v_mfma_f32_32x32x16_bf16); k1, k2 / c1, c2 must be multiples of 16. */
+int ffb6d_mlp_pm_bf16(const void* w, const float* bias, const void* x1, int64_t k1, int64_t ld1, const void* x1_idx,
+                      int64_t x1_rows_per_frame, const void* x2, int64_t k2, int64_t ld2, const void* y, int64_t ldy,
+                      const void* y_idx, int64_t y_rows_per_frame, int idx_bits, int64_t rows_per_frame, void* out,
+                      int64_t ldo, int64_t rows, int64_t cout, int act, int tile_hint, ffb6d_stream_t stream);
+int ffb6d_att_pool_pm_bf16(const void* w_fc, const void* f, int64_t c1, int64_t ldf, const void* nei, int idx_bits,
+                           const void* g, int64_t c2, int64_t ldg, void* out, int64_t ldo, int64_t B, int64_t N, int K,
+                           ffb6d_stream_t stream);
+
+/* Row operators below take `dtype`: 0 = float32 rows, 1 = bfloat16 rows (channel counts multiples of 4 resp. 8);
+ * arithmetic is fp32 either way. */
+/* FFB6D.random_sample (ffb6d.py:159-177): out[b,n,:] = max_k feat[b, idx[b,n,k], :]; feat [B,M,C], idx [B,Np,K]. */
+int ffb6d_random_sample_pm(int dtype, const void* feat, const void* idx, int idx_bits, void* out, int64_t B, int64_t M,
+                           int64_t C, int64_t Np, int K, ffb6d_stream_t stream);
 /* FFB6D.nearest_interpolation / the `choose` pick (ffb6d.py:179-194,309-312): out[b,u,:] = feat[b, idx[b,u], :]. */
-int ffb6d_gather_rows_pm_f32(const float* feat, const void* idx, int idx_bits, float* out, int64_t B, int64_t M, int64_t C,
-                             int64_t U, ffb6d_stream_t stream);
-/* relative_pos_encoding (RandLANet.py:216-223) as rows of 16 floats: [dis, p-q, p, q, 0 x 6]; out [B,N,K,16]. */
-int ffb6d_relative_pos_encoding_pm_f32(const float* xyz, const void* idx, int idx_bits, float* out, int64_t B, int64_t N,
-                                       int K, ffb6d_stream_t stream);
-/* out = act( scale[c]*x + shift[c] + (res ? (rscale ? rscale[c]*res + rshift[c] : res) : 0) ) on [rows, C]; act as
- * ffb6d_affine_act_f32.  In place (out == x) allowed. */
-int ffb6d_affine_act_pm_f32(const float* x, const float* scale, const float* shift, const float* res, const float* rscale,
-                            const float* rshift, float* out, int64_t rows, int64_t C, int act, float slope,
-                            ffb6d_stream_t stream);
+int ffb6d_gather_rows_pm(int dtype, const void* feat, const void* idx, int idx_bits, void* out, int64_t B, int64_t M,
+                         int64_t C, int64_t U, ffb6d_stream_t stream);
+/* relative_pos_encoding (RandLANet.py:216-223) as rows of 16 channels: [dis, p-q, p, q, 0 x 6]; xyz fp32, out [B,N,K,16]. */
+int ffb6d_relative_pos_encoding_pm(int dtype, const float* xyz, const void* idx, int idx_bits, void* out, int64_t B,
+                                   int64_t N, int K, ffb6d_stream_t stream);
+/* out = act( scale[c]*x + shift[c] + (res ? (rscale ? rscale[c]*res + rshift[c] : res) : 0) ) on [rows, C]; scale/shift
+ * fp32; act as ffb6d_affine_act_f32.  In place (out == x) allowed. */
+int ffb6d_affine_act_pm(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                        const float* rscale, const float* rshift, void* out, int64_t rows, int64_t C, int act, float slope,
+                        ffb6d_stream_t stream);
 /* Bilinear resize [B,IH,IW,C] -> [B,OH,OW,C] (ATen upsample_bilinear2d arithmetic; pspnet.py:24-28,37-42). */
-int ffb6d_bilinear_resize_pm_f32(const float* in, float* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
-                                 int64_t C, int align_corners, ffb6d_stream_t stream);
-/* All adaptive average pools of `sizes` of x [B,H,W,C] -> [B, sum(s*s), C] (bins of sizes[0] first, row-major in a level).
- * Two passes (row partial sums, then bins) through a workspace of ffb6d_psp_pool_pm_workspace_bytes(...) bytes. */
+int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
+                             int64_t C, int align_corners, ffb6d_stream_t stream);
+/* All adaptive average pools of `sizes` of x [B,H,W,C] -> float32 [B, sum(s*s), C] (bins of sizes[0] first, row-major in a
+ * level).  Two passes (row partial sums, then bins) through a workspace of ffb6d_psp_pool_pm_workspace_bytes(...) bytes. */
 size_t ffb6d_psp_pool_pm_workspace_bytes(int64_t B, int64_t H, int64_t C, const int* sizes, int nsizes);
-int ffb6d_psp_pool_pm_f32(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, const int* sizes,
-                          int nsizes, void* workspace, size_t workspace_bytes, ffb6d_stream_t stream);
-/* out[b,y,x,:] = sum over levels of the bilinear (align_corners = 0) up-sampling of z [B, sum(s*s), M] to (H,W). */
-int ffb6d_psp_prior_sum_pm_f32(const float* z, float* out, int64_t B, int64_t H, int64_t W, int64_t M, const int* sizes,
-                               int nsizes, ffb6d_stream_t stream);
+int ffb6d_psp_pool_pm(int dtype, const void* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, const int* sizes,
+                      int nsizes, void* workspace, size_t workspace_bytes, ffb6d_stream_t stream);
+/* out[b,y,x,:] = sum over levels of the bilinear (align_corners = 0) up-sampling of float32 z [B, sum(s*s), M] to (H,W). */
+int ffb6d_psp_prior_sum_pm(int dtype, const float* z, void* out, int64_t B, int64_t H, int64_t W, int64_t M, const int* sizes,
+                           int nsizes, ffb6d_stream_t stream);
 
 /* Attentive pooling with the score GEMM fused in (Att_pooling.forward, RandLANet.py:243-248, up to
  * the pooled tensor): scores = W_fc * S over the feature set S = cat(x1 [B,k1,N,16], x2 [B,k2,N,16]),

@@ -99,6 +99,38 @@ def test_every_fusion_stage_matches_plain_torch(device, cfg):
         assert_close_scaled(taps[k].cpu().numpy(), ref_taps[k].cpu().numpy(), HOT_TOL, (cfg, k))
 
 
+# bf16 bar (BASELINE.json configuration 5: bfloat16 activations / weights, fp32 accumulation): ~110 layers each rounding
+# its output to 8 significant bits.  Stated tolerance: max error <= 5 % and mean error <= 0.8 % of the tensor's range against
+# the fp32 plain-torch restatement, per output tensor and per fusion stage (measured values are printed).
+BF16_MAX, BF16_MEAN = 5e-2, 8e-3
+
+
+@pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (5, 2, 12288, 480, 640, 22)])
+def test_bf16_forward_matches_fp32_oracle_at_bf16_tolerance(device, cfg):
+    from oracle import forward_ref
+    config, bs, n_pts, h, w, n_cls = cfg
+    frames = synth.make_batch(config, bs, n_points=n_pts, height=h, width=w)
+    net = build(n_cls, n_pts, device)
+    net.precision = "bf16"
+    inputs = pyramid.frames_to_device(frames, device)
+    taps, ref_taps = {}, {}
+    with torch.no_grad():
+        ep = net(inputs, taps=taps)
+        ref = forward_ref.ffb6d_forward(dict(net.state_dict()), inputs, taps=ref_taps)
+    for k, want in list(ref.items()) + [(k, ref_taps[k]) for k in sorted(ref_taps)]:
+        got = ep[k] if k in ep else taps[k]
+        assert got.dtype == torch.float32 and got.shape == want.shape
+        scale = float(want.abs().max())
+        err = (got - want).abs()
+        print(cfg, k, "bf16 max err / range %.3e  mean err / range %.3e" % (float(err.max()) / scale, float(err.mean()) / scale))
+        assert float(err.max()) <= BF16_MAX * scale and float(err.mean()) <= BF16_MEAN * scale, k
+    net.precision = "fp32"                                   # and the same module answers in fp32 again (per-dtype weight caches)
+    with torch.no_grad():
+        ep32 = net(inputs)
+    for k in ref:
+        assert_close_scaled(ep32[k].cpu().numpy(), ref[k].cpu().numpy(), HOT_TOL, (cfg, k, "fp32 after bf16"))
+
+
 def test_weight_updates_reach_the_fused_kernels(device):
     """Stale-cache guard (folded / split / padded / channels-last weights are cached per module): a model that already
     ran in eval() and then gets other weights -- load_state_dict, an in-place edit -- must answer like a fresh model."""

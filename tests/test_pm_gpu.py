@@ -190,3 +190,99 @@ def test_att_pool_pm_matches_fp64_reference(device, B, N, C1, C2, dt):
     want = (S * scores).sum(dim=2).float()
     got = ops_pm.att_pool(f.to(device), nei.to(device).to(dt), pair.to(device), w.to(device)).cpu()
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bfloat16 rows (BASELINE.json configuration 5: mixed precision).  References are computed in float64 FROM THE SAME
+# bf16-rounded operands, so what is checked is the kernel (fp32 accumulation / arithmetic, one rounding at the store):
+# |err| <= 2^-8 * |want| (half an ulp of bf16 is 2^-9) + a small absolute term for cancellation.
+# ---------------------------------------------------------------------------------------------------------------
+BF = torch.bfloat16
+
+
+def _close_bf16(got, want, what=""):
+    got, want = got.double(), want.double()
+    tol = 2.0 ** -8 * want.abs() + 2.0 ** -8 * float(want.abs().mean())
+    bad = (got - want).abs() > tol
+    assert not bool(bad.any()), (what, float((got - want).abs().max()), float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", [
+    (2, 12288, 64, 64, 128, 1, 0, 0), (1, 4800, 1024, 0, 1024, 1, 48, 0), (8, 48, 1024, 0, 512, 1, 0, 0),
+    (8, 192, 512, 256, 256, 2, 0, 0), (1, 12288, 128, 0, 22, 0, 0, 0), (3, 301, 32, 16, 40, 1, 13, 0),
+    (1, 196608, 16, 0, 16, 2, 0, 0), (1, 4800, 512, 0, 1024, 1, -1, 0)] + [(2, 777, 48, 32, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)])
+def test_mlp_pm_bf16(device, B, P, K1, K2, Cout, act, py, hint):
+    g = torch.Generator().manual_seed(K1 + Cout + P)
+    r = lambda *s: torch.randn(*s, generator=g).to(BF)                               # noqa: E731
+    x1, x2 = r(B, P, K1), (r(B, P, K2) if K2 else None)
+    w = (torch.randn(Cout, K1 + K2, generator=g) / (K1 + K2) ** 0.5).to(BF)
+    bias = torch.randn(Cout, generator=g)
+    gather = (r(B, py, Cout), torch.randint(0, py, (B, P), generator=g)) if py > 0 else None
+    add = r(B, P, Cout) if py < 0 else None
+    want = _ref(x1.double(), w.double(), bias, act, None if x2 is None else x2.double(), None if add is None else add.double(),
+                None if gather is None else (gather[0].double(), gather[1]))
+    d = lambda t: None if t is None else t.to(device)                                 # noqa: E731
+    got = ops_pm.mlp(d(x1), d(w), d(bias), act, x2=d(x2), add=d(add),
+                     gather=None if gather is None else (d(gather[0]), d(gather[1])), tile_hint=hint).cpu()
+    assert got.dtype == BF and got.shape == want.shape
+    _close_bf16(got, want, (K1, K2, Cout))
+
+
+def test_att_pool_and_log_softmax_bf16(device):
+    g = torch.Generator().manual_seed(4)
+    for B, N, C1, C2 in ((2, 1000, 16, 16), (1, 192, 64, 64), (2, 48, 128, 128)):
+        f = torch.randn(B, N, C1, generator=g).to(BF)
+        nei = torch.randint(0, N, (B, N, 16), generator=g)
+        pair = torch.randn(B, N, 16, C2, generator=g).to(BF)
+        d_ = C1 + C2
+        w = (torch.randn(d_, d_, generator=g) / d_ ** 0.5 * 3).to(BF)
+        S = torch.cat([torch.gather(f, 1, nei.reshape(B, -1, 1).expand(-1, -1, C1)).view(B, N, 16, C1), pair], dim=3).double()
+        want = (S * torch.softmax(S @ w.double().t(), dim=2)).sum(dim=2)
+        got = ops_pm.att_pool(f.to(device), nei.to(device), pair.to(device), w.to(device)).cpu()
+        assert got.dtype == BF
+        _close_bf16(got, want, ("att", C1))
+    x = torch.randn(3, 350, 64, generator=g).to(BF)
+    wf, bf = (torch.randn(64, 64, generator=g) / 8).to(BF), torch.randn(64, generator=g)
+    want = torch.log_softmax(x.double() @ wf.double().t() + bf.double(), dim=-1)
+    got = ops_pm.mlp(x.to(device), wf.to(device), bf.to(device), ops_pm.ACT_LOG_SOFTMAX).cpu()
+    _close_bf16(got, want, "log_softmax")
+
+
+def test_row_operators_bf16(device):
+    """gathers / max pooling bit exact on bf16 rows; affine, bilinear, pyramid pooling and position encoding equal to the
+    float64 evaluation of the same bf16-rounded inputs up to the final rounding."""
+    g = torch.Generator().manual_seed(6)
+    F = torch.nn.functional
+    d = lambda t: t.to(device)                                                       # noqa: E731
+    f = torch.randn(2, 500, 64, generator=g).to(BF)
+    idx = torch.randint(0, 500, (2, 120, 16), generator=g)
+    want = torch.gather(f, 1, idx.reshape(2, -1, 1).expand(-1, -1, 64)).view(2, 120, 16, 64).float().max(dim=2).values.to(BF)
+    assert torch.equal(ops_pm.random_sample(d(f), d(idx)).cpu(), want)
+    up = torch.randint(0, 500, (2, 333), generator=g)
+    assert torch.equal(ops_pm.gather_rows(d(f), d(up)).cpu(), torch.gather(f, 1, up.unsqueeze(2).expand(-1, -1, 64)))
+    x = torch.randn(2, 12, 16, 64, generator=g).to(BF)
+    sc, sh = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    res = torch.randn(2, 12, 16, 64, generator=g).to(BF)
+    want = F.relu(x.double() * sc.double() + sh.double() + res.double())
+    _close_bf16(ops_pm.affine_act_(d(x).clone(), d(sc), d(sh), ops.ACT_RELU, residual=d(res)).cpu(), want, "affine")
+    want = F.interpolate(x.double().permute(0, 3, 1, 2), size=(24, 32), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    _close_bf16(ops_pm.bilinear_resize(d(x), (24, 32), True).cpu(), want, "bilinear")
+    sizes = (1, 2, 3, 6)
+    xx = torch.randn(2, 60, 80, 32, generator=g).to(BF)
+    want = torch.cat([F.adaptive_avg_pool2d(xx.double().permute(0, 3, 1, 2), s).flatten(2) for s in sizes], dim=2).transpose(1, 2)
+    got = ops_pm.psp_pool(d(xx), sizes).cpu()
+    assert got.dtype == torch.float32
+    torch.testing.assert_close(got.double(), want.contiguous(), rtol=1e-5, atol=1e-5)
+    z = torch.randn(2, 50, 16, generator=g)
+    want, off = 0, 0
+    for s in sizes:
+        want = want + F.interpolate(z[:, off:off + s * s].double().transpose(1, 2).reshape(2, 16, s, s), size=(60, 80), mode="bilinear",
+                                    align_corners=False)
+        off += s * s
+    _close_bf16(ops_pm.psp_prior_sum(d(z), sizes, (60, 80), dtype=BF).cpu(), want.permute(0, 2, 3, 1), "prior")
+    from oracle import ops_ref
+    xyz = torch.rand(2, 300, 3, generator=g)
+    nei = torch.randint(0, 300, (2, 300, 16), generator=g)
+    got = ops_pm.relative_pos_encoding(d(xyz), d(nei), dtype=BF).cpu()
+    assert got.shape == (2, 300, 16, 16) and (got[..., 10:] == 0).all()
+    assert torch.equal(got[..., :10], ops_ref.relative_pos_encoding(xyz, nei).to(BF))
