@@ -4,6 +4,8 @@
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            (no launcher: re-executes itself under torch.distributed.run, N ranks)
+    python bench.py --config 4 | --config 5  (BASELINE configs: N=24576 fp32 | bs=16 bf16 mixed precision)
 
 A *step* is one pass of the hot path over one batch of synthetic RGB-D frames that is already
 resident in HBM: the on-device index pyramid (the 22 exact-KNN searches per frame that the
@@ -14,8 +16,8 @@ ranks every rank runs its own batch of 8 (weak scaling, no data-path collective:
 are independent in the forward pass -- SURVEY.md section 8e); value = total frames / max-over-ranks time.
 
 The JSON line also carries
-  roofline      achieved algorithmic GB/s of the dominant hand-written kernel, measured live with
-                HIP events on its launch stream during the timed steps;
+  roofline      achieved algorithmic TFLOP/s (MFMA-bound launches) or GB/s (HBM-bound ones) of the dominant
+                hand-written kernel, measured live with HIP events on its launch stream during the timed steps;
   cpu_baseline  the CPU oracle path (reference nanoflann from oracle/_ref when present, else the
                 C restatement, + the plain-torch forward of oracle/forward_ref.py) timed on this
                 host's cores on a bounded sample (a few single frames).
@@ -398,7 +400,8 @@ def main():
         if r:
             traffic = None
             pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc_file):      # HBM bytes per launch measured offline with rocprofv3 --pmc
+            # HBM bytes per launch measured offline with rocprofv3 --pmc on the default workload (config 2, fp32, pm)
+            if os.path.exists(pmc_file) and args.precision == "fp32" and args.layout == "pm" and args.config == 2:
                 with open(pmc_file) as fh:
                     table = json.load(fh)
                     key = roof_op.replace(",mfma>", ">").replace(",hbm>", ">")

@@ -52,7 +52,7 @@ random_sample_kernel(const float* __restrict__ feat, const IdxT* __restrict__ id
         int am = ii[0];
 #pragma unroll
         for (int k = 1; k < K; ++k)
-            if (v[k] > m) { m = v[k]; am = ii[k]; }
+            if (v[k] > m || v[k] != v[k]) { m = v[k]; am = ii[k]; }     // torch.max: NaN propagates
         const size_t o = ((size_t)b * C + c) * Np + n;
         out[o] = m;
         if (arg) arg[o] = am;
@@ -64,12 +64,17 @@ random_sample_kernel(const float* __restrict__ feat, const IdxT* __restrict__ id
 // the 16 addresses of a row fall into 4-5 cache lines instead of 16 different ones (one lane per
 // point makes every lane of a gather hit its own line); the max over the row is four row_ror DPP
 // steps.  Lane (c & 15) keeps the result of channel c, so results leave as one store per 16 channels.
+__device__ __forceinline__ float nan_max(float a, float b)   // torch.max semantics: a NaN operand wins
+{
+    return (a != a) ? a : ((b > a || b != b) ? b : a);
+}
+
 __device__ __forceinline__ float row16_max_dpp(float v)
 {
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));  // row_ror:8
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));  // row_ror:4
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)));  // row_ror:2
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)));  // row_ror:1
+    v = nan_max(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));  // row_ror:8
+    v = nan_max(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));  // row_ror:4
+    v = nan_max(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)));  // row_ror:2
+    v = nan_max(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)));  // row_ror:1
     return v;
 }
 
@@ -122,7 +127,7 @@ random_sample_anyk_kernel(const float* __restrict__ feat, const IdxT* __restrict
         for (int k = 1; k < K; ++k) {
             const int i = (int)ip[k];
             const float v = row[i];
-            if (v > m) { m = v; am = i; }
+            if (v > m || v != v) { m = v; am = i; }                    // torch.max: NaN propagates
         }
         const size_t o = ((size_t)b * C + c) * Np + n;
         out[o] = m;

@@ -339,7 +339,9 @@ shared_mlp_kernel(const MlpParams p)
 // branches) is a separate phase of the loop that the compiler cannot mix into the MFMA stream, and
 // co-resident workgroups run in lock-step, so their refill phases coincide.
 // (measured alternatives that did not help: BK = 32 with two workgroups per CU, s_setprio around the
-// MFMA groups -- scripts/bench_mlp_ab.py.)  Here the k-loop body
+// MFMA groups, and a third-generation k-loop with LDS-direct loads into three LDS stages + hand-placed vmcnt
+// (validated on hardware at the start of round 2, profiles/r02_shared_mlp_lds_ab.txt: bit-identical, within +-3 % on
+// the large layers) -- removed again.  The point-major path (csrc/mlp_pm.hip) superseded this kernel as the default.)  Here the k-loop body
 // is ONE basic block: operands come through buffer loads (hardware range check returns 0 outside
 // [0, num_records) -> no branches for the K tail or the end of a source), the refill is issued
 // unconditionally (the surplus loads of the last steps are out of range = free zeros) and is
@@ -465,177 +467,6 @@ shared_mlp_pipe_kernel(const MlpParams p)
         }
         __syncthreads();
     }
-
-    const float* yg = p.yg ? p.yg + (size_t)b * p.yg_bs : nullptr;
-    float* out = p.out + (size_t)b * p.out_bs;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = p0 + wn * (TN * 32) + j * 32 + l31;
-        if (col >= p.P) continue;
-        long long gi = 0;
-        if (yg) {
-            gi = p.idx64 ? static_cast<const long long*>(p.gidx)[(size_t)b * p.P + col]
-                         : (long long)static_cast<const int*>(p.gidx)[(size_t)b * p.P + col];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m < p.cout) {
-                    float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[m];
-                    if (yg) v += yg[(size_t)m * p.py + gi];
-                    out[(size_t)m * p.P + col] = activate(v, p.act);
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// EXPERIMENTAL, opt-in (FFB6D_MLP_PIPE=2): third-generation k-loop with LDS-direct loads.
-// Written and compile-checked at the end of round 1 (no GPU minutes left to run it): NOT on the default
-// path, NOT yet validated on hardware; `python scripts/bench_mlp_ab.py 1 2` is the A/B for it.
-//
-// Why: the pipelined kernel above still waits (s_waitcnt vmcnt(0)) for loads issued only ~6 MFMA groups
-// earlier, and hipcc cannot be made to keep a second register staging set in flight.  Here the tile
-// images go global -> LDS without passing through VGPRs (`buffer_load_dwordx4 ... lds`: lane l of a wave
-// writes 16 bytes at M0 + 16*l, which IS this kernel's tile layout: LDS offset = 16 * thread), into three
-// LDS stages; the loads of stage k+2 are issued at the top of iteration k and only `s_waitcnt vmcnt(4)`
-// (stage k+1 landed, the four loads of stage k+2 still in flight) precedes the barrier.  hipcc does not
-// count inline-asm memory operations, so the waits are placed by hand; the fragment reads (ds_read) stay
-// compiler-generated and compiler-counted.
-// ---------------------------------------------------------------------------------------------
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ i32x4 make_srd(const void* base, int num_bytes)
-{
-    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-    return i32x4{static_cast<int>(static_cast<unsigned>(a)), static_cast<int>(static_cast<unsigned>(a >> 32) & 0xffffu),
-                 num_bytes, 0x00020000};
-}
-
-// 16 bytes per lane from buffer offset `voff` to LDS byte address lds_addr + 16 * lane (lds_addr wave-uniform)
-__device__ __forceinline__ void buffer_load_lds_x4(i32x4 rsrc, int voff, unsigned lds_addr)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(lds_addr)
-                 : "memory");
-}
-
-template <int BM>
-__global__ void __launch_bounds__(BLK)
-shared_mlp_lds_kernel(const MlpParams p)
-{
-    static_assert(BM == 128, "one 128 x 128 x 16 configuration");
-    constexpr int STAGES = 3;
-    constexpr int WN = 2, TM = 2, TN = 2;             // 2 x 2 waves, each 2 x 2 MFMA tiles of 32 x 32
-    constexpr int A_F4 = BK * BM / 4 / BLK;          // 2 loads per thread and stage
-    constexpr int B_F4 = BK * BN / 4 / BLK;          // 2
-    constexpr unsigned A_STAGE = BK * BM * 4, B_STAGE = BK * BN * 4;   // bytes
-    __shared__ __attribute__((aligned(16))) float As[STAGES][BK][BM];
-    __shared__ __attribute__((aligned(16))) float Bs[STAGES][BK][BN];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int ncol_tiles = p.col_tiles;
-    if ((int)blockIdx.x >= ncol_tiles * p.nz) return;
-    const int b = blockIdx.x / ncol_tiles;
-    const int m0 = blockIdx.y * BM;
-    const int p0 = (blockIdx.x - b * ncol_tiles) * BN;
-    const int K = p.k1 + p.k2;
-
-    const float* x1 = p.x1 + (size_t)b * p.x1_bs;
-    const float* x2 = p.x2 ? p.x2 + (size_t)b * p.x2_bs : p.x1;
-    const i32x4 rs_w = make_srd(p.wt, K * p.cout * 4);
-    const i32x4 rs_x1 = make_srd(x1, p.k1 * p.P * 4);
-    const i32x4 rs_x2 = make_srd(x2, p.x2 ? p.k2 * p.P * 4 : 0);
-
-    // per-lane source offsets (same tile mapping as the pipelined kernel: thread f covers row f / 32,
-    // floats 4 * (f % 32) ..+3 of the 16 x 128 tile image) and wave-uniform LDS destinations
-    int a_vo[A_F4], b_vo[B_F4];
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-        const int f = tid + i * BLK;
-        a_vo[i] = ((f / (BM / 4)) * p.cout + m0 + (f % (BM / 4)) * 4) * 4;
-    }
-#pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-        const int f = tid + i * BLK;
-        b_vo[i] = ((f / (BN / 4)) * p.P + p0 + (f % (BN / 4)) * 4) * 4;
-    }
-    const unsigned wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const unsigned a_lds = static_cast<unsigned>(reinterpret_cast<size_t>(&As[0][0][0])) + wave_u * 1024u;
-    const unsigned b_lds = static_cast<unsigned>(reinterpret_cast<size_t>(&Bs[0][0][0])) + wave_u * 1024u;
-
-    auto issue = [&](int k0, int stage) {            // 4 LDS-direct loads: stage image of k-rows k0 .. k0+15
-        const bool second = k0 >= p.k1;
-        const i32x4 rs_x = second ? rs_x2 : rs_x1;
-        const int a_so = k0 * p.cout * 4;
-        const int b_so = (second ? k0 - p.k1 : k0) * p.P * 4;
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) buffer_load_lds_x4(rs_w, a_vo[i] + a_so, a_lds + stage * A_STAGE + i * 4096u);
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) buffer_load_lds_x4(rs_x, b_vo[i] + b_so, b_lds + stage * B_STAGE + i * 4096u);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int kh = lane >> 5;
-    const int l31 = lane & 31;
-    const int am = wm * (TM * 32) + l31;
-    const int bn = wn * (TN * 32) + l31;
-
-    issue(0, 0);
-    issue(BK, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // stage 0 landed
-    __builtin_amdgcn_s_barrier();
-    int st = 0;
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        const int st2 = st >= 1 ? st - 1 : 2;                 // (st + 2) % 3: last read one iteration ago
-        issue(k0 + 2 * BK, st2);
-        float a[2][TM], bb[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[0][i] = As[st][kh][am + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bb[0][j] = Bs[st][kh][bn + j * 32];
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-            if (kk + 2 < BK) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[nxt][i] = As[st][kk + 2 + kh][am + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bb[nxt][j] = Bs[st][kk + 2 + kh][bn + j * 32];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // stage k0 + BK landed; stage k0 + 2 BK may still fly
-        __builtin_amdgcn_s_barrier();
-        st = st == 2 ? 0 : st + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // surplus (out-of-range) tail loads
 
     const float* yg = p.yg ? p.yg + (size_t)b * p.yg_bs : nullptr;
     float* out = p.out + (size_t)b * p.out_bs;
@@ -809,9 +640,7 @@ extern "C" int ffb6d_shared_mlp_f32(const float* wt, const float* bias, const fl
                       (k2 == 0 || k1 % BK == 0) && (K + 2 * BK) * P * 4 < (1LL << 31) &&
                       (K + 2 * BK) * cout * 4 < (1LL << 31);
     if (pipe) {
-        if (cout > 64 && mlp_pipe_enabled() == 2)      // experimental LDS-direct variant, see above
-            hipLaunchKernelGGL((shared_mlp_lds_kernel<128>), dim3(gxz, (unsigned)ceil_div(cout, 128), 1), dim3(BLK), 0, st, p);
-        else if (cout > 64)
+        if (cout > 64)
             hipLaunchKernelGGL((shared_mlp_pipe_kernel<128>), dim3(gxz, (unsigned)ceil_div(cout, 128), 1), dim3(BLK), 0, st, p);
         else
             hipLaunchKernelGGL((shared_mlp_pipe_kernel<64>), dim3(gxz, 1, 1), dim3(BLK), 0, st, p);

@@ -18,6 +18,8 @@ What is different from the reference (MI355X-first, eval mode):
   * the dense 3x3/7x7 convolutions of the colour branch stay on MIOpen (out of scope for
     hand-written kernels).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -566,9 +568,36 @@ class FFB6D(nn.Module):
             bs, 1, 3, -1).permute(0, 1, 3, 2).contiguous()
         return end_points
 
+    def check_indices(self, inputs):
+        """Debug aid (FFB6D_CHECK_INDICES=1 runs it on every forward): every index tensor of the input dict must address
+        its source set.  The gather kernels do not bounds-check (torch.gather device-asserts there); an out-of-range
+        index is an out-of-bounds read.  One device counter per tensor, one host sync at the end."""
+        B, _, H, W = inputs['rgb'].shape
+        n = [inputs['cld_xyz%d' % i].shape[1] for i in range(4)]
+        n_sub = [inputs['cld_sub_idx%d' % i].shape[1] for i in range(4)]
+
+        def hw(idx_key):            # pixels of the map a p2r index tensor has one entry per
+            return inputs[idx_key].shape[1]
+        limits = {'choose': H * W}
+        for i in range(4):
+            limits['cld_nei_idx%d' % i] = n[i]
+            limits['cld_sub_idx%d' % i] = n[i]
+            limits['cld_interp_idx%d' % i] = n_sub[i]
+            limits['r2p_ds_nei_idx%d' % i] = hw('p2r_ds_nei_idx%d' % i)
+            limits['p2r_ds_nei_idx%d' % i] = n_sub[i]
+        for i in range(3):
+            limits['r2p_up_nei_idx%d' % i] = hw('p2r_up_nei_idx%d' % i)
+            limits['p2r_up_nei_idx%d' % i] = inputs['r2p_up_nei_idx%d' % i].shape[1]
+        bad = {k: ops.check_index_range(inputs[k], m) for k, m in limits.items()}
+        bad = {k: v for k, v in bad.items() if v}
+        if bad:
+            raise IndexError(f"index tensors with out-of-range entries (tensor: count): {bad}")
+
     def forward(self, inputs, end_points=None, scale=1, taps=None):
         if not end_points:
             end_points = {}
+        if os.environ.get("FFB6D_CHECK_INDICES") == "1" and inputs['rgb'].is_cuda:
+            self.check_indices(inputs)
         rgb = inputs['rgb']
         fused = not _autograd_path(rgb, self)
         if fused and self.layout == "pm" and forward_pm.supported(self):

@@ -1,7 +1,7 @@
 """oracle/ops_ref.py -- TEST INFRASTRUCTURE ONLY.  Plain PyTorch fp32 (CPU) restatements of
 the reference's neighbour operators, written with advanced indexing instead of the
 reference's gather+repeat so they are an independent statement of the same maths.  Each
-is pinned against the reference's own function in tests/test_oracle_vs_ref.py."""
+is pinned against the reference's own function in tests/test_oracle_cpu.py."""
 import torch
 
 

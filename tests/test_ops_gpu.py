@@ -130,6 +130,34 @@ def test_backward_matches_torch_autograd(device):
     torch.testing.assert_close(a[1], b[1], **TOL)
 
 
+def test_random_sample_propagates_nan_like_torch_max(device):
+    """torch.max (ffb6d.py:176) returns NaN when a gathered neighbour is NaN; both channel-major kernels (one lane per
+    point, and the 16-lane row kernel used for image sources) must do the same instead of masking it."""
+    for M, Np in ((64, 16), (4096, 32)):                 # M <= 4*Np: lane kernel;  M > 4*Np: row16 kernel
+        f = torch.zeros(1, 3, M)
+        f[0, 1, 5] = float("nan")
+        idx = torch.stack([torch.arange(16) + s for s in range(Np)]).view(1, Np, 16) % M
+        want = ops_ref.random_sample(f.unsqueeze(3), idx)
+        got = ops.random_sample(f.to(device).unsqueeze(3), idx.to(device)).cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want)) and bool(torch.isnan(got).any())
+        assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
+
+
+def test_model_index_check_catches_out_of_range_entries(device, monkeypatch):
+    from ffb6d_amd import model, pyramid, synth
+    frames = synth.make_batch(7, 1, n_points=1024, height=120, width=160)
+    inputs = pyramid.frames_to_device(frames, device)
+    net = model.FFB6D(n_classes=5, n_pts=1024).to(device).eval()
+    net.check_indices(inputs)                              # a pyramid built by this package is clean
+    inputs['p2r_ds_nei_idx1'] = inputs['p2r_ds_nei_idx1'].clone()
+    inputs['p2r_ds_nei_idx1'][0, 3, 0] = 10 ** 6
+    with pytest.raises(IndexError, match="p2r_ds_nei_idx1"):
+        net.check_indices(inputs)
+    monkeypatch.setenv("FFB6D_CHECK_INDICES", "1")
+    with torch.no_grad(), pytest.raises(IndexError):
+        net(inputs)
+
+
 def test_index_range_check(device):
     idx = torch.tensor([[0, 5, 9, 10, -1]], device=device)
     assert ops.check_index_range(idx, 10) == 2
