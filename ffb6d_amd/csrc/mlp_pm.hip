@@ -116,12 +116,117 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
+// epilogue shared by the GEMM kernels: bias, gathered / added row of Y, activation or log-softmax, store
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM][TN], int c0, int r0, int wm, int wn, int l31, int kh)
+{
+    constexpr int SZ = El<T>::SZ;
+    // epilogue: lane = one point, 4 groups of 4 consecutive channels per 32 x 32 tile
+    const T* yb = static_cast<const T*>(p.y);
+    T* ob = static_cast<T*>(p.out);
+    const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
+    constexpr int AL = 4 * SZ - 1;                         // alignment mask of a 4-channel group
+    const bool vec = (p.cout & 3) == 0 && (p.ldo & 3) == 0 && (p.ldy & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.y)) & AL) == 0 &&
+                     (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = r0 + (wn * TN + j) * 32 + l31;
+        const bool live = r < p.rows;
+        const T* yrow = nullptr;
+        if (yb && live) {
+            long long yr = r;
+            if (p.gidx) {
+                const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[r]
+                                             : (long long)static_cast<const int*>(p.gidx)[r];
+                yr = (long long)(r / p.P) * p.py + gi;
+            }
+            yrow = yb + yr * p.ldy;
+        }
+        T* orow = ob + (size_t)r * p.ldo;
+        if (vec) {
+            float4 v[TM][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
+                    v[i][g] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    if (ch >= p.cout || !live) continue;
+                    if (p.bias) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
+                        v[i][g].x += b4.x; v[i][g].y += b4.y; v[i][g].z += b4.z; v[i][g].w += b4.w;
+                    }
+                    if (yrow) {
+                        const float4 y4 = El<T>::ld4(yrow + ch);
+                        v[i][g].x += y4.x; v[i][g].y += y4.y; v[i][g].z += y4.z; v[i][g].w += y4.w;
+                    }
+                }
+            }
+            if (p.act == 3) {
+                // log_softmax over the channels of a point (pspnet.py:108-112 `final`): the launcher guarantees that the
+                // wave's tile spans all cout channels; a point's channels sit in lanes l and l ^ 32
+                float m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (i * 32 + 8 * g + 4 * kh < p.cout)
+                            m = fmaxf(fmaxf(fmaxf(m, v[i][g].x), fmaxf(v[i][g].y, v[i][g].z)), v[i][g].w);
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (i * 32 + 8 * g + 4 * kh < p.cout)
+                            sum += (expf(v[i][g].x - m) + expf(v[i][g].y - m)) + (expf(v[i][g].z - m) + expf(v[i][g].w - m));
+                sum += __shfl_xor(sum, 32, 64);
+                const float lse = m + logf(sum);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
+                        if (ch < p.cout && live)
+                            El<T>::st4(orow + ch, make_float4(v[i][g].x - lse, v[i][g].y - lse, v[i][g].z - lse, v[i][g].w - lse));
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
+                        if (ch < p.cout && live)
+                            El<T>::st4(orow + ch, make_float4(activate(v[i][g].x, slope), activate(v[i][g].y, slope),
+                                                              activate(v[i][g].z, slope), activate(v[i][g].w, slope)));
+                    }
+            }
+        } else if (live) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int ch = c0 + (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                    if (ch >= p.cout) continue;
+                    float u = acc[i][j][q];
+                    if (p.bias) u += p.bias[ch];
+                    if (yrow) u += El<T>::ld(yrow + ch);
+                    El<T>::st(orow + ch, activate(u, slope));
+                }
+            }
+        }
+    }
+}
+
 // TM x TN MFMA tiles of 32 (channels) x 32 (points) per wave; WM x WN waves per workgroup.
 // KSPLIT: the four waves of the workgroup share ONE TM x TN tile and each take a quarter of K (partial sums meet
 // in LDS) -- for the deep layers, where a frame has a few hundred points and K up to 1024: without it a handful of
 // workgroups would each walk the whole K.
-// (Measured and dropped: 128 x 64 / 64 x 128 tiles per wave, and stages of 32 k = one whole 128-byte line per row and lane
-// pair -- all within +-5 % of this form on the MFMA-bound layers, profiles/r02_mlp_pm_tiles.txt.)
+// (Measured and dropped, profiles/r02_mlp_pm_tiles.txt: 128 x 64 / 64 x 128 tiles per wave and stages of 32 k = one whole
+// 128-byte line per row and lane pair -- all within +-5 % of this form on the MFMA-bound layers; for the HBM-bound short-K
+// layers a variant that issues ALL operand loads of a tile before the first MFMA -- no faster: those launches run at
+// t_MFMA + t_HBM instead of max(t_MFMA, t_HBM), i.e. what is missing is overlap ACROSS tiles, a persistent loop.)
 template <typename T, int TM, int TN, int WM, int WN, bool KSPLIT>
 __global__ void __launch_bounds__(BLK)
 mlp_pm_kernel(const PmParams p)
@@ -244,102 +349,7 @@ mlp_pm_kernel(const PmParams p)
                     for (int r = 0; r < 16; ++r) acc[i][j][r] += part[w][(i * TN + j) * 16 + r][lane];
     }
 
-    // epilogue: lane = one point, 4 groups of 4 consecutive channels per 32 x 32 tile
-    const T* yb = static_cast<const T*>(p.y);
-    T* ob = static_cast<T*>(p.out);
-    const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
-    constexpr int AL = 4 * SZ - 1;                         // alignment mask of a 4-channel group
-    const bool vec = (p.cout & 3) == 0 && (p.ldo & 3) == 0 && (p.ldy & 3) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.y)) & AL) == 0 &&
-                     (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int r = r0 + (wn * TN + j) * 32 + l31;
-        const bool live = r < p.rows;
-        const T* yrow = nullptr;
-        if (yb && live) {
-            long long yr = r;
-            if (p.gidx) {
-                const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[r]
-                                             : (long long)static_cast<const int*>(p.gidx)[r];
-                yr = (long long)(r / p.P) * p.py + gi;
-            }
-            yrow = yb + yr * p.ldy;
-        }
-        T* orow = ob + (size_t)r * p.ldo;
-        if (vec) {
-            float4 v[TM][4];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
-                    v[i][g] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                    if (ch >= p.cout || !live) continue;
-                    if (p.bias) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
-                        v[i][g].x += b4.x; v[i][g].y += b4.y; v[i][g].z += b4.z; v[i][g].w += b4.w;
-                    }
-                    if (yrow) {
-                        const float4 y4 = El<T>::ld4(yrow + ch);
-                        v[i][g].x += y4.x; v[i][g].y += y4.y; v[i][g].z += y4.z; v[i][g].w += y4.w;
-                    }
-                }
-            }
-            if (p.act == 3) {
-                // log_softmax over the channels of a point (pspnet.py:108-112 `final`): the launcher guarantees that the
-                // wave's tile spans all cout channels; a point's channels sit in lanes l and l ^ 32
-                float m = -INFINITY;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (i * 32 + 8 * g + 4 * kh < p.cout)
-                            m = fmaxf(fmaxf(fmaxf(m, v[i][g].x), fmaxf(v[i][g].y, v[i][g].z)), v[i][g].w);
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
-                float sum = 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (i * 32 + 8 * g + 4 * kh < p.cout)
-                            sum += (expf(v[i][g].x - m) + expf(v[i][g].y - m)) + (expf(v[i][g].z - m) + expf(v[i][g].w - m));
-                sum += __shfl_xor(sum, 32, 64);
-                const float lse = m + logf(sum);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
-                        if (ch < p.cout && live)
-                            El<T>::st4(orow + ch, make_float4(v[i][g].x - lse, v[i][g].y - lse, v[i][g].z - lse, v[i][g].w - lse));
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
-                        if (ch < p.cout && live)
-                            El<T>::st4(orow + ch, make_float4(activate(v[i][g].x, slope), activate(v[i][g].y, slope),
-                                                              activate(v[i][g].z, slope), activate(v[i][g].w, slope)));
-                    }
-            }
-        } else if (live) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int ch = c0 + (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-                    if (ch >= p.cout) continue;
-                    float u = acc[i][j][q];
-                    if (p.bias) u += p.bias[ch];
-                    if (yrow) u += El<T>::ld(yrow + ch);
-                    El<T>::st(orow + ch, activate(u, slope));
-                }
-            }
-        }
-    }
+    pm_epilogue<T, TM, TN>(p, acc, c0, r0, wm, wn, l31, kh);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

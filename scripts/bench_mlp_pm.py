@@ -23,6 +23,8 @@ SHAPES = [("ds3 p2r_fuse 1024->1024 +gather", 1024, 0, 1024, 4800, 48), ("psp bo
 hints = [int(h) for h in sys.argv[1:]] or [0]
 if os.environ.get("MLP_PM_BIG"):
     SHAPES = SHAPES[:4] + SHAPES[8:10]
+if os.environ.get("MLP_PM_STREAM"):
+    SHAPES = [s for s in SHAPES if s[1] + s[2] <= 64 and s[4] >= 12288]
 
 
 def timeit(fn, n=10):

@@ -35,6 +35,7 @@ CASES = [
     (1, 4800, 512, 0, 1024, 1, -1, 0), (1, 1, 8, 0, 8, 0, 0, 0), (1, 33, 8, 8, 5, 1, 0, 0),
     (2, 1000, 64, 0, 136, 1, 7, 0),
 ]
+CASES += [(2, 777, 40, 24, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)] + [(1, 70000, 64, 0, 64, 1, 300, 0), (2, 40000, 16, 0, 16, 2, 0, 0)]
 CASES += [(2, 777, 40, 24, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)] + [(1, 4100, 256, 0, 200, 1, -1, h) for h in (1, 2, 3, 4, 5)]
 
 
@@ -210,7 +211,8 @@ def _close_bf16(got, want, what=""):
 @pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", [
     (2, 12288, 64, 64, 128, 1, 0, 0), (1, 4800, 1024, 0, 1024, 1, 48, 0), (8, 48, 1024, 0, 512, 1, 0, 0),
     (8, 192, 512, 256, 256, 2, 0, 0), (1, 12288, 128, 0, 22, 0, 0, 0), (3, 301, 32, 16, 40, 1, 13, 0),
-    (1, 196608, 16, 0, 16, 2, 0, 0), (1, 4800, 512, 0, 1024, 1, -1, 0)] + [(2, 777, 48, 32, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)])
+    (1, 196608, 16, 0, 16, 2, 0, 0), (1, 4800, 512, 0, 1024, 1, -1, 0), (1, 70000, 128, 0, 64, 1, 300, 0)] +
+    [(2, 777, 48, 32, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)])
 def test_mlp_pm_bf16(device, B, P, K1, K2, Cout, act, py, hint):
     g = torch.Generator().manual_seed(K1 + Cout + P)
     r = lambda *s: torch.randn(*s, generator=g).to(BF)                               # noqa: E731
