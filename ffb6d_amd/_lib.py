@@ -66,6 +66,9 @@ SIGNATURES = {
     "ffb6d_sample_points_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "ffb6d_sample_points_f32": (_i32, [_vp, _c.c_float, _vp, _vp, _i32, _vp, _c.c_uint64, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                        _i64, _vp, _sz, _vp]),
+    "ffb6d_depth_normal": (_i32, [_vp, _i32, _c.c_double, _c.c_double, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _vp]),
+    "ffb6d_fill_missing_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "ffb6d_fill_missing_f32": (_i32, [_vp, _c.c_double, _c.c_double, _c.c_float, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffb6d_check_index_range": (_i32, [_vp, _i32, _i64, _i64, _vp, _vp]),
     # include/ffb6d_pose.h
     "ffb6d_vote_sets_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _vp]),

@@ -79,6 +79,63 @@ assemble_points_kernel(const uint32_t* __restrict__ sorted, const int32_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Surface normals from a depth image.  The reference calls the third-party package
+// `normalSpeed` (github.com/hfutcgncas/normalSpeed, installed from source per the reference's README.md:66-72, no version
+// pin; NOT vendored in the reference tree and absent from this image):
+//     nrm_map = normalSpeed.depth_normal(dpt_mm, K[0][0], K[1][1], 5, 2000, 20, False)
+// at linemod_dataset.py:252-254, ycb_dataset.py:208-210 and utils/basic_utils.py:323.  Restated here from its published
+// algorithm -- OpenCV's LINE-MOD depth normals (opencv/modules/rgbd, `accumBilateral` least squares): for a pixel of depth
+// d < distance_threshold take the 8 neighbours at offset (+-r, +-r) / (+-r, 0) / (0, +-r), r = kernel_size; a neighbour
+// whose depth differs from d by less than difference_threshold contributes (i, j, delta) to the normal equations
+//     A = sum [i*i, i*j; i*j, j*j],  b = sum [i*delta, j*delta]            (integer arithmetic)
+// and the normal is  (fx * (A11 b0 - A01 b1),  fy * (-A01 b0 + A00 b1),  -det(A) * d)  normalised; pixels in the r-wide border,
+// pixels with d >= distance_threshold and degenerate systems stay (0, 0, 0).  PARITY UNPINNED: no reference output can be
+// produced here; parity is anchored on the call sites' arguments and checked against the CPU restatement (oracle/inputs_ref.py).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename DepthT>
+__global__ void __launch_bounds__(BLK)
+depth_normal_kernel(const DepthT* __restrict__ depth, float* __restrict__ out, int H, int W, double fx, double fy, int r,
+                    int dist_thr, int diff_thr)
+{
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * BLK + threadIdx.x;
+    if (pix >= H * W) return;
+    const int y = pix / W, x = pix - y * W;
+    const DepthT* img = depth + (size_t)b * H * W;
+    auto at = [&](int yy, int xx) -> long long { return (long long)(unsigned short)(long long)img[(size_t)yy * W + xx]; };
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (y >= r && y < H - r - 1 && x >= r && x < W - r - 1) {
+        const long long d = at(y, x);
+        if (d < dist_thr) {
+            long long a00 = 0, a01 = 0, a11 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const int t = n < 4 ? n : n + 1;               // the 3 x 3 stencil without its centre
+                const long long i = (t % 3 - 1) * r, j = (t / 3 - 1) * r;
+                const long long delta = at(y + (int)j, x + (int)i) - d;
+                if ((delta < 0 ? -delta : delta) < diff_thr) {
+                    a00 += i * i; a01 += i * j; a11 += j * j;
+                    b0 += i * delta; b1 += j * delta;
+                }
+            }
+            const long long det = a00 * a11 - a01 * a01;
+            const long long ddx = a11 * b0 - a01 * b1;
+            const long long ddy = -a01 * b0 + a00 * b1;
+            const float fxn = (float)(fx * (double)ddx), fyn = (float)(fy * (double)ddy), fzn = (float)(-det * d);
+            const float len = sqrtf(fxn * fxn + fyn * fyn + fzn * fzn);
+            if (len > 0.f) {
+                const float inv = 1.0f / len;
+                nx = fxn * inv; ny = fyn * inv; nz = fzn * inv;
+            }
+        }
+    }
+    float* o = out + (size_t)b * 3 * H * W + pix;
+    o[0] = nx;
+    o[(size_t)H * W] = ny;
+    o[(size_t)2 * H * W] = nz;
+}
+
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct SampleLayout { size_t keys_in, keys_out, vals_in, vals_out, temp, temp_bytes, total; };
@@ -148,6 +205,27 @@ extern "C" int ffb6d_sample_points_f32(const float* depth, float min_depth, cons
     else
         hipLaunchKernelGGL((assemble_points_kernel<float>), grid, dim3(BLK), 0, st, vals_out, n_valid, xyz,
                            static_cast<const float*>(rgb), nrm, reinterpret_cast<long long*>(choose), cld, cld_rgb_nrm, (int)HW, (int)N);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+extern "C" int ffb6d_depth_normal(const void* depth_mm, int depth_is_u16, double fx, double fy, int kernel_size,
+                                  int distance_threshold, int difference_threshold, int point_into_surface, float* out,
+                                  int64_t B, int64_t H, int64_t W, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && H * W < (1LL << 31) && B < 65536, "depth_normal: bad shape");
+    FFB6D_REQUIRE(kernel_size >= 1 && kernel_size < 64, "depth_normal: kernel_size must be in [1, 63]");
+    FFB6D_REQUIRE(point_into_surface == 0, "depth_normal: point_into_surface = True has no call site in the reference and is not provided");
+    if (B == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(depth_mm && out, "depth_normal: null pointer");
+    const dim3 grid((unsigned)ceil_div(H * W, BLK), (unsigned)B);
+    hipStream_t st = as_stream(stream);
+    if (depth_is_u16)
+        hipLaunchKernelGGL((depth_normal_kernel<uint16_t>), grid, dim3(BLK), 0, st, static_cast<const uint16_t*>(depth_mm), out, (int)H,
+                           (int)W, fx, fy, kernel_size, distance_threshold, difference_threshold);
+    else
+        hipLaunchKernelGGL((depth_normal_kernel<float>), grid, dim3(BLK), 0, st, static_cast<const float*>(depth_mm), out, (int)H, (int)W,
+                           fx, fy, kernel_size, distance_threshold, difference_threshold);
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }

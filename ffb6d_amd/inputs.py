@@ -42,6 +42,59 @@ def depth_to_cloud(depth, K, cam_scale=1.0):
     return out
 
 
+def depth_normal(depth_mm, fx, fy, k_size=5, distance_threshold=2000, difference_threshold=20, point_into_surface=False):
+    """Surface normals of a depth image, the algorithm of `normalSpeed.depth_normal` with its argument order
+    (linemod_dataset.py:252-254: `normalSpeed.depth_normal(dpt_mm, K[0][0], K[1][1], 5, 2000, 20, False)`).
+    depth_mm [B,H,W] (or [H,W]) in millimetres: float32 (truncated to uint16 like `.astype(np.uint16)`), int16/uint16 bit
+    patterns are taken as uint16.  Returns float32 [B,3,H,W] ([3,H,W]) -- the channel-major planes `assemble_inputs`
+    consumes (the reference's map is [H,W,3]: `.permute(0, 2, 3, 1)`).  normalSpeed is not available here: parity is
+    checked against the CPU restatement of the published algorithm only (csrc/inputs.hip)."""
+    if not depth_mm.is_cuda:
+        raise _lib.FFB6DNativeError("depth_normal needs a GPU tensor (no CPU fallback)")
+    lib = _lib.load()
+    single = depth_mm.dim() == 2
+    d = (depth_mm.unsqueeze(0) if single else depth_mm).contiguous()
+    if d.dim() != 3:
+        raise ValueError("depth_mm must be [B,H,W] or [H,W]")
+    if d.dtype in (torch.int16, torch.uint16):
+        is_u16 = 1
+    elif d.dtype == torch.float32:
+        is_u16 = 0
+    else:
+        raise TypeError(f"depth_mm must be float32 or (u)int16, got {d.dtype}")
+    B, H, W = d.shape
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device), _lib.traced("depth_normal", d.element_size() * d.numel() + 12 * d.numel(), (H, W)):
+        rc = lib.ffb6d_depth_normal(d.data_ptr(), is_u16, float(fx), float(fy), int(k_size), int(distance_threshold),
+                                    int(difference_threshold), 1 if point_into_surface else 0, out.data_ptr(), B, H, W,
+                                    torch.cuda.current_stream(d.device).cuda_stream)
+    _lib.check(rc, "ffb6d_depth_normal")
+    return out[0] if single else out
+
+
+def fill_missing(dpt, cam_scale, scale_2_80m=1.0, max_depth=3.0):
+    """Basic_Utils.fill_missing(dpt, cam_scale, scale_2_80m) with its default fill_type='multiscale', extrapolate=False,
+    blur_type='bilateral' (utils/basic_utils.py:467-487 -> fill_in_multiscale, depth_map_utils_ycb.py:290-445): dense depth
+    from a depth image with holes, same unit in and out.  dpt [B,H,W] (or [H,W]) float32 on the GPU.  OpenCV is not
+    available here: parity is checked against the CPU restatement only (oracle/holefill_ref.py)."""
+    if not dpt.is_cuda:
+        raise _lib.FFB6DNativeError("fill_missing needs a GPU tensor (no CPU fallback)")
+    lib = _lib.load()
+    single = dpt.dim() == 2
+    d = (dpt.unsqueeze(0) if single else dpt).float().contiguous()
+    if d.dim() != 3:
+        raise ValueError("dpt must be [B,H,W] or [H,W]")
+    B, H, W = d.shape
+    out = torch.empty_like(d)
+    wbytes = lib.ffb6d_fill_missing_workspace_bytes(B, H, W)
+    ws = torch.empty((wbytes,), dtype=torch.uint8, device=d.device)
+    with torch.cuda.device(d.device), _lib.traced("fill_missing", 8 * d.numel(), (H, W)):
+        rc = lib.ffb6d_fill_missing_f32(d.data_ptr(), float(cam_scale), float(scale_2_80m), float(max_depth), out.data_ptr(),
+                                        B, H, W, ws.data_ptr(), wbytes, torch.cuda.current_stream(d.device).cuda_stream)
+    _lib.check(rc, "ffb6d_fill_missing_f32")
+    return out[0] if single else out
+
+
 def _seed(seed, generator):
     if seed is not None:
         return int(seed) & 0xFFFFFFFFFFFFFFFF

@@ -122,6 +122,24 @@ int ffb6d_sample_points_f32(const float* depth, float min_depth, const float* xy
                             int32_t* n_valid, int64_t B, int64_t H, int64_t W, int64_t N, void* workspace,
                             size_t workspace_bytes, ffb6d_stream_t stream);
 
+/* Surface normals of a depth image: the published algorithm of `normalSpeed.depth_normal(dpt_mm, fx, fy, k_size,
+ * distance_threshold, difference_threshold, point_into_surface)` (third-party, not vendored in the reference; call sites
+ * linemod_dataset.py:252-254, ycb_dataset.py:208-210: (dpt_mm, K[0][0], K[1][1], 5, 2000, 20, False)) = OpenCV LINE-MOD
+ * bilateral least-squares normals, see csrc/inputs.hip.  depth_mm [B,H,W]: uint16 (depth_is_u16) or float32 truncated to
+ * uint16 like `.astype(np.uint16)`; out [B,3,H,W] float32 unit normals ((0,0,0) where undefined).  Parity unpinned. */
+int ffb6d_depth_normal(const void* depth_mm, int depth_is_u16, double fx, double fy, int kernel_size,
+                       int distance_threshold, int difference_threshold, int point_into_surface, float* out, int64_t B,
+                       int64_t H, int64_t W, ffb6d_stream_t stream);
+
+/* YCB depth hole filling: Basic_Utils.fill_missing(dpt, cam_scale, scale_2_80m) (utils/basic_utils.py:467-487) ->
+ * fill_in_multiscale(extrapolate=False, blur_type='bilateral', max_depth) (utils/ip_basic/ip_basic/depth_map_utils_ycb.py:
+ * 290-445), restated operator by operator (csrc/holefill.hip).  depth [B,H,W] in the caller's unit, out the filled map in
+ * the same unit; the reference's call (ycb_dataset.py:204) is (dpt_um, cam_scale, 1) with max_depth = 3.0.  Parity
+ * unpinned (OpenCV absent here).  workspace: ffb6d_fill_missing_workspace_bytes(B, H, W) bytes of device scratch. */
+size_t ffb6d_fill_missing_workspace_bytes(int64_t B, int64_t H, int64_t W);
+int ffb6d_fill_missing_f32(const float* depth, double cam_scale, double scale_2_80m, float max_depth, float* out, int64_t B,
+                           int64_t H, int64_t W, void* workspace, size_t workspace_bytes, ffb6d_stream_t stream);
+
 /* ==== point-major / pixel-major ("channels last") operators: one row of C contiguous floats per point or pixel ====
  * (csrc/mlp_pm.hip, csrc/ops_pm.hip).  Rows run over the points of ALL frames unless stated; row strides (ld*) are in floats. */
 

@@ -1,7 +1,13 @@
 """oracle/inputs_ref.py -- TEST INFRASTRUCTURE ONLY.  numpy restatement of the reference's depth
 back-projection `dpt_2_pcld` (ffb6d/datasets/linemod/linemod_dataset.py:188-199) and the NaN/Inf
 clean-up that follows it (:258-259), with numpy's own dtype promotion (float32 depth, int64 pixel
-maps, float64 intrinsics -> float64 result)."""
+maps, float64 intrinsics -> float64 result); pinned bit-exactly to the reference's own method
+(tests/test_oracle_cpu.py::test_inputs_ref_equals_the_reference_dpt_2_pcld).
+
+`depth_normal`: restatement of the published algorithm behind the third-party `normalSpeed.depth_normal` the
+reference calls at linemod_dataset.py:252-254 (OpenCV LINE-MOD bilateral least-squares normals).  PARITY
+UNPINNED: normalSpeed is neither vendored in /root/reference nor installed in this image, so neither this
+restatement nor the HIP kernel can be compared with its output; they are compared with each other."""
 import numpy as np
 
 
@@ -20,3 +26,33 @@ def dpt_2_pcld(dpt, cam_scale, K):
     dpt_3d[np.isnan(dpt_3d)] = 0.0
     dpt_3d[np.isinf(dpt_3d)] = 0.0
     return dpt_3d
+
+
+def depth_normal(depth_mm, fx, fy, k_size=5, distance_threshold=2000, difference_threshold=20, point_into_surface=False):
+    """depth_mm [H,W] (cast to uint16 like the call sites do) -> float32 [H,W,3] unit normals, zeros where undefined."""
+    assert not point_into_surface
+    d = np.asarray(depth_mm).astype(np.uint16).astype(np.int64)
+    H, W = d.shape
+    r = int(k_size)
+    out = np.zeros((H, W, 3), np.float32)
+    ys, xs = np.arange(r, H - r - 1), np.arange(r, W - r - 1)
+    c = d[np.ix_(ys, xs)]
+    a00 = np.zeros_like(c); a01 = np.zeros_like(c); a11 = np.zeros_like(c); b0 = np.zeros_like(c); b1 = np.zeros_like(c)
+    for j in (-r, 0, r):
+        for i in (-r, 0, r):
+            if i == 0 and j == 0:
+                continue
+            delta = d[np.ix_(ys + j, xs + i)] - c
+            f = (np.abs(delta) < difference_threshold).astype(np.int64)
+            a00 += f * i * i; a01 += f * i * j; a11 += f * j * j
+            b0 += f * i * delta; b1 += f * j * delta
+    det = a00 * a11 - a01 * a01
+    ddx = a11 * b0 - a01 * b1
+    ddy = -a01 * b0 + a00 * b1
+    n = np.stack([(float(fx) * ddx.astype(np.float64)).astype(np.float32),
+                  (float(fy) * ddy.astype(np.float64)).astype(np.float32), (-det * c).astype(np.float32)], axis=-1)
+    length = np.sqrt((n[..., 0] * n[..., 0] + n[..., 1] * n[..., 1]) + n[..., 2] * n[..., 2]).astype(np.float32)
+    ok = (c < distance_threshold) & (length > 0)
+    inv = np.where(ok, np.float32(1.0) / np.where(ok, length, np.float32(1.0)), np.float32(0.0)).astype(np.float32)
+    out[np.ix_(ys, xs)] = n * inv[..., None]
+    return out

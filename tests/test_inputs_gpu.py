@@ -92,3 +92,63 @@ def test_assemble_inputs_feeds_the_model(device):
     assert torch.equal(d['cld_xyz0'], d['cld_rgb_nrm'][:, :3].transpose(1, 2))
     for k in ('cld_nei_idx0', 'r2p_ds_nei_idx3', 'p2r_up_nei_idx2'):
         assert k in d
+
+
+def test_depth_normal_matches_the_restatement_bit_exactly(device):
+    """Surface normals (normalSpeed.depth_normal's published algorithm, parity unpinned -- see
+    oracle/inputs_ref.py): HIP kernel vs the numpy restatement, bit exact, on depth with holes, steps, far pixels
+    (>= distance_threshold) and both input dtypes."""
+    rng = np.random.RandomState(4)
+    yy, xx = np.mgrid[0:120, 0:160]
+    d = (900.0 + 1.5 * xx + 0.7 * yy + 3.0 * rng.randn(120, 160)).astype(np.float32)
+    d[30:50, 40:90] += 300.0                       # a step: neighbours beyond the difference threshold are dropped
+    d[rng.rand(120, 160) < 0.05] = 0.0              # holes
+    d[80:, 100:] = 2500.0                           # beyond the distance threshold
+    for K in (synth.LINEMOD_K, np.array([[1066.778, 0., 312.9869], [0., 1067.487, 241.3109], [0., 0., 1.]])):
+        want = inputs_ref.depth_normal(d, K[0][0], K[1][1], 5, 2000, 20, False)                  # [H,W,3]
+        got = inputs.depth_normal(torch.from_numpy(d).to(device), K[0][0], K[1][1], 5, 2000, 20, False)
+        assert got.shape == (3, 120, 160)
+        np.testing.assert_array_equal(got.permute(1, 2, 0).cpu().numpy(), want)
+        d16 = torch.from_numpy(d.astype(np.uint16).astype(np.int32)).to(torch.int16).to(device)   # same bits as uint16
+        got16 = inputs.depth_normal(torch.stack([d16, d16]), K[0][0], K[1][1])
+        np.testing.assert_array_equal(got16[1].permute(1, 2, 0).cpu().numpy(), want)
+    n = np.linalg.norm(want, axis=2)
+    assert ((np.abs(n - 1) < 1e-5) | (n == 0)).all() and (n[80:, 100:] == 0).all() and (n[:5] == 0).all()
+    with pytest.raises(Exception):
+        inputs.depth_normal(torch.from_numpy(d).to(device), 500.0, 500.0, point_into_surface=True)
+
+
+def _holey_depth(seed, h=120, w=160, unit=10000.0):
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    metres = 0.6 + 0.012 * xx + 0.004 * yy + 0.002 * rng.randn(h, w)       # spans the near / medium / far bins (1 m, 2 m)
+    metres[40:70, 60:100] += 0.9                                            # an object in front of / behind the plane
+    d = (metres * unit).astype(np.uint16).astype(np.float32)
+    d[rng.rand(h, w) < 0.25] = 0.0                                          # sensor drop-outs
+    d[50:58, 20:45] = 0.0                                                   # a hole larger than the 5x5 kernels
+    d[:12] = 0.0                                                            # nothing above the top row
+    d[:, 150:] = 0.0                                                        # empty columns
+    return d
+
+
+def test_fill_missing_matches_the_restatement(device):
+    """YCB depth hole filling (basic_utils.py:467-487 -> depth_map_utils_ycb.py:290-445; parity
+    unpinned, see oracle/holefill_ref.py): HIP chain vs the scipy restatement.  Everything before the bilateral blur is
+    max / min / median selection and must agree exactly where the blur is not applied; the blur itself within 1e-5."""
+    from oracle import holefill_ref
+    deps = np.stack([_holey_depth(1), _holey_depth(2)])
+    want = np.stack([holefill_ref.fill_missing(d, 10000.0, 1) for d in deps])
+    got = inputs.fill_missing(torch.from_numpy(deps).to(device), 10000.0, 1).cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert ((got > 0) == (want > 0)).all()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+    assert (got[:, :7, :140] == 0).all()                                     # never extrapolates upwards (extrapolate=False)
+    assert (got[:, 20:, :140] > 0).all()                                     # every hole below the top row is filled
+    one = inputs.fill_missing(torch.from_numpy(deps[1]).to(device), 10000.0, 1).cpu().numpy()
+    np.testing.assert_array_equal(one, got[1])
+    # other scale arguments (the LineMOD-style millimetre unit, scale_2_80m != 1)
+    d_mm = _holey_depth(3, unit=1000.0)
+    np.testing.assert_allclose(inputs.fill_missing(torch.from_numpy(d_mm).to(device), 1000.0, 2.0, max_depth=6.0).cpu().numpy(),
+                               holefill_ref.fill_missing(d_mm, 1000.0, 2.0, max_depth=6.0), rtol=1e-5, atol=0)
+    with pytest.raises(Exception):
+        inputs.fill_missing(torch.zeros(1, 4, 4, device=device), 1000.0)

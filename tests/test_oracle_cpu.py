@@ -162,6 +162,26 @@ def test_inputs_ref_equals_the_reference_dpt_2_pcld():
         np.testing.assert_array_equal(got, want)
 
 
+def test_depth_normal_restatement_recovers_plane_normals():
+    """normalSpeed is absent here (parity unpinned, oracle/inputs_ref.py): property check of the restated algorithm --
+    on a planar depth image z = z0 + gx*x + gy*y (mm per pixel) the LINE-MOD normal is normalize(fx*gx, fy*gy, -z);
+    the r-wide border, zero-depth regions and pixels at or beyond the distance threshold stay (0, 0, 0)."""
+    from oracle import inputs_ref
+    yy, xx = np.mgrid[0:100, 0:140]
+    fx, fy = 572.4, 573.6
+    for gx, gy in ((2.0, 1.0), (-1.0, 0.5), (0.0, 0.0)):
+        z = 1000.0 + gx * xx + gy * yy
+        n = inputs_ref.depth_normal(z.astype(np.float32), fx, fy, 5, 2000, 20, False)
+        want = np.stack([fx * gx * np.ones_like(z), fy * gy * np.ones_like(z), -np.floor(z)], axis=-1)
+        want /= np.linalg.norm(want, axis=-1, keepdims=True)
+        np.testing.assert_allclose(n[5:94, 5:134], want[5:94, 5:134], atol=2e-3)
+        assert (n[:5] == 0).all() and (n[:, :5] == 0).all() and (n[94:] == 0).all() and (n[:, 134:] == 0).all()
+    z = np.full((60, 60), 2000.0, np.float32)
+    assert (inputs_ref.depth_normal(z, fx, fy) == 0).all()                       # d < distance_threshold is strict
+    z[:] = 0.0
+    assert (inputs_ref.depth_normal(z, fx, fy) == 0).all()                       # invalid depth: degenerate system
+
+
 # ---- whole-forward restatement (oracle/forward_ref.py) against the reference's end_points ----
 def _oracle_forward(config, bs, n_points, h, w, n_classes):
     from oracle import forward_ref
@@ -201,3 +221,25 @@ def test_depth_backprojection_restatement_matches_the_frame_generator():
     z = f["dpt_xyz"][2].copy()
     z[0, 0] = np.nan
     assert (inputs_ref.dpt_2_pcld(z, 1.0, synth.LINEMOD_K)[0, 0] == 0).all()
+
+
+def test_fill_missing_restatement_fills_holes_and_keeps_the_surface():
+    """oracle/holefill_ref.py is unpinned (no cv2 here); these are the properties IP-Basic's completion guarantees: holes
+    below each column's first valid pixel are filled, nothing is invented more than the unconditional dilations' reach
+    (3 + 2 rows) above it, and the filled surface stays within a few centimetres of a smooth ground truth."""
+    from oracle import holefill_ref
+    rng = np.random.RandomState(0)
+    yy, xx = np.mgrid[0:96, 0:128]
+    truth = 0.7 + 0.01 * xx + 0.003 * yy
+    d = (truth * 10000.0).astype(np.uint16)
+    d[rng.rand(96, 128) < 0.3] = 0
+    d[:10] = 0
+    out = holefill_ref.fill_missing(d, 10000.0, 1)
+    assert out.dtype == np.float32 and out.shape == d.shape
+    assert (out[:5] == 0).all()
+    assert (out[16:] > 0).all()
+    assert np.abs(out[16:] / 10000.0 - truth[16:]).max() < 0.05
+    # the morphology helpers have OpenCV's border rule: out-of-image pixels never win
+    img = np.full((6, 6), -2.0, np.float32)
+    assert (holefill_ref.dilate(img, holefill_ref.full(5)) == -2.0).all() and (holefill_ref.erode(img, holefill_ref.full(5)) == -2.0).all()
+    assert holefill_ref.CROSS_3.sum() == 5 and holefill_ref.CROSS_5.sum() == 9 and holefill_ref.CROSS_7.sum() == 13
