@@ -70,9 +70,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
                     help="2: point branch on a second HIP stream under the colour branch (inference); "
                          "1: everything on one stream")
-    ap.add_argument("--overlap-pyramid", type=int, default=0,
-                    help="1: enqueue the index pyramid on the second stream too (under the colour stem); "
-                         "measured neutral on MI355X, the GPU is throughput-bound (DESIGN.md section 4b)")
+    ap.add_argument("--overlap-pyramid", type=int, default=1,
+                    help="1 (default, inference with --streams 2): the forward builds the index pyramid itself, level by "
+                         "level on a third HIP stream (forward_pm.StreamedPyramid), so the point branch starts after the "
+                         "level-0 searches and the rest runs under the network; 0: whole pyramid first, then the forward")
     ap.add_argument("--layout", choices=["pm", "cm"], default="pm",
                     help="activation layout of the fused forward: pm = point-major / pixel-major rows (default), "
                          "cm = the reference's channel-major layout on the first-generation kernels (A/B)")
@@ -259,18 +260,17 @@ def main():
     net.two_streams = overlap
     net.layout = args.layout
     net.precision = args.precision
-    side = net._side_stream(dev) if (overlap and args.overlap_pyramid) else None
+    net.index_dtype = idt
+    side = True if (overlap and args.overlap_pyramid and args.layout == "pm") else None       # pyramid streamed inside the forward
 
     def step(record=False):
         e0, e1, e2 = (ev(), ev(), ev()) if record else (None, None, None)
         if record:
             e0.record()
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                inputs = pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
-                if record:
-                    e1.record()
+            inputs = {"dpt_xyz": dpt_xyz}
+            if record:
+                e1.record()
         else:
             inputs = pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
             if record:
@@ -326,6 +326,16 @@ def main():
             torch.cuda.synchronize()
             _lib.TRACER = None
             net.two_streams, side = True, keep_side
+        pyr_alone_ms = None
+        if pyramid_on_side and rank == 0:       # the pyramid by itself (it has no interval of its own inside a streamed step)
+            pe = [ev(), ev()]
+            pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
+            pe[0].record()
+            for _ in range(5):
+                pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
+            pe[1].record()
+            torch.cuda.synchronize()
+            pyr_alone_ms = pe[0].elapsed_time(pe[1]) / 5
 
         if args.trace_all and rank == 0:
             full = _lib.Tracer(None)
@@ -392,7 +402,12 @@ def main():
         summary = tracer.summary()
         # dominant hand-written op of the timed steps.  KNN is latency/VALU bound (10.7 MB of
         # algorithmic bytes per frame) and is reported through hot_path_ops instead.
-        cand = {k: v for k, v in summary.items() if not k.startswith("knn") and v["launches"]}
+        # Chosen on the one-stream pass when there is one: with two or three streams an event bracket also counts the time a
+        # launch waits behind the other streams' kernels, which can make a latency-bound op look dominant.
+        if serial is not None:
+            split_mlp(serial)
+        pick_from = serial.summary() if serial is not None else summary
+        cand = {k: v for k, v in pick_from.items() if not k.startswith("knn") and v["launches"] and k in summary}
         roof_op = args.roofline_op if args.roofline_op != "auto" else \
             (max(cand, key=lambda k: cand[k]["total_ms"]) if cand else None)
         roofline = None
@@ -415,7 +430,6 @@ def main():
             else:
                 roofline["algorithmic_bytes_per_launch"] = r["bytes"] / r["launches"]
         if roofline and serial is not None:
-            split_mlp(serial)
             iso = roofline_of(serial, roof_op)
             if iso:
                 roofline["isolated"] = {"achieved": iso["achieved"], "frac": iso["frac"], "avg_launch_us": iso["avg_launch_us"],
@@ -468,11 +482,12 @@ def main():
                        "index_dtype": args.index_dtype, "layout": args.layout,
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "
                                       f"{args.dist_backend if world > 1 else 'no'} process group)"},
-            "breakdown_ms": ({"knn_pyramid_on_side_stream": pyr_ms, "step_on_main_stream": fwd_ms,
-                              "note": "pyramid + point branch run under the colour branch; both intervals "
-                                      "start at the step's first event and overlap"}
+            "breakdown_ms": ({"step": fwd_ms, "knn_pyramid_alone": pyr_alone_ms,
+                              "note": "the forward builds the index pyramid itself, level by level on a third HIP stream, "
+                                      "under the network (forward_pm.StreamedPyramid); knn_pyramid_alone = the same 22 "
+                                      "searches run by themselves after the timed region"}
                              if pyramid_on_side else {"knn_pyramid": pyr_ms, "forward": fwd_ms}),
-            "streams": 2 if overlap else 1,
+            "streams": (3 if pyramid_on_side else 2) if overlap else 1,
             **({} if pyramid_on_side else {"forward_only_fps": args.batch * world / (fwd_ms * 1e-3)}),
             "roofline": roofline,
             # hot-path-only time, i.e. without the MIOpen convolutions of the colour branch = sum of

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import forward_pm, ops
+from . import forward_pm, ops, pyramid
 from .forward_pm import cached, mlp_sources
 
 D_OUT = (32, 64, 128, 256)   # ConfigRandLA.d_out (ffb6d/common.py:26)
@@ -480,6 +480,17 @@ class FFB6D(nn.Module):
     # bfloat16 activations and weights, fp32 accumulation / BatchNorm / softmax arithmetic, fp32 end_points)
     precision = "fp32"
 
+    # dtype of the indices when the forward builds the index pyramid itself (inputs carry 'dpt_xyz' instead of the 26
+    # index tensors): int64 is what model_fn feeds the reference network (train_lm.py:236-237)
+    index_dtype = torch.int64
+
+    def _index_stream(self, device):
+        st = getattr(self, "_idx_stream", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device, priority=-1)
+            self._idx_stream = st
+        return st
+
     def _side_stream(self, device):
         st = getattr(self, "_side", None)
         if st is None or st.device != device:
@@ -596,10 +607,20 @@ class FFB6D(nn.Module):
     def forward(self, inputs, end_points=None, scale=1, taps=None):
         if not end_points:
             end_points = {}
-        if os.environ.get("FFB6D_CHECK_INDICES") == "1" and inputs['rgb'].is_cuda:
+        if os.environ.get("FFB6D_CHECK_INDICES") == "1" and inputs['rgb'].is_cuda and 'cld_nei_idx0' in inputs:
             self.check_indices(inputs)
         rgb = inputs['rgb']
         fused = not _autograd_path(rgb, self)
+        if 'cld_nei_idx0' not in inputs:
+            # no index pyramid in the dict (the dataset's 22 knn_search calls, linemod_dataset.py:299-353): build it on
+            # the device from the xyz image.  The fused point-major path streams it level by level under the network;
+            # every other path builds it up front.
+            if 'dpt_xyz' not in inputs:
+                raise KeyError("inputs carry neither the index pyramid ('cld_nei_idx0', ...) nor 'dpt_xyz' to build it from")
+            if not (fused and self.layout == "pm" and forward_pm.supported(self)) or taps is not None:
+                inputs = dict(inputs)
+                inputs.update(pyramid.build_index_pyramid(inputs['cld_rgb_nrm'][:, :3, :].transpose(1, 2).contiguous(),
+                                                          inputs['dpt_xyz'], index_dtype=self.index_dtype))
         if fused and self.layout == "pm" and forward_pm.supported(self):
             return forward_pm.forward(self, inputs, end_points, two_streams=self.two_streams, taps=taps)
         if self.two_streams and fused and (rgb.shape[2] * rgb.shape[3]) % 16 == 0:

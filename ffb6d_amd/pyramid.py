@@ -32,51 +32,75 @@ def strided_grid(dpt_xyz, s):
     return g.reshape(B, 3, h * w).transpose(1, 2).contiguous()
 
 
+class PyramidBuilder:
+    """The pyramid level by level, so that a consumer can start on level 0 while the later levels are still being
+    searched (forward_pm.forward enqueues the levels on their own HIP stream): `encoder_level(i)` for i = 0..3 in
+    order, then `decoder_level(i)` for i = 0..2.  Each returns the keys of that level."""
+
+    def __init__(self, cld, dpt_xyz, index_dtype=torch.int64):
+        if cld.dim() != 3 or cld.shape[2] != 3 or dpt_xyz.dim() != 4 or dpt_xyz.shape[1] != 3:
+            raise ValueError(f"bad shapes {tuple(cld.shape)} / {tuple(dpt_xyz.shape)}")
+        self.B = cld.shape[0]
+        self.index_dtype = index_dtype
+        self.dpt_xyz = dpt_xyz
+        self.grids = {}
+        self.prepared = {}
+        self.cur = cld.contiguous()
+        self.xyz = []
+
+    def grid(self, s):
+        if s not in self.grids:
+            self.grids[s] = strided_grid(self.dpt_xyz, s)
+        return self.grids[s]
+
+    def search(self, support, query, k):
+        """Route big supports through Morton-prepared sets (each set is sorted once and reused by
+        every search that touches it), small ones through the brute-force scan."""
+        prepared = self.prepared
+        if not uses_pruning(self.B, support.shape[1], query.shape[1], k):
+            return knn_batch_device(support, query, k, dtype=self.index_dtype)
+        if id(support) not in prepared:
+            prepared[id(support)] = PreparedPoints(support)
+        if k >= 2 and id(query) not in prepared:
+            # 16-lane rows work on one query each: unsorted queries are fine, skip their sort
+            return knn_prepared(prepared[id(support)], query, k, dtype=self.index_dtype)
+        if id(query) not in prepared:
+            prepared[id(query)] = PreparedPoints(query)
+        return knn_prepared(prepared[id(support)], prepared[id(query)], k, dtype=self.index_dtype)
+
+    def encoder_level(self, i):
+        assert i == len(self.xyz), "levels are built in order"
+        cur = self.cur
+        n_sub = cur.shape[1] // SUB_RATIO[i]
+        nei = self.search(cur, cur, K_NEI)
+        sub = cur[:, :n_sub, :].contiguous()
+        g = self.grid(RGB_DS_SR[i])
+        out = {'cld_xyz%d' % i: cur, 'cld_nei_idx%d' % i: nei, 'cld_sub_idx%d' % i: nei[:, :n_sub, :].contiguous(),
+               'cld_interp_idx%d' % i: self.search(sub, cur, 1),
+               'r2p_ds_nei_idx%d' % i: self.search(g, sub, K_NEI), 'p2r_ds_nei_idx%d' % i: self.search(sub, g, 1)}
+        self.xyz.append(cur)
+        self.cur = sub
+        return out
+
+    def decoder_level(self, i):
+        assert len(self.xyz) == 4, "decoder levels come after the four encoder levels"
+        g = self.grid(RGB_UP_SR[i])
+        pts = self.xyz[3 - i]
+        return {'r2p_up_nei_idx%d' % i: self.search(g, pts, K_NEI), 'p2r_up_nei_idx%d' % i: self.search(pts, g, 1)}
+
+
 def build_index_pyramid(cld, dpt_xyz, index_dtype=torch.int64):
     """cld [B,N,3] f32, dpt_xyz [B,3,H,W] f32 (both on the GPU) -> dict with the reference's
     key names: cld_xyz{i}, cld_nei_idx{i}, cld_sub_idx{i}, cld_interp_idx{i},
     r2p_ds_nei_idx{i}, p2r_ds_nei_idx{i} (i=0..3), r2p_up_nei_idx{i}, p2r_up_nei_idx{i}
     (i=0..2).  Index dtype int64 is what `model_fn` feeds the network (train_lm.py:236-237);
     int32 is what the dataset stores (halves the index traffic of every gather)."""
-    if cld.dim() != 3 or cld.shape[2] != 3 or dpt_xyz.dim() != 4 or dpt_xyz.shape[1] != 3:
-        raise ValueError(f"bad shapes {tuple(cld.shape)} / {tuple(dpt_xyz.shape)}")
-    B = cld.shape[0]
-    grids = {s: strided_grid(dpt_xyz, s) for s in sorted(set(RGB_DS_SR + RGB_UP_SR))}
-    prepared = {}
-
-    def search(support, query, k):
-        """Route big supports through Morton-prepared sets (each set is sorted once and reused by
-        every search that touches it), small ones through the brute-force scan."""
-        if not uses_pruning(B, support.shape[1], query.shape[1], k):
-            return knn_batch_device(support, query, k, dtype=index_dtype)
-        if id(support) not in prepared:
-            prepared[id(support)] = PreparedPoints(support)
-        if k >= 2 and id(query) not in prepared:
-            # 16-lane rows work on one query each: unsorted queries are fine, skip their sort
-            return knn_prepared(prepared[id(support)], query, k, dtype=index_dtype)
-        if id(query) not in prepared:
-            prepared[id(query)] = PreparedPoints(query)
-        return knn_prepared(prepared[id(support)], prepared[id(query)], k, dtype=index_dtype)
-
+    b = PyramidBuilder(cld, dpt_xyz, index_dtype)
     out = {}
-    cur = cld.contiguous()
     for i in range(4):
-        n_sub = cur.shape[1] // SUB_RATIO[i]
-        nei = search(cur, cur, K_NEI)
-        sub = cur[:, :n_sub, :].contiguous()
-        out['cld_xyz%d' % i] = cur
-        out['cld_nei_idx%d' % i] = nei
-        out['cld_sub_idx%d' % i] = nei[:, :n_sub, :].contiguous()
-        out['cld_interp_idx%d' % i] = search(sub, cur, 1)
-        g = grids[RGB_DS_SR[i]]
-        out['r2p_ds_nei_idx%d' % i] = search(g, sub, K_NEI)
-        out['p2r_ds_nei_idx%d' % i] = search(sub, g, 1)
-        cur = sub
+        out.update(b.encoder_level(i))
     for i in range(3):
-        g = grids[RGB_UP_SR[i]]
-        pts = out['cld_xyz%d' % (3 - i)]
-        out['r2p_up_nei_idx%d' % i] = search(g, pts, K_NEI)
-        out['p2r_up_nei_idx%d' % i] = search(pts, g, 1)
+        out.update(b.decoder_level(i))
     return out
 
 

@@ -253,6 +253,40 @@ def test_two_stream_forward_equals_single_stream(device):
                     assert float((got[k] - want[k]).abs().max()) <= HOT_TOL * scale, (rep, k)
 
 
+@pytest.mark.parametrize("layout,two_streams", [("pm", True), ("pm", False), ("cm", True)])
+def test_forward_builds_the_index_pyramid_itself_when_it_is_missing(device, layout, two_streams):
+    """Inputs that carry `dpt_xyz` instead of the 26 index tensors: the forward runs the dataset's 22 KNN searches
+    (linemod_dataset.py:299-353) on the device -- the point-major path level by level on a third HIP stream under the
+    network (forward_pm.StreamedPyramid) -- and must produce the bits of the forward fed with a prebuilt pyramid.
+    Repeated with recycled NaN blocks so that a missing event / record_stream shows up as a race."""
+    frames = synth.make_batch(9, 2, n_points=12288, height=480, width=640)
+    net = build(22, 12288, device)
+    net.layout, net.two_streams = layout, two_streams
+    full = pyramid.frames_to_device(frames, device)
+    lazy = {k: full[k] for k in ('rgb', 'cld_rgb_nrm', 'choose')}
+    lazy['dpt_xyz'] = torch.from_numpy(frames['dpt_xyz']).to(device)
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in net(full).items()}
+        again = net(full)
+        reproducible = all(torch.equal(again[k], want[k]) for k in want)
+        for rep in range(3):
+            got = net(lazy)
+            junk = torch.empty(64 << 20, device=device).fill_(float("nan"))
+            del junk
+            for k in want:
+                if reproducible:
+                    assert torch.equal(got[k], want[k]), (rep, k, float((got[k] - want[k]).abs().max()))
+                else:
+                    assert float((got[k] - want[k]).abs().max()) <= HOT_TOL * float(want[k].abs().max()), (rep, k)
+        with pytest.raises(KeyError):
+            net({k: full[k] for k in ('rgb', 'cld_rgb_nrm', 'choose')})
+    net.index_dtype = torch.int32
+    with torch.no_grad():
+        got = net(lazy)
+    for k in want:
+        assert float((got[k] - want[k]).abs().max()) <= HOT_TOL * float(want[k].abs().max()), k
+
+
 def test_batch_items_are_independent(device):
     """Every op on the path is per-sample in eval mode: a frame's
     result must not depend on its batch neighbours -- the property multi-GPU sharding relies on."""
