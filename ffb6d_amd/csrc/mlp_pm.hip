@@ -31,6 +31,8 @@
 // (lane l: k0 + 8*(l>>5) .. +7) -- so the byte arithmetic of the operand stream is identical: a step is 32 bytes of
 // every row, i.e. 8 k and four MFMAs in fp32, 16 k and ONE MFMA (16x the rate) in bf16.  Bias and all epilogue
 // arithmetic stay fp32; stores round to nearest even (v_cvt_pk_bf16_f32).
+#include <algorithm>
+
 #include "common.h"
 #include "ffb6d_ops.h"
 
@@ -117,7 +119,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 
 // epilogue shared by the GEMM kernels: bias, gathered / added row of Y, activation or log-softmax, store
-template <typename T, int TM, int TN>
+// LSM = false compiles the log-softmax branch out (it needs all channels of a point live at once: 16 * TM more registers)
+template <typename T, int TM, int TN, bool LSM = true>
 __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM][TN], int c0, int r0, int wm, int wn, int l31, int kh)
 {
     constexpr int SZ = El<T>::SZ;
@@ -144,7 +147,27 @@ __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM]
             yrow = yb + yr * p.ldy;
         }
         T* orow = ob + (size_t)r * p.ldo;
-        if (vec) {
+        if (vec && !(LSM && p.act == 3)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
+                    float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    if (ch >= p.cout || !live) continue;
+                    if (p.bias) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                    }
+                    if (yrow) {
+                        const float4 y4 = El<T>::ld4(yrow + ch);
+                        v.x += y4.x; v.y += y4.y; v.z += y4.z; v.w += y4.w;
+                    }
+                    El<T>::st4(orow + ch, make_float4(activate(v.x, slope), activate(v.y, slope), activate(v.z, slope),
+                                                      activate(v.w, slope)));
+                }
+            }
+        } else if (vec) {
             float4 v[TM][4];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -163,7 +186,7 @@ __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM]
                     }
                 }
             }
-            if (p.act == 3) {
+            {
                 // log_softmax over the channels of a point (pspnet.py:108-112 `final`): the launcher guarantees that the
                 // wave's tile spans all cout channels; a point's channels sit in lanes l and l ^ 32
                 float m = -INFINITY;
@@ -190,16 +213,6 @@ __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM]
                         const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
                         if (ch < p.cout && live)
                             El<T>::st4(orow + ch, make_float4(v[i][g].x - lse, v[i][g].y - lse, v[i][g].z - lse, v[i][g].w - lse));
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
-                        if (ch < p.cout && live)
-                            El<T>::st4(orow + ch, make_float4(activate(v[i][g].x, slope), activate(v[i][g].y, slope),
-                                                              activate(v[i][g].z, slope), activate(v[i][g].w, slope)));
                     }
             }
         } else if (live) {
@@ -350,6 +363,225 @@ mlp_pm_kernel(const PmParams p)
     }
 
     pm_epilogue<T, TM, TN>(p, acc, c0, r0, wm, wn, l31, kh);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stream form of the same GEMM for the HBM-bound layers: short rows (K <= 128 fp32 / 256 bf16) and cout <= 128, where a launch
+// moves far more bytes than it has MFMA work (64 -> 64 on 2.4 M pixels: 1.26 GB against 20 GFLOP).  PMC of mlp_pm_kernel on
+// that layer (profiles/r02_mlp_pm_stream_pmc.txt): HBM traffic = the algorithmic bytes, MFMA pipe 35 % busy, waves waiting
+// 55 % of their cycles, 3.0 TB/s where a plain copy of the same bytes runs at 5.4.  The limiter is the texture-address path:
+// an MFMA-fragment-shaped load or store touches 32 rows x 32 bytes per instruction (64 tag look-ups for 1 KB), and every
+// wave re-fetches W that way for every 32-byte step.  Here every global access is whole rows:
+//   * persistent workgroups (a few per CU) walk the point tiles; W (all cout rows) sits in LDS for the life of the workgroup;
+//   * a wave owns 32 points x ALL channels, so X is read exactly once; the tile's rows are fetched as contiguous 16-byte
+//     chunks (16 lanes = one 256-byte row), parked in a wave-private LDS image and picked up from there in fragment order
+//     (row stride = odd multiple of 16 bytes: conflict-free ds_read_b128); the loads of the next two tiles are in flight
+//     (two register sets, loop unrolled by two) while the current one is multiplied and written;
+//   * the epilogue (bias, gathered / added Y row, activation, log-softmax -- the arithmetic of pm_epilogue) deposits the
+//     result rows in the same LDS image and they leave as whole rows too.
+// No barrier after the W copy: each wave reads and writes only its own image.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int TM, bool LSM>
+__device__ __forceinline__ void stream_epilogue(const PmParams& p, f32x16 (&acc)[TM][1], unsigned char* img, int os, int r0,
+                                                int l31, int kh)
+{
+    const T* yb = static_cast<const T*>(p.y);
+    const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
+    const int r = r0 + l31;
+    const bool live = r < p.rows;
+    const T* yrow = nullptr;
+    if (yb && live) {
+        long long yr = r;
+        if (p.gidx) {
+            const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[r] : (long long)static_cast<const int*>(p.gidx)[r];
+            yr = (long long)(r / p.P) * p.py + gi;
+        }
+        yrow = yb + yr * p.ldy;
+    }
+    T* orow = reinterpret_cast<T*>(img + l31 * os);
+    auto value = [&](int i, int g, int ch) {
+        float4 v = make_float4(acc[i][0][4 * g], acc[i][0][4 * g + 1], acc[i][0][4 * g + 2], acc[i][0][4 * g + 3]);
+        if (ch < p.cout && live) {
+            if (p.bias) {
+                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
+                v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            }
+            if (yrow) {
+                const float4 y4 = El<T>::ld4(yrow + ch);
+                v.x += y4.x; v.y += y4.y; v.z += y4.z; v.w += y4.w;
+            }
+        }
+        return v;
+    };
+    if (!(LSM && p.act == 3)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = i * 32 + 8 * g + 4 * kh;
+                const float4 v = value(i, g, ch);
+                El<T>::st4(orow + ch, make_float4(activate(v.x, slope), activate(v.y, slope), activate(v.z, slope), activate(v.w, slope)));
+            }
+    } else {
+        // log_softmax over the channels of a point (pspnet.py:108-112 `final`); a point's channels sit in lanes l and l ^ 32
+        float4 v[TM][4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = i * 32 + 8 * g + 4 * kh;
+                v[i][g] = value(i, g, ch);
+                if (ch < p.cout) m = fmaxf(fmaxf(fmaxf(m, v[i][g].x), fmaxf(v[i][g].y, v[i][g].z)), v[i][g].w);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (i * 32 + 8 * g + 4 * kh < p.cout)
+                    sum += (expf(v[i][g].x - m) + expf(v[i][g].y - m)) + (expf(v[i][g].z - m) + expf(v[i][g].w - m));
+        sum += __shfl_xor(sum, 32, 64);
+        const float lse = m + logf(sum);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                El<T>::st4(orow + i * 32 + 8 * g + 4 * kh,
+                           make_float4(v[i][g].x - lse, v[i][g].y - lse, v[i][g].z - lse, v[i][g].w - lse));
+    }
+}
+
+template <typename T, int TM, int NS, bool LSM, bool TWO>
+__global__ void __launch_bounds__(BLK)
+mlp_pm_stream_kernel(const PmParams p)
+{
+    constexpr int SZ = El<T>::SZ;
+    constexpr int CRX = 2 * NS;                       // 16-byte chunks of an X / W image row (K is padded with zeros to NS steps)
+    constexpr int XS = NS * 32 + 16;                  // X and W image row stride, bytes
+    constexpr int CRO = 32 * TM * SZ / 16;            // chunks of an output image row (capacity)
+    constexpr int OS = 32 * TM * SZ + 16;             // output image row stride
+    constexpr int IMG = 32 * (XS > OS ? XS : OS);     // bytes of a wave's image (X and output rows share it)
+    constexpr int NPRE = NS <= 8 ? 2 : 1;             // tiles of loads in flight ahead of the one being multiplied
+    constexpr int OOB = 0x7ffffff0;                   // byte offset past every buffer -> loads return zeros, stores are dropped
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 4 wave images, then W [32 * TM][XS]
+
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = p.k1 + p.k2;
+    const int c1 = p.k1 * SZ / 16, crx = K * SZ / 16, cro = p.cout * SZ / 16;      // chunks: of x1, of a row [x1|x2], of an output row
+    unsigned char* img = lds + wave * IMG;
+    unsigned char* w_lds = lds + 4 * IMG;
+
+    {   // W -> LDS, once: rows past cout and columns past K read as zeros
+        const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)K * SZ);
+        for (int u = threadIdx.x; u < 32 * TM * CRX; u += BLK) {
+            const int row = u / CRX, col = u % CRX;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, col < crx ? (row * K * SZ) + col * 16 : OOB, 0, 0);
+            *reinterpret_cast<u32x4*>(w_lds + row * XS + col * 16) = v;
+        }
+        __syncthreads();
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, (unsigned)p.rows * (unsigned)p.ld1 * SZ);
+    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(TWO ? p.x2 : p.x1, TWO ? (unsigned)p.rows * (unsigned)p.ld2 * SZ : 0u);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, (unsigned)p.rows * (unsigned)p.ldo * SZ);
+
+    // whole rows: load j of a lane is chunk (64 j + lane) % CRX of image row (64 j + lane) / CRX; chunks past K stay zero
+    constexpr int RPI = 64 / CRX;                                      // rows per instruction (CRX <= 32)
+    const int lrow = lane / CRX, lchunk = lane % CRX;
+    const bool from1 = lchunk < c1, from2 = TWO && !from1 && lchunk < crx;
+    const int src1 = from1 ? lchunk * 16 : OOB, src2 = from2 ? (lchunk - c1) * 16 : OOB;
+    const int step1 = RPI * p.ld1 * SZ, step2 = RPI * p.ld2 * SZ;
+
+    auto gload = [&](int t, u32x4 (&x)[NS]) {
+        const int rbase = t * 128 + wave * 32 + lrow;
+        const int o1 = rbase * p.ld1 * SZ, o2 = rbase * p.ld2 * SZ;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const bool live = rbase + j * RPI < p.rows;
+            x[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x1, (live && from1) ? o1 + j * step1 + src1 : OOB, 0, 0);
+            if constexpr (TWO) {      // second source: a lane takes its chunk from exactly one of the two, the other load returns zeros
+                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, (live && from2) ? o2 + j * step2 + src2 : OOB, 0, 0);
+                x[j] |= b;
+            }
+        }
+    };
+    auto stage = [&](const u32x4 (&x)[NS]) {          // registers -> this wave's image
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            *reinterpret_cast<u32x4*>(img + (lrow + j * RPI) * XS + lchunk * 16) = x[j];
+    };
+    auto compute = [&](int t) {
+        f32x16 acc[TM][1];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        // fragments of step s + 1 are read while step s is multiplied (two register sets; the pins keep hipcc from hoisting
+        // every ds_read of the tile above the first MFMA, which costs 4 * NS * (TM + 1) registers)
+        u32x4 wa[2][TM], xf[2][1];
+        auto frags = [&](int s, u32x4 (&wf)[TM], u32x4 (&xv)[1]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                wf[i] = *reinterpret_cast<const u32x4*>(w_lds + (i * 32 + l31) * XS + (2 * s + kh) * 16);
+            xv[0] = *reinterpret_cast<const u32x4*>(img + l31 * XS + (2 * s + kh) * 16);
+        };
+        frags(0, wa[0], xf[0]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) frags(s + 1, wa[(s + 1) & 1], xf[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step<T, TM, 1>(acc, wa[s & 1], xf[s & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int r0 = t * 128 + wave * 32;
+        stream_epilogue<T, TM, LSM>(p, acc, img, OS, r0, l31, kh);
+        // whole result rows out of the image
+        constexpr int OPI = 64 / CRO;                 // rows per instruction (CRO <= 32)
+        const int orow = lane / CRO, ochunk = lane % CRO;
+        const int ob = (r0 + orow) * p.ldo * SZ + ochunk * 16, ostep = OPI * p.ldo * SZ;
+#pragma unroll
+        for (int j = 0; j < CRO / 2; ++j) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(img + (orow + j * OPI) * OS + ochunk * 16);
+            const bool live = r0 + orow + j * OPI < p.rows && ochunk < cro;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, live ? ob + j * ostep : OOB, 0, 0);
+        }
+    };
+
+#define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
+    const int stride = gridDim.x;
+    int t = blockIdx.x;
+    if constexpr (NPRE == 2) {
+        u32x4 xa[NS], xb[NS];
+        gload(t, xa);
+        gload(t + stride, xb);
+        while (true) {
+            stage(xa);                    FFB6D_PIN();
+            gload(t + 2 * stride, xa);    FFB6D_PIN();
+            compute(t);                   FFB6D_PIN();
+            t += stride;
+            if (t >= p.n_pt) break;
+            stage(xb);                    FFB6D_PIN();
+            gload(t + 2 * stride, xb);    FFB6D_PIN();
+            compute(t);                   FFB6D_PIN();
+            t += stride;
+            if (t >= p.n_pt) break;
+        }
+    } else {
+        u32x4 xa[NS];
+        gload(t, xa);
+        while (true) {
+            stage(xa);                    FFB6D_PIN();
+            gload(t + stride, xa);        FFB6D_PIN();
+            compute(t);                   FFB6D_PIN();
+            t += stride;
+            if (t >= p.n_pt) break;
+        }
+    }
+#undef FFB6D_PIN
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -505,12 +737,47 @@ void launch_pm(PmParams& p, hipStream_t st)
     hipLaunchKernelGGL((mlp_pm_kernel<T, TM, TN, WM, WN, KSPLIT>), dim3(grid), dim3(BLK), 0, st, p);
 }
 
+template <typename T, int TM, int NS, bool LSM, bool TWO>
+void launch_stream(PmParams& p, hipStream_t st)
+{
+    constexpr int SZ = El<T>::SZ;
+    p.n_ct = 1;
+    p.n_pt = (int)ceil_div(p.rows, 128);
+    constexpr size_t XS = NS * 32 + 16, OS = 32 * TM * SZ + 16, IMG = 32 * (XS > OS ? XS : OS);       // as in the kernel
+    constexpr size_t lds = 4 * IMG + (size_t)32 * TM * XS;
+    const void* fn = reinterpret_cast<const void*>(&mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>);
+    // resident workgroups per CU: registers (the X sets in flight + accumulators) and LDS (four wave images + the W copy)
+    static const int per_cu = [&] {
+        int n = 0;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, BLK, lds) != hipSuccess || n < 1)
+            n = 1;
+        return n;
+    }();
+    const unsigned grid = (unsigned)std::min<int64_t>(p.n_pt, (int64_t)256 * per_cu);
+    hipLaunchKernelGGL((mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>), dim3(grid), dim3(BLK), lds, st, p);
+}
+
 template <typename T, int TM, int TN>
 void launch_att(AttParams& p, hipStream_t st)
 {
     p.n_ct = (int)ceil_div(p.c1 + p.c2, 32 * TN);
     p.n_pt = (int)ceil_div(p.npts, 2 * TM * 4);
     hipLaunchKernelGGL((att_pool_pm_kernel<T, TM, TN>), dim3((unsigned)(ceil_div(p.n_pt, 8) * p.n_ct * 8)), dim3(BLK), 0, st, p);
+}
+
+// the stream form handles: cout <= 128, 96 <= K * SZ <= 512 bytes, plain (ungathered) operand rows, 16-byte aligned output
+// rows, and log-softmax only for a single source
+template <typename T>
+bool stream_form_ok(const PmParams& p, int64_t K)
+{
+    constexpr int SZ = El<T>::SZ;
+    constexpr int KSTEP = 32 / SZ;
+    const int64_t ns = K / KSTEP;
+    return p.cout <= 128 && ns >= 3 && ns <= 16 && !p.xidx && (p.cout * SZ) % 16 == 0 && (p.ldo * SZ) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 &&
+           (!p.y || ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.y) & (4 * SZ - 1)) == 0)) &&
+           ((int64_t)p.rows + 256) * p.ldo * SZ < (1LL << 31) && !(p.act == 3 && (p.k2 > 0 || p.cout > 64));
 }
 
 template <typename T>
@@ -553,13 +820,41 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
     p.px = (int)x1_rows_per_frame; p.act = act;
     p.idx64 = idx_bits == 64;
     hipStream_t st = as_stream(stream);
-    const int choice = tile_hint > 0 ? tile_hint : ffb6d_mlp_pm_tile(rows, cout, K, act);
+    int choice = tile_hint;
+    if (choice <= 0) {
+        choice = ffb6d_mlp_pm_choice(rows, cout, k1, k2, act, SZ == 2, x1_idx != nullptr);
+        if (choice == 6 && !stream_form_ok<T>(p, K)) choice = ffb6d_mlp_pm_tile(rows, cout, K, act);      // misaligned rows
+    }
     switch (choice) {
         case 1: launch_pm<T, 2, 2, 2, 2, false>(p, st); break;      // 128 ch x 128 pt
         case 2: launch_pm<T, 2, 2, 1, 4, false>(p, st); break;      // 64 ch x 256 pt
         case 3: launch_pm<T, 1, 2, 1, 4, false>(p, st); break;      // 32 ch x 256 pt
         case 4: launch_pm<T, 1, 1, 2, 2, false>(p, st); break;      // 64 ch x 64 pt
         case 5: launch_pm<T, 2, 1, 2, 2, true>(p, st); break;       // 64 ch x 32 pt, K over the 4 waves
+        case 6: {                                                   // stream form: all channels x 32 pt per wave, whole-row traffic
+            const int ns = (int)(K / KSTEP);
+            FFB6D_REQUIRE(stream_form_ok<T>(p, K), "mlp_pm: the stream form needs cout <= 128, %d <= K <= %d, no operand gather and "
+                          "16-byte aligned output rows", 3 * KSTEP, 16 * KSTEP);
+            const int tm = cout <= 32 ? 1 : (cout <= 64 ? 2 : 4);
+            const bool two = k2 > 0;
+#define FFB6D_STREAM_NS(TM_, LSM_, TWO_)                                          \
+    do {                                                                          \
+        if (ns <= 4) launch_stream<T, TM_, 4, LSM_, TWO_>(p, st);                 \
+        else if (ns <= 8) launch_stream<T, TM_, 8, LSM_, TWO_>(p, st);            \
+        else launch_stream<T, TM_, 16, LSM_, TWO_>(p, st);                        \
+    } while (0)
+#define FFB6D_STREAM(TM_)                                                         \
+    do {                                                                          \
+        if (two) FFB6D_STREAM_NS(TM_, false, true); else FFB6D_STREAM_NS(TM_, false, false); \
+    } while (0)
+            if (act == 3) { if (tm == 1) FFB6D_STREAM_NS(1, true, false); else FFB6D_STREAM_NS(2, true, false); }
+            else if (tm == 1) FFB6D_STREAM(1);
+            else if (tm == 2) FFB6D_STREAM(2);
+            else FFB6D_STREAM(4);
+#undef FFB6D_STREAM
+#undef FFB6D_STREAM_NS
+            break;
+        }
         default: return set_error(FFB6D_ERR_ARG, "mlp_pm: unknown tile_hint %d", tile_hint);
     }
     FFB6D_LAUNCH_CHECK();
@@ -614,6 +909,17 @@ extern "C" int ffb6d_mlp_pm_tile(int64_t rows, int64_t cout, int64_t K, int act)
     if (cout <= 32) return ceil_div(rows, 256) >= 256 ? 3 : 5;
     if (small >= 512 || K < 64) return 4;
     return 5;
+}
+
+// Kernel form for tile_hint 0: the stream form (6) on the short-row layers it is faster on (profiles/r02_mlp_pm_stream_ab.txt:
+// every single-source shape with 96..512-byte rows and cout <= 128 once there are >= 128 tiles; two-source rows in bf16 only),
+// else the tile shape of ffb6d_mlp_pm_tile.
+extern "C" int ffb6d_mlp_pm_choice(int64_t rows, int64_t cout, int64_t k1, int64_t k2, int act, int bf16, int x1_gathered)
+{
+    const int64_t K = k1 + k2, row_bytes = K * (bf16 ? 2 : 4);
+    const bool stream = cout <= 128 && row_bytes >= 96 && row_bytes <= 512 && !x1_gathered && rows >= 16384 &&
+                        (cout * (bf16 ? 2 : 4)) % 16 == 0 && (k2 == 0 || bf16) && !(act == 3 && (k2 > 0 || cout > 64));
+    return stream ? 6 : ffb6d_mlp_pm_tile(rows, cout, K, act);
 }
 
 #define FFB6D_MLP_PM_ARGS                                                                                                    \

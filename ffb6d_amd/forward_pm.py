@@ -297,20 +297,30 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
     def on_side():
         return torch.cuda.stream(side)
 
-    def handover(t, producer, consumer):
+    probe = getattr(net, "_stall_probe", None)      # diagnostics: list that receives (tag, event, event) around every wait
+
+    def handover(t, producer, consumer, tag=None):
         """tensor produced on `producer`, about to be read on `consumer`"""
         if producer is not consumer:
             ev = torch.cuda.Event()
             ev.record(producer)
+            if probe is not None:
+                a = torch.cuda.Event(enable_timing=True)
+                a.record(consumer)
             consumer.wait_event(ev)
+            if probe is not None:
+                b = torch.cuda.Event(enable_timing=True)
+                b.record(consumer)
+                probe.append((tag, a, b))
             t.record_stream(consumer)
         return t
 
     def fuse(i, pre_p2r, fuse_p2r, pre_r2p, fuse_r2p, rgb0, p0, p2r_idx, r2p_idx):
         """One bidirectional fusion step (ffb6d.py:245-263 / 281-298); both directions read the pre-fusion tensors."""
         B, h, w_, c = rgb0.shape
-        handover(p0, side, main)
-        handover(rgb0, main, side)
+        st = ("ds%d" if pre_p2r is net.ds_fuse_p2r_pre_layers else "up%d") % i
+        handover(p0, side, main, "main waits for point stage " + st)
+        handover(rgb0, main, side, "side waits for colour stage " + st)
         if two_streams:
             p2r_idx.record_stream(main)
         # p2r on main: conv(cat(rgb0, interp(e))) = W_a rgb0 + gather(W_b e)
@@ -370,7 +380,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
     rgb_emb = cnn_stage(net.cnn_up_stages[n_up - 1], rgb_emb)
     with on_side():
         p_emb = decode(net.rndla_up_stages[n_up - 1], ds_emb[0], p_emb, inputs['cld_interp_idx0'])
-    handover(p_emb, side, main)                 # also the final join: main is behind all side work
+    handover(p_emb, side, main, "main waits for the last decoder")                 # also the final join: main is behind all side work
 
     # ---- heads: conv(cat(rgb[choose], p_emb)) with the pick as the operand gather of the first GEMM ----
     B, H, W_, c = rgb_emb.shape

@@ -97,7 +97,7 @@ def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gathe
     nbytes = esz * ((K1 + K2) * Cout + rows * (K1 + K2) + rows * Cout) + rows * (bits // 8) * ((gi is not None) + (xi is not None)) + \
         (esz * (y.shape[0] if gi is None else rows) * Cout if y is not None else 0)
     if _lib.TRACER is not None:      # tag = the kernel instantiation a profile lists this launch under
-        tile = int(tile_hint) if tile_hint > 0 else lib.ffb6d_mlp_pm_tile(rows, Cout, K1 + K2, int(act))
+        tile = int(tile_hint) if tile_hint > 0 else lib.ffb6d_mlp_pm_choice(rows, Cout, K1, K2, int(act), int(dt), int(xi is not None))
     else:
         tile = 0
     with torch.cuda.device(x1.device), _lib.traced("mlp_pm", nbytes, (K1 + K2, Cout, rows, tile, dt)):

@@ -150,7 +150,8 @@ int ffb6d_fill_missing_f32(const float* depth, double cam_scale, double scale_2_
  * Optional epilogue rows y [.., ldy]: with y_idx [rows] row (r / rows_per_frame) * y_rows_per_frame + y_idx[r]
  * (conv(cat(a, interp(b))) == W_a a + gather(W_b b), ffb6d.py:247-253,273-279), with y_idx NULL row r itself.
  * idx_bits 32/64 applies to both index arrays.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 log_softmax over the cout <= 64
- * channels (pspnet.py:108-112).  out [rows, ldo].  tile_hint 0 = choose the tile shape from the problem size. */
+ * channels (pspnet.py:108-112).  out [rows, ldo].  tile_hint 0 = choose the kernel form from the problem
+ * (ffb6d_mlp_pm_choice). */
 int ffb6d_mlp_pm_f32(const float* w, const float* bias, const float* x1, int64_t k1, int64_t ld1, const void* x1_idx,
                      int64_t x1_rows_per_frame, const float* x2, int64_t k2, int64_t ld2, const float* y, int64_t ldy,
                      const void* y_idx, int64_t y_rows_per_frame, int idx_bits, int64_t rows_per_frame, float* out,
@@ -159,6 +160,9 @@ int ffb6d_mlp_pm_f32(const float* w, const float* bias, const float* x1, int64_t
 /* Tile shape ffb6d_mlp_pm_f32 picks for tile_hint 0 (pure host logic): 1 = 128 ch x 128 pt, 2 = 64 x 256, 3 = 32 x 256,
  * 4 = 64 x 64, 5 = 64 x 32 with K split over the four waves -- i.e. which kernel instantiation a profile will list. */
 int ffb6d_mlp_pm_tile(int64_t rows, int64_t cout, int64_t K, int act);
+/* Kernel form for tile_hint 0: 6 = the stream form (mlp_pm_stream_kernel: persistent workgroups, W resident in LDS, whole-row
+ * loads and stores through wave-private LDS images) for the HBM-bound short-row layers, else ffb6d_mlp_pm_tile's tile. */
+int ffb6d_mlp_pm_choice(int64_t rows, int64_t cout, int64_t k1, int64_t k2, int act, int bf16, int x1_gathered);
 
 /* Att_pooling.forward up to the pooled tensor (RandLANet.py:243-248) with the neighbour gather fused in:
  * S[(n,k),:] = [ f[nei[n,k],:] | g[(n,k),:] ], out[n,m] = sum_k S[(n,k),m] * softmax_k((S w_fc^T)[(n,k),m]).

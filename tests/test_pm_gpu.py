@@ -37,6 +37,11 @@ CASES = [
 ]
 CASES += [(2, 777, 40, 24, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)] + [(1, 70000, 64, 0, 64, 1, 300, 0), (2, 40000, 16, 0, 16, 2, 0, 0)]
 CASES += [(2, 777, 40, 24, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)] + [(1, 4100, 256, 0, 200, 1, -1, h) for h in (1, 2, 3, 4, 5)]
+# the stream form (hint 6: whole-row loads / stores through LDS images, W resident): every register-set count (K = 24 .. 128),
+# channel-tile count, ragged last tile, two sources, gathered / added epilogue rows; the last two are picked by tile_hint 0
+CASES += [(2, 777, 40, 24, 72, 2, 50, 6), (1, 100000, 64, 0, 64, 1, 0, 6), (2, 5001, 24, 0, 16, 0, 0, 6), (1, 4100, 128, 0, 128, 1, -1, 6),
+          (3, 1300, 32, 96, 100, 2, 70, 6), (1, 130, 64, 0, 32, 1, 0, 6), (1, 40000, 48, 16, 64, 1, 300, 6), (2, 20000, 64, 0, 64, 2, 900, 0),
+          (1, 70000, 128, 0, 128, 1, -1, 0)]
 
 
 @pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", CASES)
@@ -103,8 +108,9 @@ def test_mlp_pm_operand_gather_and_log_softmax(device):
         wf = torch.randn(C, 64, generator=g) / 8
         bf = torch.randn(C, generator=g)
         want = torch.log_softmax((x.double() @ wf.double().t() + bf.double()), dim=-1).float()
-        got = ops_pm.mlp(x.to(device), wf.to(device), bf.to(device), ops_pm.ACT_LOG_SOFTMAX).cpu()
-        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+        for hint in (0, 6):             # 1050 rows: tile kernels; hint 6: the stream form's log-softmax epilogue
+            got = ops_pm.mlp(x.to(device), wf.to(device), bf.to(device), ops_pm.ACT_LOG_SOFTMAX, tile_hint=hint).cpu()
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("B,M,C,Np,K,dt", [(2, 3072, 64, 768, 16, torch.int64), (1, 19200, 64, 3072, 16, torch.int32),
@@ -212,7 +218,9 @@ def _close_bf16(got, want, what=""):
     (2, 12288, 64, 64, 128, 1, 0, 0), (1, 4800, 1024, 0, 1024, 1, 48, 0), (8, 48, 1024, 0, 512, 1, 0, 0),
     (8, 192, 512, 256, 256, 2, 0, 0), (1, 12288, 128, 0, 22, 0, 0, 0), (3, 301, 32, 16, 40, 1, 13, 0),
     (1, 196608, 16, 0, 16, 2, 0, 0), (1, 4800, 512, 0, 1024, 1, -1, 0), (1, 70000, 128, 0, 64, 1, 300, 0)] +
-    [(2, 777, 48, 32, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)])
+    [(2, 777, 48, 32, 72, 2, 50, h) for h in (1, 2, 3, 4, 5, 6)] +
+    [(1, 100000, 64, 0, 64, 1, 0, 6), (2, 5001, 48, 0, 16, 0, 0, 6), (1, 4100, 256, 0, 128, 1, -1, 6), (3, 1300, 64, 96, 104, 2, 70, 6),
+     (1, 70000, 64, 64, 128, 1, 300, 0), (2, 20000, 256, 0, 64, 2, 0, 0)])
 def test_mlp_pm_bf16(device, B, P, K1, K2, Cout, act, py, hint):
     g = torch.Generator().manual_seed(K1 + Cout + P)
     r = lambda *s: torch.randn(*s, generator=g).to(BF)                               # noqa: E731
@@ -246,8 +254,9 @@ def test_att_pool_and_log_softmax_bf16(device):
     x = torch.randn(3, 350, 64, generator=g).to(BF)
     wf, bf = (torch.randn(64, 64, generator=g) / 8).to(BF), torch.randn(64, generator=g)
     want = torch.log_softmax(x.double() @ wf.double().t() + bf.double(), dim=-1)
-    got = ops_pm.mlp(x.to(device), wf.to(device), bf.to(device), ops_pm.ACT_LOG_SOFTMAX).cpu()
-    _close_bf16(got, want, "log_softmax")
+    for hint in (0, 6):
+        got = ops_pm.mlp(x.to(device), wf.to(device), bf.to(device), ops_pm.ACT_LOG_SOFTMAX, tile_hint=hint).cpu()
+        _close_bf16(got, want, ("log_softmax", hint))
 
 
 def test_row_operators_bf16(device):
