@@ -294,41 +294,64 @@ def main():
             phase["forward"].append((e0 if side is not None else e1, e2))
         return out
 
+    # op name of a traced launch as hot_path_ops lists it: the shared-MLP launches are split by the kernel instantiation
+    # rocprofv3 lists them under -- shared_mlp_kernel<BM, FLAT> (BM by Cout, FLAT for small per-frame P, csrc/shared_mlp.hip),
+    # mlp_pm by tile / kernel form -- and mlp_pm also by the side of the ridge the layer is on (157.3 TFLOP/s / 8 TB/s =
+    # 19.7 flop per byte in fp32: arithmetic intensity of a row = 2 K Cout flop over esz (K + Cout) bytes)
+    def split_name(name, tag):
+        if name == "shared_mlp":
+            k, cout, pcols = tag
+            bm = 128 if cout > 64 else (64 if cout > 32 else 32)
+            flat = pcols < 2048 and pcols % 4 == 0
+            return "shared_mlp<%d,%s>" % (bm, "flat" if flat else "frame")
+        if name == "mlp_pm":
+            k, cout = tag[0], tag[1]
+            esz, peak = (2.0, BF16_PEAK_TFLOPS) if args.precision == "bf16" else (4.0, VALU_PEAK_TFLOPS)
+            ridge_side = "mfma" if 2.0 * k * cout / (esz * (k + cout)) >= peak * 1e3 / HBM_PEAK_GBS else "hbm"
+            return "mlp_pm<%s,%s>" % (PM_TILES.get(tag[3], "?"), ridge_side)
+        return name
+
+    def split_mlp(tr):
+        for base in ("shared_mlp", "mlp_pm"):
+            for rec in tr.records.pop(base, []):
+                tr.records.setdefault(split_name(base, rec[3]), []).append(rec)
+
     with torch.no_grad():
-        # every hand-written op is bracketed by HIP events on its launch stream during the timed
-        # steps (two event records per launch; the GPU stays the bottleneck)
-        tracer = _lib.Tracer(None if args.roofline_op == "auto" else [args.roofline_op])
         marker = torch.zeros(4, dtype=torch.int32, device=dev)
+        for _ in range(args.warmup):            # the W untimed warm-up steps (MIOpen find, allocator, caches)
+            step()
+        torch.cuda.synchronize()
 
-        def one_step(timed):
-            if timed and _lib.TRACER is None:
-                if args.mark_region:
-                    ops.check_index_range(marker, 1)
-                _lib.TRACER = tracer
-            step(record=timed)
-
-        elapsed = distributed.timed_steps(one_step, args.warmup, args.steps, group, sync=torch.cuda.synchronize)
+        # Untimed measurement passes between warm-up and the timed region (every rank runs them, to stay in step):
+        #  1. N_FULL steps in the benchmarked stream configuration with EVERY hand-written op bracketed by HIP events on
+        #     its launch stream -> hot_path_ops (with several streams an interval also counts the time a launch waits
+        #     behind the other streams' kernels);
+        #  2. the same steps on ONE stream: clean per-kernel durations -> which kernel is the dominant one, and
+        #     roofline.isolated.
+        # The timed region then brackets only the launches of that dominant kernel (two event records per launch are
+        # measurement overhead: ~180 launches per step cost ~3 % of a step when all of them are bracketed).
+        N_FULL = 3
+        full = _lib.Tracer(None if args.roofline_op == "auto" else [args.roofline_op])
+        _lib.TRACER = full
+        for _ in range(N_FULL):
+            step()
+        torch.cuda.synchronize()
         _lib.TRACER = None
-        if args.mark_region:
-            ops.check_index_range(marker, 1)
-
-        # after the timed region: the same steps on ONE stream, to time every kernel without a
-        # neighbour from the other stream sharing its CUs (reported as roofline.isolated)
         serial = None
         pyramid_on_side = side is not None
-        if overlap and rank == 0:
+        if overlap:
             net.two_streams, keep_side, side = False, side, None
             serial = _lib.Tracer(None if args.roofline_op == "auto" else [args.roofline_op])
             step()
             torch.cuda.synchronize()
             _lib.TRACER = serial
-            for _ in range(max(2, min(args.steps, 5))):
+            for _ in range(N_FULL):
                 step()
             torch.cuda.synchronize()
             _lib.TRACER = None
             net.two_streams, side = True, keep_side
         pyr_alone_ms = None
-        if pyramid_on_side and rank == 0:       # the pyramid by itself (it has no interval of its own inside a streamed step)
+        if pyramid_on_side:       # the pyramid by itself (it has no interval of its own inside a streamed step)
             pe = [ev(), ev()]
             pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
             pe[0].record()
@@ -338,19 +361,40 @@ def main():
             torch.cuda.synchronize()
             pyr_alone_ms = pe[0].elapsed_time(pe[1]) / 5
 
+        split_mlp(full)
+        if serial is not None:
+            split_mlp(serial)
+        pick_from = (serial if serial is not None else full).summary()
+        cand = {k: v for k, v in pick_from.items() if not k.startswith("knn") and v["launches"] and k in full.records}
+        roof_op = args.roofline_op if args.roofline_op != "auto" else \
+            (max(cand, key=lambda k: cand[k]["total_ms"]) if cand else None)
+        tracer = _lib.Tracer(pred=lambda name, tag: roof_op is not None and split_name(name, tag) == roof_op)
+
+        def one_step(timed):
+            if timed and _lib.TRACER is None:
+                if args.mark_region:
+                    ops.check_index_range(marker, 1)
+                _lib.TRACER = tracer
+            step(record=timed)
+
+        elapsed = distributed.timed_steps(one_step, 0, args.steps, group, sync=torch.cuda.synchronize)
+        _lib.TRACER = None
+        if args.mark_region:
+            ops.check_index_range(marker, 1)
+
         if args.trace_all and rank == 0:
-            full = _lib.Tracer(None)
-            _lib.TRACER = full
+            tall = _lib.Tracer(None)
+            _lib.TRACER = tall
             for _ in range(max(2, args.steps // 2)):
                 step()
             torch.cuda.synchronize()
             _lib.TRACER = None
             print("%-24s %9s %10s %10s %10s" % ("op", "launches", "total ms", "avg us", "alg GB/s"), file=sys.stderr)
-            for name, r in sorted(full.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
+            for name, r in sorted(tall.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
                 print("%-24s %9d %10.3f %10.1f %10.1f" % (name, r["launches"], r["total_ms"], r["avg_us"], r["gbps"]),
                       file=sys.stderr)
             print("--- by shape ---", file=sys.stderr)
-            for (name, tag), r in sorted(full.summary(by_tag=True).items(), key=lambda kv: -kv[1]["total_ms"])[:40]:
+            for (name, tag), r in sorted(tall.summary(by_tag=True).items(), key=lambda kv: -kv[1]["total_ms"])[:40]:
                 print("%-24s %-22s %5d %9.3f %9.1f %9.1f" % (name, str(tag), r["launches"], r["total_ms"], r["avg_us"],
                                                             r["gbps"]), file=sys.stderr)
 
@@ -359,22 +403,6 @@ def main():
         value = args.batch * world * args.steps / elapsed
         pyr_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["pyramid"]]))
         fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["forward"]]))
-        # split the shared-MLP launches by the kernel instantiation rocprofv3 lists them under:
-        # shared_mlp_kernel<BM, FLAT>, BM by Cout, FLAT for small per-frame P (csrc/shared_mlp.hip); mlp_pm_kernel by tile
-        def split_mlp(tr):
-            for rec in tr.records.pop("shared_mlp", []):
-                k, cout, pcols = rec[3]
-                bm = 128 if cout > 64 else (64 if cout > 32 else 32)
-                flat = pcols < 2048 and pcols % 4 == 0
-                tr.records.setdefault("shared_mlp<%d,%s>" % (bm, "flat" if flat else "frame"), []).append(rec)
-            for rec in tr.records.pop("mlp_pm", []):
-                # the same instantiation serves layers on both sides of the ridge (157.3 TFLOP/s / 8 TB/s = 19.7 flop per
-                # byte): arithmetic intensity of a row = 2 K Cout flop over 4 (K + Cout) bytes
-                k, cout = rec[3][0], rec[3][1]
-                esz, peak = (2.0, BF16_PEAK_TFLOPS) if args.precision == "bf16" else (4.0, VALU_PEAK_TFLOPS)
-                side = "mfma" if 2.0 * k * cout / (esz * (k + cout)) >= peak * 1e3 / HBM_PEAK_GBS else "hbm"
-                tr.records.setdefault("mlp_pm<%s,%s>" % (PM_TILES.get(rec[3][3], "?"), side), []).append(rec)
-
         def is_gemm(name):
             return name.startswith(("shared_mlp", "mlp_pm", "att_pool_pm", "att_score_pool"))
 
@@ -400,17 +428,7 @@ def main():
                     "avg_launch_us": summ["avg_us"], "flops": 0.0, "bytes": summ["bytes"]}
 
         split_mlp(tracer)
-        summary = tracer.summary()
-        # dominant hand-written op of the timed steps.  KNN is latency/VALU bound (10.7 MB of
-        # algorithmic bytes per frame) and is reported through hot_path_ops instead.
-        # Chosen on the one-stream pass when there is one: with two or three streams an event bracket also counts the time a
-        # launch waits behind the other streams' kernels, which can make a latency-bound op look dominant.
-        if serial is not None:
-            split_mlp(serial)
-        pick_from = serial.summary() if serial is not None else summary
-        cand = {k: v for k, v in pick_from.items() if not k.startswith("knn") and v["launches"] and k in summary}
-        roof_op = args.roofline_op if args.roofline_op != "auto" else \
-            (max(cand, key=lambda k: cand[k]["total_ms"]) if cand else None)
+        summary = full.summary()         # every op: the N_FULL fully bracketed steps before the timed region
         roofline = None
         r = roofline_of(tracer, roof_op) if roof_op else None
         if r:
@@ -436,16 +454,16 @@ def main():
                 roofline["isolated"] = {"achieved": iso["achieved"], "frac": iso["frac"], "avg_launch_us": iso["avg_launch_us"],
                                         "note": "same kernel, same steps on one stream after the timed region: "
                                                 "no kernel of the other stream shares the CUs"}
-        ops_table = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": v["total_ms"] / args.steps,
+        ops_table = {k: {"launches_per_step": v["launches"] / N_FULL, "ms_per_step": v["total_ms"] / N_FULL,
                          "algorithmic_GBps": v["gbps"]} for k, v in summary.items()}
         for k in ops_table:
             if is_gemm(k):      # GEMM-shaped ops: MFMA rate next to the byte rate
-                fl = sum(gemm_flops(k, t, args.batch) for _, _, _, t in tracer.records[k])
+                fl = sum(gemm_flops(k, t, args.batch) for _, _, _, t in full.records[k])
                 ops_table[k]["algorithmic_TFLOPs"] = fl / (summary[k]["total_ms"] * 1e-3) / 1e12
         if "knn" in summary:
             # exact KNN is VALU/latency bound, not HBM bound: brute-force-equivalent pairs/s, and the pairs
             # the pruned search really evaluated (device counter, one extra untimed pyramid) against the fp32 VALU roof
-            recs = tracer.records["knn"]
+            recs = full.records["knn"]
             pairs = sum(tag[0] * tag[1] for _, _, _, tag in recs) * args.batch
             sec = summary["knn"]["total_ms"] * 1e-3
             ops_table["knn"]["bruteforce_equivalent_Gpairs_per_s"] = pairs / sec / 1e9
@@ -456,13 +474,13 @@ def main():
             pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
             torch.cuda.synchronize()
             _lib.check(lib.ffb6d_knn_set_pair_counter(None), "ffb6d_knn_set_pair_counter")
-            scanned = sum(tag[0] * tag[1] for _, _, _, tag in recs[:len(recs) // args.steps]
+            scanned = sum(tag[0] * tag[1] for _, _, _, tag in recs[:len(recs) // N_FULL]
                           if not lib.ffb6d_knn_uses_pruning(args.batch, tag[0], tag[1], tag[2])) * args.batch
             evaluated = int(ctr.item()) + scanned
-            per_step_s = sec / args.steps
+            per_step_s = sec / N_FULL
             ops_table["knn"].update({
                 "evaluated_Mpairs_per_step": evaluated / 1e6,
-                "evaluated_fraction_of_bruteforce": evaluated / (pairs / args.steps),
+                "evaluated_fraction_of_bruteforce": evaluated / (pairs / N_FULL),
                 "evaluated_Gpairs_per_s": evaluated / per_step_s / 1e9,
                 # 8 flop per pair (3 sub, 3 mul, 2 add) against the fp32 vector peak
                 "valu_frac_of_fp32_peak": evaluated * 8.0 / per_step_s / (VALU_PEAK_TFLOPS * 1e12)})
@@ -497,6 +515,8 @@ def main():
             "hot_path_only": {"kernel_ms_per_step": sum(v["ms_per_step"] for v in ops_table.values()),
                               "launches_per_step": sum(v["launches_per_step"] for v in ops_table.values())},
             "hot_path_ops": ops_table,
+            "hot_path_ops_source": f"{N_FULL} untimed steps between warm-up and the timed region with every hand-written launch "
+                                   "bracketed by HIP events; the timed region brackets only the roofline kernel's launches",
         }
         if not args.no_cpu_baseline and world == 1 and not train:
             line["cpu_baseline"] = cpu_baseline(args, sd)

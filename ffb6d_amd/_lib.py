@@ -127,12 +127,13 @@ def check(rc, what):
 # on, and tagged with its algorithmic byte count, so achieved GB/s can be computed live.
 # ------------------------------------------------------------------------------------
 class Tracer:
-    def __init__(self, names=None):
+    def __init__(self, names=None, pred=None):
         self.names = set(names) if names else None   # None = every op
+        self.pred = pred                              # optional (name, tag) -> bool: trace only these launches
         self.records = {}                             # name -> list of (start, end, bytes, tag)
 
-    def wants(self, name):
-        return self.names is None or name in self.names
+    def wants(self, name, tag=None):
+        return (self.names is None or name in self.names) and (self.pred is None or self.pred(name, tag))
 
     def summary(self, by_tag=False):
         """name -> dict(launches, total_ms, avg_us, bytes, gbps); call after a device sync.
@@ -163,7 +164,7 @@ class traced:
 
     def __enter__(self):
         t = TRACER
-        if t is not None and t.wants(self.name):
+        if t is not None and t.wants(self.name, self.tag):
             import torch
             self.start = torch.cuda.Event(enable_timing=True)
             self.start.record()

@@ -1,5 +1,5 @@
 """Where do the two streams of the fused forward wait for each other?  Event pairs around every cross-stream wait
-(forward_pm.handover), averaged over steps of the default workload (bs=8, N=12288).  Usage: python scripts/stall_probe.py"""
+(forward_pm.handover), averaged over steps of the default workload (bs=8, N=12288).  Usage: python scripts/stall_probe.py [bf16]   (bf16 = BASELINE config 5: bs=16, bf16 rows)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,8 +9,11 @@ from ffb6d_amd import model, synth
 
 dev = torch.device("cuda:0")
 torch.backends.cudnn.benchmark = True
-frames = synth.make_batch(0, 8, n_points=12288, height=480, width=640)
+bf16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"
+frames = synth.make_batch(0, 16 if bf16 else 8, n_points=12288, height=480, width=640)
 net = model.FFB6D(n_classes=22, n_pts=12288).to(dev).eval()
+if bf16:
+    net.precision = "bf16"
 inputs = {"rgb": torch.from_numpy(frames["rgb"]).to(dev).float(), "cld_rgb_nrm": torch.from_numpy(frames["cld_rgb_nrm"]).to(dev),
           "choose": torch.from_numpy(frames["choose"]).to(dev).long(), "dpt_xyz": torch.from_numpy(frames["dpt_xyz"]).to(dev)}
 with torch.no_grad():
