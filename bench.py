@@ -10,14 +10,18 @@
 A *step* is one pass of the hot path over one batch of synthetic RGB-D frames that is already
 resident in HBM: the on-device index pyramid (the 22 exact-KNN searches per frame that the
 reference runs on the CPU in its DataLoader, linemod_dataset.py:318-353) followed by
-FFB6D.forward (ffb6d.py:203-337) in fp32, eval mode.  Workload = BASELINE.json configs[1]:
+FFB6D.forward (ffb6d.py:203-337) in fp32, eval mode -- by default the forward builds the pyramid itself, level by
+level on a third HIP stream under the network (--overlap-pyramid 0: pyramid first, then the forward).
+Workload = BASELINE.json configs[1]:
 bs=8, N=12288 points, 480x640, 4 encoder + 3 decoder fusion layers, one MI355X.  With N>1
 ranks every rank runs its own batch of 8 (weak scaling, no data-path collective: batch items
 are independent in the forward pass -- SURVEY.md section 8e); value = total frames / max-over-ranks time.
 
 The JSON line also carries
   roofline      achieved algorithmic TFLOP/s (MFMA-bound launches) or GB/s (HBM-bound ones) of the dominant
-                hand-written kernel, measured live with HIP events on its launch stream during the timed steps;
+                hand-written kernel, measured live with HIP events on its launch stream during the timed steps
+                (which kernel that is, and hot_path_ops for all of them, come from untimed fully bracketed steps
+                between warm-up and the timed region);
   cpu_baseline  the CPU oracle path (reference nanoflann from oracle/_ref when present, else the
                 C restatement, + the plain-torch forward of oracle/forward_ref.py) timed on this
                 host's cores on a bounded sample (a few single frames).
