@@ -108,8 +108,9 @@ MLP_KERNEL_NAMES = {"shared_mlp<128,frame>": "shared_mlp_pipe_kernel<128>", "sha
                     "mlp_pm<128x128>": "mlp_pm_kernel<2, 2, 2, 2, false>", "mlp_pm<64x256>": "mlp_pm_kernel<2, 2, 1, 4, false>",
                     "mlp_pm<32x256>": "mlp_pm_kernel<1, 2, 1, 4, false>", "mlp_pm<64x64>": "mlp_pm_kernel<1, 1, 2, 2, false>",
                     "mlp_pm<64x32,ksplit>": "mlp_pm_kernel<2, 1, 2, 2, true>",
-                    "mlp_pm<stream>": "mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>", "att_pool_pm": "att_pool_pm_kernel<TM, TN>"}
-PM_TILES = {1: "128x128", 2: "64x256", 3: "32x256", 4: "64x64", 5: "64x32,ksplit", 6: "stream"}
+                    "mlp_pm<stream>": "mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>", "mlp_pm<lds128x128>": "mlp_pm_lds_kernel<T>",
+                    "att_pool_pm": "att_pool_pm_kernel<TM, TN>"}
+PM_TILES = {1: "128x128", 2: "64x256", 3: "32x256", 4: "64x64", 5: "64x32,ksplit", 6: "stream", 7: "lds128x128"}
 
 
 def gemm_flops(name, rec_tag, batch):

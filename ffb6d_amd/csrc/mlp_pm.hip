@@ -585,6 +585,153 @@ mlp_pm_stream_kernel(const PmParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LDS-tiled form for the long-row layers in bf16 (K * SZ > 512 bytes or cout > 128: the p2r fusion GEMMs, the PSP bottleneck).
+// In bf16 an MFMA retires 16x the k of an fp32 one per operand byte, so mlp_pm_kernel's fragment-shaped operand loads (each
+// wave pulls its own W and X fragments through the texture path, 32 rows x 32 bytes per instruction) bound it at ~230 TFLOP/s.
+// Here a workgroup (2 x 2 waves, 128 channels x 128 points) stages 128 bytes of every W and X row per step through LDS:
+//   * global side: 8 lanes fetch one 128-byte row segment (a whole cache line), every byte once per workgroup;
+//   * LDS images [128 rows][128 + 16 bytes] (odd multiple of 16: conflict-free ds_read_b128 in fragment order), two stages:
+//     the loads of step s + 1 are in flight while step s is multiplied, one barrier per step;
+//   * each wave multiplies its 64 x 64 tile (2 x 2 MFMA tiles) out of the images; epilogue = pm_epilogue.
+// Same products and the same k order per accumulator as mlp_pm_kernel -> identical results.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(BLK, 2)            // two workgroups per CU (LDS allows two): at most 256 registers per lane
+mlp_pm_lds_kernel(const PmParams p)
+{
+    constexpr int SZ = El<T>::SZ;
+    constexpr int CB = 128;                           // bytes of every row per step
+    constexpr int RS = CB + 16;                       // image row stride
+    constexpr int IMG = 128 * RS;                     // one operand image
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [2 stages][W image | X image]
+
+    const int t = blockIdx.x;
+    const int xcd = t & 7, sl = t >> 3;
+    const int pt = (sl / p.n_ct) * 8 + xcd;
+    const int ct = sl % p.n_ct;
+    if (pt >= p.n_pt) return;
+    const int c0 = ct * 128, r0 = pt * 128;
+
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int K = p.k1 + p.k2;
+    const int kb1 = p.k1 * SZ, kbt = K * SZ;          // row bytes of x1, of [x1 | x2] (= of a W row)
+    const int nstage = (kbt + CB - 1) / CB;
+
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)kbt);
+    const unsigned x1_rows = p.xidx ? (unsigned)(p.rows / p.P) * (unsigned)p.px : (unsigned)p.rows;
+    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, x1_rows * (unsigned)p.ld1 * SZ);
+    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? (unsigned)p.rows * (unsigned)p.ld2 * SZ : 0u);
+
+    // loader: thread -> 16-byte chunk lchunk of the 128-byte segment of rows lrow + 32 i (i < 4), for W and for X.  The
+    // launcher guarantees K * SZ % 128 == 0 (no row tail) and, with a second source, k1 * SZ % 128 == 0 (a step comes from
+    // ONE of the two: wave-uniform descriptor), so the per-thread offsets are loop invariant and the step travels in the scalar
+    // offset of the load; rows past the end sit at an out-of-range offset and read zeros.
+    const int lchunk = threadIdx.x & 7, lrow = threadIdx.x >> 3;
+    int w_off[4], x1_off[4], x2_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = c0 + lrow + 32 * i, r = r0 + lrow + 32 * i;
+        w_off[i] = ch < p.cout ? ch * kbt + lchunk * 16 : OOB;
+        x1_off[i] = OOB;
+        x2_off[i] = OOB;
+        if (r < p.rows) {
+            int xr = r;
+            if (p.xidx)
+                xr = (r / p.P) * p.px + (p.idx64 ? (int)static_cast<const long long*>(p.xidx)[r] : static_cast<const int*>(p.xidx)[r]);
+            x1_off[i] = xr * p.ld1 * SZ + lchunk * 16;
+            x2_off[i] = r * p.ld2 * SZ + lchunk * 16;
+        }
+    }
+
+    struct Step { u32x4 w[4], x[4]; };                // one step of loads: 8 x 16 bytes per thread
+    auto gload = [&](int s, Step& v) {
+        if (s >= nstage) return;                      // prefetch past the last step
+        const int seg = s * CB;
+        if (seg < kb1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[i], seg, 0);
+                v.x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x1, x1_off[i], seg, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[i], seg, 0);
+                v.x[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x2, x2_off[i], seg - kb1, 0);
+            }
+        }
+    };
+    auto park = [&](const Step& v, int stage) {
+        unsigned char* wi = lds + stage * 2 * IMG;
+        unsigned char* xi = wi + IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(wi + (lrow + 32 * i) * RS + lchunk * 16) = v.w[i];
+            *reinterpret_cast<u32x4*>(xi + (lrow + 32 * i) * RS + lchunk * 16) = v.x[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto multiply = [&](int stage) {
+        const unsigned char* wi = lds + stage * 2 * IMG + (wm * 64 + l31) * RS + kh * 16;
+        const unsigned char* xi = lds + stage * 2 * IMG + IMG + (wn * 64 + l31) * RS + kh * 16;
+        u32x4 wa[2][2], xb[2][2];
+        auto frags = [&](int ks, u32x4 (&a)[2], u32x4 (&b)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const u32x4*>(wi + i * 32 * RS + ks * 32);
+                b[i] = *reinterpret_cast<const u32x4*>(xi + i * 32 * RS + ks * 32);
+            }
+        };
+        frags(0, wa[0], xb[0]);
+#pragma unroll
+        for (int ks = 0; ks < CB / 32; ++ks) {
+            if (ks + 1 < CB / 32) frags(ks + 1, wa[(ks + 1) & 1], xb[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step<T, 2, 2>(acc, wa[ks & 1], xb[ks & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Three register sets: the loads of steps s + 1 .. s + 3 are in flight while step s is multiplied (a bf16 step is ~500
+    // MFMA cycles, far less than the memory latency: one step of prefetch leaves the pipe waiting, measured 605 -> see
+    // profiles/r02_mlp_pm_lds_ab.txt).  Two LDS stages, one barrier per step: step s + 1 is parked after step s was read.
+#define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
+#define FFB6D_LDS_ITER(FILL, NEXT)                                   \
+    gload(s + 3, FILL);                 FFB6D_PIN();                 \
+    multiply(s & 1);                    FFB6D_PIN();                 \
+    if (s + 1 < nstage) park(NEXT, (s + 1) & 1);                     \
+    __syncthreads();                                                 \
+    if (++s >= nstage) break;
+    Step va, vb, vc;
+    gload(0, va);
+    gload(1, vb);
+    gload(2, vc);
+    park(va, 0);
+    __syncthreads();
+    int s = 0;
+    while (true) {
+        FFB6D_LDS_ITER(va, vb)
+        FFB6D_LDS_ITER(vb, vc)
+        FFB6D_LDS_ITER(vc, va)
+    }
+#undef FFB6D_LDS_ITER
+#undef FFB6D_PIN
+    pm_epilogue<T, 2, 2, false>(p, acc, c0, r0, wm, wn, l31, kh);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Attentive pooling with the score GEMM fused in (Att_pooling.forward up to the pooled tensor, RandLANet.py:243-248):
 //     S[(n,k), :] = [ F[nei[n,k], :] | G[(n,k), :] ]           feature set: gathered point rows | per-pair rows
 //     A = S * W_fc^T                                           scores, never written
@@ -737,6 +884,19 @@ void launch_pm(PmParams& p, hipStream_t st)
     hipLaunchKernelGGL((mlp_pm_kernel<T, TM, TN, WM, WN, KSPLIT>), dim3(grid), dim3(BLK), 0, st, p);
 }
 
+template <typename T>
+void launch_lds(PmParams& p, hipStream_t st)
+{
+    p.n_ct = (int)ceil_div(p.cout, 128);
+    p.n_pt = (int)ceil_div(p.rows, 128);
+    constexpr size_t lds = 2 * 2 * 128 * (128 + 16);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pm_lds_kernel<T>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    const unsigned grid = (unsigned)(ceil_div(p.n_pt, 8) * p.n_ct * 8);
+    hipLaunchKernelGGL((mlp_pm_lds_kernel<T>), dim3(grid), dim3(BLK), lds, st, p);
+}
+
 template <typename T, int TM, int NS, bool LSM, bool TWO>
 void launch_stream(PmParams& p, hipStream_t st)
 {
@@ -855,6 +1015,11 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
 #undef FFB6D_STREAM_NS
             break;
         }
+        case 7:                                                     // LDS-tiled form: 128 ch x 128 pt, whole-row staging
+            FFB6D_REQUIRE(act != 3 && (K * SZ) % 128 == 0 && (k1 * SZ) % 128 == 0,
+                          "mlp_pm: the LDS-tiled form has no log_softmax epilogue and needs k1 * %d and K * %d to be multiples of 128", SZ, SZ);
+            launch_lds<T>(p, st);
+            break;
         default: return set_error(FFB6D_ERR_ARG, "mlp_pm: unknown tile_hint %d", tile_hint);
     }
     FFB6D_LAUNCH_CHECK();
@@ -913,13 +1078,18 @@ extern "C" int ffb6d_mlp_pm_tile(int64_t rows, int64_t cout, int64_t K, int act)
 
 // Kernel form for tile_hint 0: the stream form (6) on the short-row layers it is faster on (profiles/r02_mlp_pm_stream_ab.txt:
 // every single-source shape with 96..512-byte rows and cout <= 128 once there are >= 128 tiles; two-source rows in bf16 only),
-// else the tile shape of ffb6d_mlp_pm_tile.
+// the LDS-tiled form (7) on the big long-row layers, else the tile shape of ffb6d_mlp_pm_tile.
 extern "C" int ffb6d_mlp_pm_choice(int64_t rows, int64_t cout, int64_t k1, int64_t k2, int act, int bf16, int x1_gathered)
 {
     const int64_t K = k1 + k2, row_bytes = K * (bf16 ? 2 : 4);
     const bool stream = cout <= 128 && row_bytes >= 96 && row_bytes <= 512 && !x1_gathered && rows >= 16384 &&
                         (cout * (bf16 ? 2 : 4)) % 16 == 0 && (k2 == 0 || bf16) && !(act == 3 && (k2 > 0 || cout > 64));
-    return stream ? 6 : ffb6d_mlp_pm_tile(rows, cout, K, act);
+    if (stream) return 6;
+    // LDS-tiled form: rows of whole 128-byte segments (both sources), enough 128 x 128 tiles to fill the chip; bit-identical to
+    // the tile kernels and faster on every such layer measured (profiles/r02_mlp_pm_lds_ab.txt: bf16 2.0-2.4x, fp32 0-10 %)
+    const bool lds = act != 3 && row_bytes % 128 == 0 && (k1 * (bf16 ? 2 : 4)) % 128 == 0 &&
+                     ceil_div(rows, 128) * ceil_div(cout, 128) >= 256;
+    return lds ? 7 : ffb6d_mlp_pm_tile(rows, cout, K, act);
 }
 
 #define FFB6D_MLP_PM_ARGS                                                                                                    \

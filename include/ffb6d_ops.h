@@ -161,7 +161,9 @@ int ffb6d_mlp_pm_f32(const float* w, const float* bias, const float* x1, int64_t
  * 4 = 64 x 64, 5 = 64 x 32 with K split over the four waves -- i.e. which kernel instantiation a profile will list. */
 int ffb6d_mlp_pm_tile(int64_t rows, int64_t cout, int64_t K, int act);
 /* Kernel form for tile_hint 0: 6 = the stream form (mlp_pm_stream_kernel: persistent workgroups, W resident in LDS, whole-row
- * loads and stores through wave-private LDS images) for the HBM-bound short-row layers, else ffb6d_mlp_pm_tile's tile. */
+ * loads and stores through wave-private LDS images) for the HBM-bound short-row layers, 7 = the LDS-tiled form
+ * (mlp_pm_lds_kernel: 128 x 128 tiles, 128-byte row segments staged through LDS) for the big long-row layers, else
+ * ffb6d_mlp_pm_tile's tile.  All forms give identical results. */
 int ffb6d_mlp_pm_choice(int64_t rows, int64_t cout, int64_t k1, int64_t k2, int act, int bf16, int x1_gathered);
 
 /* Att_pooling.forward up to the pooled tensor (RandLANet.py:243-248) with the neighbour gather fused in:

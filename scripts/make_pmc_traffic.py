@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 KEYS = [("mlp_pm_kernel<2, 2, 1, 4, false>", "mlp_pm<64x256>", 2.0), ("mlp_pm_kernel<2, 2, 2, 2, false>", "mlp_pm<128x128>", 2.0),
         ("mlp_pm_kernel<1, 2, 1, 4, false>", "mlp_pm<32x256>", 2.0), ("mlp_pm_kernel<1, 1, 2, 2, false>", "mlp_pm<64x64>", 2.0),
-        ("mlp_pm_kernel<2, 1, 2, 2, true>", "mlp_pm<64x32,ksplit>", 2.0), ("att_pool_pm_kernel", "att_pool_pm", 2.0),
+        ("mlp_pm_kernel<2, 1, 2, 2, true>", "mlp_pm<64x32,ksplit>", 2.0), ("mlp_pm_lds_kernel", "mlp_pm<lds128x128>", 2.0),
+        ("mlp_pm_stream_kernel", "mlp_pm<stream>", 2.0), ("att_pool_pm_kernel", "att_pool_pm", 2.0),
         ("affine_act_pm_kernel", "affine_act_pm", 2.0), ("bilinear_pm_kernel", "bilinear_resize_pm", 2.0),
         ("random_sample_pm_kernel", "random_sample_pm", 2.0), ("rel_pos_enc_pm_kernel", "relative_pos_encoding_pm", 1.0),
         ("psp_rowsum_pm_kernel", "psp_pool_pm", 2.0), ("psp_binsum_pm_kernel", "psp_pool_pm", 2.0),

@@ -42,6 +42,11 @@ CASES += [(2, 777, 40, 24, 72, 2, 50, h) for h in (1, 2, 3, 4, 5)] + [(1, 4100, 
 CASES += [(2, 777, 40, 24, 72, 2, 50, 6), (1, 100000, 64, 0, 64, 1, 0, 6), (2, 5001, 24, 0, 16, 0, 0, 6), (1, 4100, 128, 0, 128, 1, -1, 6),
           (3, 1300, 32, 96, 100, 2, 70, 6), (1, 130, 64, 0, 32, 1, 0, 6), (1, 40000, 48, 16, 64, 1, 300, 6), (2, 20000, 64, 0, 64, 2, 900, 0),
           (1, 70000, 128, 0, 128, 1, -1, 0)]
+# the LDS-tiled form (hint 7: 128 x 128 tiles, 128-byte row segments staged through LDS, rows of whole segments only): one to
+# many steps, two sources, ragged rows / channels, gathered / added epilogue rows; gathered operand rows live in
+# test_..._operand_gather; the last one is picked by tile_hint 0
+CASES += [(1, 4800, 1024, 0, 1024, 1, 48, 7), (2, 777, 32, 32, 72, 2, 50, 7), (1, 4100, 256, 0, 200, 1, -1, 7), (8, 192, 512, 256, 256, 2, 0, 7),
+          (3, 301, 96, 0, 37, 1, 13, 7), (1, 130, 32, 0, 8, 0, 0, 7), (1, 70000, 256, 0, 256, 1, 0, 0)]
 
 
 @pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", CASES)
@@ -99,9 +104,9 @@ def test_mlp_pm_operand_gather_and_log_softmax(device):
     bias = torch.randn(128, generator=g)
     picked = torch.gather(img, 1, choose.unsqueeze(2).expand(-1, -1, 64))
     want = _ref(picked, w, bias, 1, pts)
-    for dt in (torch.int64, torch.int32):
+    for dt, hint in ((torch.int64, 0), (torch.int32, 0), (torch.int64, 7)):          # 7: the LDS-tiled form's loader gathers too
         got = ops_pm.mlp(img.to(device), w.to(device), bias.to(device), ops.ACT_RELU, x2=pts.to(device),
-                         x1_gather=choose.to(device).to(dt)).cpu()
+                         x1_gather=choose.to(device).to(dt), tile_hint=hint).cpu()
         torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
     for C in (64, 32, 16, 40):
         x = torch.randn(3, 50, 7, 64, generator=g)
@@ -218,7 +223,9 @@ def _close_bf16(got, want, what=""):
     (2, 12288, 64, 64, 128, 1, 0, 0), (1, 4800, 1024, 0, 1024, 1, 48, 0), (8, 48, 1024, 0, 512, 1, 0, 0),
     (8, 192, 512, 256, 256, 2, 0, 0), (1, 12288, 128, 0, 22, 0, 0, 0), (3, 301, 32, 16, 40, 1, 13, 0),
     (1, 196608, 16, 0, 16, 2, 0, 0), (1, 4800, 512, 0, 1024, 1, -1, 0), (1, 70000, 128, 0, 64, 1, 300, 0)] +
-    [(2, 777, 48, 32, 72, 2, 50, h) for h in (1, 2, 3, 4, 5, 6)] +
+    [(2, 777, 48, 32, 72, 2, 50, h) for h in (1, 2, 3, 4, 5, 6)] + [(2, 777, 64, 64, 72, 2, 50, 7), (1, 4800, 1024, 0, 1024, 1, 48, 7),
+                                                                  (1, 4100, 512, 0, 200, 1, -1, 7), (8, 192, 512, 256, 256, 2, 0, 7),
+                                                                  (1, 70000, 512, 0, 256, 1, 0, 0)] +
     [(1, 100000, 64, 0, 64, 1, 0, 6), (2, 5001, 48, 0, 16, 0, 0, 6), (1, 4100, 256, 0, 128, 1, -1, 6), (3, 1300, 64, 96, 104, 2, 70, 6),
      (1, 70000, 64, 64, 128, 1, 300, 0), (2, 20000, 256, 0, 64, 2, 0, 0)])
 def test_mlp_pm_bf16(device, B, P, K1, K2, Cout, act, py, hint):
