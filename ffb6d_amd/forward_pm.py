@@ -177,11 +177,54 @@ def pyramid_pooling(pp, x):
     return ops_pm.mlp(x, wx, pp.bottleneck.bias.detach().float(), ops.ACT_RELU, add=prior)
 
 
-def up_block(ub, x):
-    """pspnet.py:34-45 (PSPUpsample): bilinear x2 (align_corners) -> conv3x3 -> [BN + PReLU in one pass]."""
-    B, h, w_, _ = x.shape
-    y = ops_pm.bilinear_resize(x, (2 * h, 2 * w_), align_corners=True)
+# Input widths of the PSPUpsample blocks that run in the folded form (csrc/upconv.hip).  FFB6D_UPCONV_FOLD: "0" = none,
+# "1" = every block, or a comma-separated list of input widths ("1024,256").
+def _fold_setting():
+    import os
+    v = os.environ.get("FFB6D_UPCONV_FOLD", "0").strip()
+    if v in ("", "0"):
+        return frozenset()
+    if v == "1":
+        return None                                       # every block
+    return frozenset(int(t) for t in v.split(","))
+
+
+UPCONV_FOLD = _fold_setting()
+
+
+def upconv_folded(ub, dt=F32):
+    """PSPUpsample's convolution regrouped for the low resolution: (W9 [9*cout, cin] of dtype `dt` with rows
+    (ky*3+kx)*cout + co = BatchNorm scale[co] * conv.weight[co, :, ky, kx], shift [cout] float32 = BatchNorm shift +
+    scale * conv bias, PReLU slope).  Pure torch: also what the host simulation of the kernel is checked with on CPU."""
     cv, bn, prelu = ub.conv[1], ub.conv[2], ub.conv[3]
+    if prelu.weight.numel() != 1:
+        raise NotImplementedError("per-channel PReLU in PSPUpsample")
+
+    def build():
+        scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+        shift = bn.bias.detach() - bn.running_mean * scale
+        if cv.bias is not None:
+            shift = shift + scale * cv.bias.detach()
+        w = cv.weight.detach() * scale[:, None, None, None]                                  # [cout, cin, 3, 3]
+        w9 = w.permute(2, 3, 0, 1).reshape(9 * w.shape[0], w.shape[1])
+        return w9.to(dt).contiguous(), shift.float().contiguous(), float(prelu.weight.detach().item())
+    src = [cv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, prelu.weight] + ([cv.bias] if cv.bias is not None else [])
+    return cached(ub, "fold9%s" % dt, src, build)
+
+
+def up_block(ub, x):
+    """pspnet.py:34-45 (PSPUpsample): bilinear x2 (align_corners) -> conv3x3 -> [BN + PReLU in one pass].
+    Folded form (UPCONV_FOLD): up-sampling and channel mixing commute, so the nine taps of the convolution are mixed at
+    the LOW resolution by one GEMM with 9*cout output channels (a quarter of the convolution's flops, on csrc/mlp_pm.hip)
+    and `upconv_combine` blends the tap planes, adds the BatchNorm shift and applies the PReLU in one pass."""
+    B, h, w_, cin = x.shape
+    cv, bn, prelu = ub.conv[1], ub.conv[2], ub.conv[3]
+    if (UPCONV_FOLD is None or cin in UPCONV_FOLD) and cv.kernel_size == (3, 3) and cv.padding == (1, 1) \
+            and cv.stride == (1, 1) and cv.dilation == (1, 1) and cv.groups == 1:
+        w9, shift, slope = upconv_folded(ub, x.dtype)
+        z = ops_pm.mlp(x, w9)                                                                 # [B,h,w,9*cout]
+        return ops_pm.upconv_combine(z, shift, slope, (2 * h, 2 * w_))
+    y = ops_pm.bilinear_resize(x, (2 * h, 2 * w_), align_corners=True)
     y = conv(y, cv)
     if prelu.weight.numel() != 1:
         raise NotImplementedError("per-channel PReLU in PSPUpsample")

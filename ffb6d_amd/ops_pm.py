@@ -232,6 +232,28 @@ def bilinear_resize(x, size, align_corners):
     return out
 
 
+def upconv_combine(z, shift, slope, size):
+    """Second half of the folded PSPUpsample (pspnet.py:34-45; csrc/upconv.hip): z [B,IH,IW,9*C] = per-tap channel mixing
+    at the low resolution (tap-major blocks of C channels), shift [C] float32, one PReLU slope -> [B,OH,OW,C]:
+    prelu(shift + sum over the 3x3 taps of the align_corners bilinear up-sampling of their plane, zero padding outside)."""
+    _need_gpu(z)
+    lib = _lib.load()
+    zc = z.detach()
+    zc = zc if zc.is_contiguous() else zc.contiguous()
+    B, IH, IW, C9 = zc.shape
+    if C9 % 9 or shift.dtype != torch.float32 or shift.numel() * 9 != C9 or not shift.is_contiguous():
+        raise ValueError(f"z {tuple(z.shape)} must hold 9 tap blocks of the {shift.numel()} channels of a contiguous float32 shift")
+    C = C9 // 9
+    OH, OW = int(size[0]), int(size[1])
+    out = torch.empty((B, OH, OW, C), dtype=z.dtype, device=z.device)
+    nbytes = z.element_size() * (zc.numel() + out.numel())
+    with torch.cuda.device(z.device), _lib.traced("upconv_combine_pm", nbytes, (C, OH, OW)):
+        rc = lib.ffb6d_upconv_combine_pm(_dt(zc), zc.data_ptr(), shift.data_ptr(), float(slope), out.data_ptr(), B, IH, IW, OH, OW,
+                                         C, _stream(zc))
+    _lib.check(rc, "ffb6d_upconv_combine_pm")
+    return out
+
+
 def _int_array(values):
     import ctypes
     return (ctypes.c_int * len(values))(*[int(v) for v in values])

@@ -204,6 +204,14 @@ int ffb6d_affine_act_pm(int dtype, const void* x, const float* scale, const floa
 /* Bilinear resize [B,IH,IW,C] -> [B,OH,OW,C] (ATen upsample_bilinear2d arithmetic; pspnet.py:24-28,37-42). */
 int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
                              int64_t C, int align_corners, ffb6d_stream_t stream);
+/* Second half of the folded up-convolution (PSPUpsample, pspnet.py:34-45: bilinear x2 with align_corners -> Conv2d 3x3,
+ * padding 1 -> BatchNorm -> PReLU).  z [B,IH,IW,9,C] holds, per low-resolution pixel and filter tap (ky*3+kx), the channel
+ * mixing (BatchNorm scale * W[:, :, ky, kx]) x -- one ffb6d_mlp_pm GEMM with 9*C output channels -- and
+ *   out[b,Y,X,:] = prelu(shift + sum_taps [tap inside the OHxOW map] * bilinear_align_corners(z[..., tap, :])(Y+ky-1, X+kx-1))
+ * with shift [C] float32 = BatchNorm shift + BatchNorm scale * conv bias, one PReLU slope.  Arithmetic of the blend as
+ * ffb6d_bilinear_resize_pm (ATen's upsample_bilinear2d); fp32 accumulation in both precisions. */
+int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* shift, float slope, void* out, int64_t B, int64_t IH,
+                            int64_t IW, int64_t OH, int64_t OW, int64_t C, ffb6d_stream_t stream);
 /* All adaptive average pools of `sizes` of x [B,H,W,C] -> float32 [B, sum(s*s), C] (bins of sizes[0] first, row-major in a
  * level).  Two passes (row partial sums, then bins) through a workspace of ffb6d_psp_pool_pm_workspace_bytes(...) bytes. */
 size_t ffb6d_psp_pool_pm_workspace_bytes(int64_t B, int64_t H, int64_t C, const int* sizes, int nsizes);

@@ -1,0 +1,32 @@
+// tests/hostsim/hostsim.hip -- TEST INFRASTRUCTURE: runs per-thread kernel bodies of the product library on the HOST.
+//
+// Kernels whose threads are independent (no cross-lane operations, no LDS, no barriers) keep their body in a
+// `__host__ __device__` function under ffb6d_amd/csrc/*_body.h.  This file is compiled host-only
+// (`hipcc --cuda-host-only`, tests/hostsim/build.py) and loops over the launch grid calling the same source the GPU runs,
+// so that index arithmetic and numerics of a kernel can be checked against torch on a machine without a GPU.
+// Nothing in the product path loads this library.
+#include <cstdint>
+
+#include "upconv_body.h"
+
+extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shift, float slope, void* out, int64_t B, int64_t IH,
+                                      int64_t IW, int64_t OH, int64_t OW, int64_t C)
+{
+    using namespace ffb6d::upconv;
+    const int VL = dtype == 1 ? 8 : 4;
+    if (C % VL) return -1;
+    CombineArgs a;
+    a.z = z; a.shift = shift; a.out = out;
+    a.IH = (int)IH; a.IW = (int)IW; a.OH = (int)OH; a.OW = (int)OW;
+    a.q = (int)(C / VL);
+    a.rh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;       // as the launcher in csrc/upconv.hip
+    a.rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+    a.slope = slope;
+    const int threads = (int)((OW * a.q + 255) / 256 * 256);        // whole workgroups: the surplus threads must bail out
+    for (int row = 0; row < (int)(B * OH); ++row)
+        for (int t = 0; t < threads; ++t) {
+            if (dtype == 1) combine_body<__bf16>(a, row, t);
+            else combine_body<float>(a, row, t);
+        }
+    return 0;
+}

@@ -1,0 +1,94 @@
+"""Per-thread kernel bodies of the product library, compiled for the host and run on CPU against torch
+(tests/hostsim/): index arithmetic and numerics of kernels without cross-lane operations are checked here,
+without a GPU, on the very source the GPU executes."""
+import ctypes
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from ffb6d_amd import forward_pm, model
+
+pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not __import__("os").path.exists("/opt/rocm/bin/hipcc"),
+                                reason="hipcc is needed to compile the host simulation")
+
+
+@pytest.fixture(scope="module")
+def sim():
+    from tests.hostsim import build
+    lib = ctypes.CDLL(build.build())
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.hostsim_upconv_combine.restype = ctypes.c_int
+    lib.hostsim_upconv_combine.argtypes = [ctypes.c_int, vp, vp, ctypes.c_float, vp, i64, i64, i64, i64, i64, i64]
+    return lib
+
+
+def _up_block(cin, cout, seed):
+    g = torch.Generator().manual_seed(seed)
+    ub = model.UpBlock(cin, cout).eval()
+    with torch.no_grad():
+        for p in ub.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+        bn = ub.conv[2]
+        bn.running_mean.copy_(torch.randn(cout, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+        ub.conv[3].weight.fill_(0.25 + 0.05 * seed)
+    return ub
+
+
+def _folded_on_host(sim, ub, x, dt):
+    """the folded up-convolution exactly as forward_pm.up_block runs it, with torch for the GEMM and the host simulation of
+    upconv_combine_pm_kernel for the second half; x [B,cin,h,w] float32 -> [B,cout,2h,2w] float32"""
+    B, cin, h, w = x.shape
+    w9, shift, slope = forward_pm.upconv_folded(ub, dt)
+    rows = x.permute(0, 2, 3, 1).contiguous().to(dt)                               # [B,h,w,cin] pixel-major
+    z = (rows.float().reshape(-1, cin) @ w9.float().t()).to(dt).reshape(B, h, w, -1).contiguous()
+    cout = shift.numel()
+    out = torch.empty(B, 2 * h, 2 * w, cout, dtype=dt)
+    rc = sim.hostsim_upconv_combine(1 if dt == torch.bfloat16 else 0, z.data_ptr(), shift.data_ptr(), slope, out.data_ptr(),
+                                    B, h, w, 2 * h, 2 * w, cout)
+    assert rc == 0
+    return out.float().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("B,cin,cout,h,w", [(2, 16, 8, 5, 7), (1, 8, 16, 1, 1), (1, 24, 4, 2, 9), (3, 8, 12, 6, 3)])
+def test_folded_upconv_equals_upsample_conv_bn_prelu(sim, B, cin, cout, h, w):
+    """PSPUpsample (pspnet.py:34-45) = the reference modules run by torch on CPU; bar 1e-5 of the output range."""
+    ub = _up_block(cin, cout, seed=B + cin)
+    x = torch.randn(B, cin, h, w, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        want = ub.conv(x)
+        got = _folded_on_host(sim, ub, x, torch.float32)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-5 * scale
+    # the negative (PReLU) side and the border taps are exercised
+    assert float(want.min()) < 0 and got.shape == want.shape
+
+
+def test_folded_upconv_bf16_rows(sim):
+    """bfloat16 rows (configuration 5): the same bodies with 8-channel units; bar = bf16 rounding of z and of the output."""
+    ub = _up_block(16, 8, seed=3)
+    x = torch.randn(2, 16, 4, 6, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        want = ub.conv(x)
+        got = _folded_on_host(sim, ub, x, torch.bfloat16)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 3e-2 * scale
+    assert float((got - want).abs().mean()) <= 5e-3 * scale
+
+
+def test_folded_weights_follow_weight_updates():
+    """the regrouped weights are cached per module and keyed on the version of every source tensor"""
+    ub = _up_block(8, 4, seed=1)
+    w9a, sa, _ = forward_pm.upconv_folded(ub)
+    assert forward_pm.upconv_folded(ub)[0] is w9a
+    with torch.no_grad():
+        ub.conv[1].weight.mul_(2.0)
+    w9b, sb, _ = forward_pm.upconv_folded(ub)
+    assert torch.allclose(w9b, 2 * w9a) and torch.equal(sa, sb)
+    # layout: row (ky*3+kx)*cout + co
+    cv, bn = ub.conv[1], ub.conv[2]
+    scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach()
+    assert torch.allclose(w9b[(1 * 3 + 2) * 4 + 3], (cv.weight[3, :, 1, 2] * scale[3]).detach())
+    assert np.isfinite(w9b.numpy()).all()
