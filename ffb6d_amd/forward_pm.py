@@ -100,11 +100,20 @@ def fc_weight(att, dt=F32):
 # ----------------------------------------------------------------------------------------------------
 # point branch
 # ----------------------------------------------------------------------------------------------------
+# FFB6D_POSENC_FUSED=1: relative_pos_encoding + lfa.mlp1 as one vector-ALU pass (csrc/posenc.hip) instead of the padded
+# encoding tensor + a K = 16 GEMM
+POSENC_FUSED = __import__("os").environ.get("FFB6D_POSENC_FUSED", "0").strip() not in ("", "0")
+
+
 def building_block(bb, xyz, f_pc, nei):
     """RandLANet.py:196-214 (Building_block.forward): f_pc [B,N,d/2] -> [B,N,d]."""
     dt = f_pc.dtype
-    enc = ops_pm.relative_pos_encoding(xyz, nei, dtype=dt)                        # [B,N,16,16] (10 used)
-    f_xyz = mlp(bb.mlp1, enc, pad_k=16)                                            # [B,N,16,d/2]
+    if POSENC_FUSED:                                                               # encoding generated in registers
+        w, b = folded(bb.mlp1)                                                     # fp32 [d/2, 10] in both precisions
+        f_xyz = ops_pm.posenc_mlp(xyz, nei, w, b, bb.mlp1.act_code, dtype=dt)      # [B,N,16,d/2]
+    else:
+        enc = ops_pm.relative_pos_encoding(xyz, nei, dtype=dt)                    # [B,N,16,16] (10 used)
+        f_xyz = mlp(bb.mlp1, enc, pad_k=16)                                        # [B,N,16,d/2]
     pooled = ops_pm.att_pool(f_pc, nei, f_xyz, fc_weight(bb.att_pooling_1, dt))    # [B,N,d]
     f_agg = mlp(bb.att_pooling_1.mlp, pooled)                                      # [B,N,d/2]
     f_xyz = mlp(bb.mlp2, f_xyz)

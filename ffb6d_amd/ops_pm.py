@@ -187,6 +187,27 @@ def relative_pos_encoding(xyz, neigh_idx, dtype=torch.float32):
     return out
 
 
+def posenc_mlp(xyz, neigh_idx, w, bias, act, dtype=torch.float32):
+    """mlp1(relative_pos_encoding(xyz, neigh_idx)) of Building_block.forward (RandLANet.py:196-199,216-223) in one pass:
+    xyz [B,N,3] float32, neigh_idx [B,N,K], w [cout, >=10] float32 (BatchNorm folded, columns past 10 ignored), bias [cout]
+    float32 or None -> [B,N,K,cout] rows of `dtype`; the 10-channel encoding stays in registers (csrc/posenc.hip)."""
+    _need_gpu(xyz, neigh_idx, w)
+    lib = _lib.load()
+    x = xyz.detach().contiguous()
+    idx, bits = _idx(neigh_idx)
+    B, N, K = idx.shape
+    if w.dtype != torch.float32 or w.dim() != 2 or w.shape[1] < 10 or w.stride(1) != 1 or (bias is not None and bias.dtype != torch.float32):
+        raise ValueError("posenc_mlp: w must be float32 [cout, >=10] with contiguous rows, bias float32")
+    cout = w.shape[0]
+    out = torch.empty((B, N, K, cout), dtype=dtype, device=x.device)
+    nbytes = 12 * B * N + (bits // 8) * B * N * K + out.element_size() * out.numel()
+    with torch.cuda.device(x.device), _lib.traced("posenc_mlp_pm", nbytes, (N, cout)):
+        rc = lib.ffb6d_posenc_mlp_pm(_dt(out), x.data_ptr(), idx.data_ptr(), bits, w.data_ptr(), w.stride(0),
+                                     bias.data_ptr() if bias is not None else None, int(act), out.data_ptr(), B, N, K, cout, _stream(x))
+    _lib.check(rc, "ffb6d_posenc_mlp_pm")
+    return out
+
+
 def affine_act_(x, scale, shift, act=ACT_NONE, slope=0.0, residual=None, res_affine=None):
     """In-place per-channel affine + optional (affine) residual + activation on [..., C] rows (the eval-mode
     BatchNorm / ReLU / PReLU / residual glue of the colour branch, extractors.py:49-63, pspnet.py:34-45)."""

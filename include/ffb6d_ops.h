@@ -204,6 +204,13 @@ int ffb6d_affine_act_pm(int dtype, const void* x, const float* scale, const floa
 /* Bilinear resize [B,IH,IW,C] -> [B,OH,OW,C] (ATen upsample_bilinear2d arithmetic; pspnet.py:24-28,37-42). */
 int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
                              int64_t C, int align_corners, ffb6d_stream_t stream);
+/* Relative position encoding fused with the first shared MLP of the local feature aggregation (Building_block.forward,
+ * RandLANet.py:196-199: mlp1(relative_pos_encoding(xyz, neigh_idx)), encoding [dis, p-q, p, q] of RandLANet.py:216-223):
+ *   out[b,n,k,:] = act(w[:, 0:10] . enc(b,n,k) + bias),   xyz [B,N,3] float32, idx [B,N,K], w [cout, ldw] float32 with
+ * BatchNorm folded (columns 10.. ignored), out [B,N,K,cout] rows of dtype (0 = float32, 1 = bfloat16); act 0/1/2 =
+ * none / ReLU / LeakyReLU(0.2).  The 10-channel encoding is never written. */
+int ffb6d_posenc_mlp_pm(int dtype, const float* xyz, const void* idx, int idx_bits, const float* w, int64_t ldw, const float* bias,
+                        int act, void* out, int64_t B, int64_t N, int K, int64_t cout, ffb6d_stream_t stream);
 /* Second half of the folded up-convolution (PSPUpsample, pspnet.py:34-45: bilinear x2 with align_corners -> Conv2d 3x3,
  * padding 1 -> BatchNorm -> PReLU).  z [B,IH,IW,9,C] holds, per low-resolution pixel and filter tap (ky*3+kx), the channel
  * mixing (BatchNorm scale * W[:, :, ky, kx]) x -- one ffb6d_mlp_pm GEMM with 9*C output channels -- and

@@ -7,6 +7,7 @@
 // Nothing in the product path loads this library.
 #include <cstdint>
 
+#include "posenc_body.h"
 #include "upconv_body.h"
 
 extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shift, float slope, void* out, int64_t B, int64_t IH,
@@ -28,5 +29,26 @@ extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shi
             if (dtype == 1) combine_body<__bf16>(a, row, t);
             else combine_body<float>(a, row, t);
         }
+    return 0;
+}
+
+extern "C" int hostsim_posenc_mlp(int dtype, const float* xyz, const void* idx, int idx_bits, const float* w, int64_t ldw,
+                                  const float* bias, int act, void* out, int64_t B, int64_t N, int K, int64_t cout, int64_t blocks)
+{
+    using namespace ffb6d::posenc;
+    const int VL = dtype == 1 ? 8 : 4;
+    if (cout % VL) return -1;
+    MlpArgs a;
+    a.xyz = xyz; a.idx = idx; a.w = w; a.bias = bias; a.out = out;
+    a.N = (int)N; a.K = K; a.ldw = (int)ldw;
+    a.q = (int)(cout / VL);
+    a.slope = act == 0 ? 1.f : (act == 1 ? 0.f : 0.2f);
+    a.pairs = (long long)B * N * K;
+    const long long nthreads = blocks * 256;                    // the launcher's grid: a multiple of q
+    if (nthreads % a.q) return -2;
+    for (long long tid = 0; tid < nthreads; ++tid) {
+        if (dtype == 1) { if (idx_bits == 64) mlp_body<__bf16, int64_t>(a, tid, nthreads); else mlp_body<__bf16, int32_t>(a, tid, nthreads); }
+        else { if (idx_bits == 64) mlp_body<float, int64_t>(a, tid, nthreads); else mlp_body<float, int32_t>(a, tid, nthreads); }
+    }
     return 0;
 }

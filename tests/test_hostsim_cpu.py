@@ -92,3 +92,43 @@ def test_folded_weights_follow_weight_updates():
     scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach()
     assert torch.allclose(w9b[(1 * 3 + 2) * 4 + 3], (cv.weight[3, :, 1, 2] * scale[3]).detach())
     assert np.isfinite(w9b.numpy()).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# relative position encoding fused with lfa.mlp1 (csrc/posenc_body.h)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sim_posenc(sim):
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    sim.hostsim_posenc_mlp.restype = ctypes.c_int
+    sim.hostsim_posenc_mlp.argtypes = [i32, vp, vp, i32, vp, i64, vp, i32, vp, i64, i64, i32, i64, i64]
+    return sim
+
+
+@pytest.mark.parametrize("B,N,K,cout,idt,blocks", [(2, 50, 16, 16, torch.int64, 3), (1, 33, 16, 128, torch.int32, 1),
+                                                    (3, 17, 5, 24, torch.int64, 6), (1, 1, 1, 8, torch.int64, 2)])
+def test_fused_posenc_mlp_equals_encoding_then_shared_mlp(sim_posenc, B, N, K, cout, idt, blocks):
+    """RandLANet.py:196-199: mlp1(relative_pos_encoding(xyz, idx)), with the oracle's plain-torch encoding and a float64
+    matmul as the reference; bar 1e-5 of the output range; also the padded [cout,16] weight layout the forward passes."""
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(B * 100 + N)
+    xyz = torch.randn(B, N, 3, generator=g)
+    idx = torch.randint(0, N, (B, N, K), generator=g).to(idt)
+    w = torch.zeros(cout, 16)
+    w[:, :10] = torch.randn(cout, 10, generator=g) * 0.5
+    w[:, 10:] = 7.0                                            # must be ignored
+    bias = torch.randn(cout, generator=g)
+    enc = ops_ref.relative_pos_encoding(xyz, idx.long())       # [B,N,K,10]
+    for act, f in ((0, lambda v: v), (1, torch.relu), (2, lambda v: torch.nn.functional.leaky_relu(v, 0.2))):
+        want = f(enc.double() @ w[:, :10].double().t() + bias.double())
+        out = torch.full((B, N, K, cout), float("nan"))
+        rc = sim_posenc.hostsim_posenc_mlp(0, xyz.data_ptr(), idx.data_ptr(), 64 if idt == torch.int64 else 32, w.data_ptr(), 16,
+                                           bias.data_ptr(), act, out.data_ptr(), B, N, K, cout, blocks * (3 if cout == 24 else 1))
+        assert rc == 0
+        assert float((out.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    outb = torch.zeros((B, N, K, cout), dtype=torch.bfloat16)
+    if cout % 8 == 0:
+        rc = sim_posenc.hostsim_posenc_mlp(1, xyz.data_ptr(), idx.data_ptr(), 64 if idt == torch.int64 else 32, w.data_ptr(), 16,
+                                           bias.data_ptr(), 2, outb.data_ptr(), B, N, K, cout, blocks)
+        assert rc == 0
+        assert float((outb.double() - want).abs().max()) <= 1e-2 * float(want.abs().max())
