@@ -465,6 +465,18 @@ def main():
             if is_gemm(k):      # GEMM-shaped ops: MFMA rate next to the byte rate
                 fl = sum(gemm_flops(k, t, args.batch) for _, _, _, t in full.records[k])
                 ops_table[k]["algorithmic_TFLOPs"] = fl / (summary[k]["total_ms"] * 1e-3) / 1e12
+        # the same table from the one-stream pass: durations no kernel of another stream shares the CUs with (the numbers a
+        # per-kernel roofline fraction should be read from; hot_path_ops above is the benchmarked, overlapped schedule)
+        ops_one_stream = None
+        if serial is not None:
+            one = serial.summary()
+            ops_one_stream = {k: {"launches_per_step": v["launches"] / N_FULL, "ms_per_step": v["total_ms"] / N_FULL,
+                                  "algorithmic_GBps": v["gbps"], "frac_of_hbm_peak": v["gbps"] / HBM_PEAK_GBS}
+                              for k, v in one.items() if v["launches"] and v["total_ms"] > 0}
+            for k in ops_one_stream:
+                if is_gemm(k):
+                    fl = sum(gemm_flops(k, t, args.batch) for _, _, _, t in serial.records[k])
+                    ops_one_stream[k]["algorithmic_TFLOPs"] = fl / (one[k]["total_ms"] * 1e-3) / 1e12
         if "knn" in summary:
             # exact KNN is VALU/latency bound, not HBM bound: brute-force-equivalent pairs/s, and the pairs
             # the pruned search really evaluated (device counter, one extra untimed pyramid) against the fp32 VALU roof
@@ -520,6 +532,7 @@ def main():
             "hot_path_only": {"kernel_ms_per_step": sum(v["ms_per_step"] for v in ops_table.values()),
                               "launches_per_step": sum(v["launches_per_step"] for v in ops_table.values())},
             "hot_path_ops": ops_table,
+            "hot_path_ops_one_stream": ops_one_stream,
             "hot_path_ops_source": f"{N_FULL} untimed steps between warm-up and the timed region with every hand-written launch "
                                    "bracketed by HIP events; the timed region brackets only the roofline kernel's launches",
         }

@@ -304,3 +304,67 @@ def test_row_operators_bf16(device):
     got = ops_pm.relative_pos_encoding(d(xyz), d(nei), dtype=BF).cpu()
     assert got.shape == (2, 300, 16, 16) and (got[..., 10:] == 0).all()
     assert torch.equal(got[..., :10], ops_ref.relative_pos_encoding(xyz, nei).to(BF))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# folded up-convolution (csrc/upconv.hip) and fused position encoding + mlp1 (csrc/posenc.hip); the same kernel bodies
+# run on the host in tests/test_hostsim_cpu.py
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,cin,cout,h,w", [(2, 64, 64, 24, 32), (1, 256, 64, 30, 40), (2, 1024, 256, 6, 8), (1, 16, 8, 1, 1),
+                                            (3, 24, 40, 5, 7)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_folded_upconv_matches_upsample_conv_bn_prelu(device, B, cin, cout, h, w, dt):
+    """PSPUpsample (pspnet.py:34-45) through forward_pm.up_block in the folded form against the torch modules in float64."""
+    from ffb6d_amd import forward_pm, model
+    if dt == torch.bfloat16 and (cin % 16 or cout % 8):
+        pytest.skip("bf16 rows need 16-channel inputs and 8-channel units")
+    g = torch.Generator().manual_seed(cin + cout)
+    ub = model.UpBlock(cin, cout).eval()
+    with torch.no_grad():
+        ub.conv[1].weight.copy_(torch.randn(ub.conv[1].weight.shape, generator=g) / (9 * cin) ** 0.5)
+        ub.conv[1].bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        ub.conv[2].weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        ub.conv[2].bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        ub.conv[2].running_mean.copy_(torch.randn(cout, generator=g) * 0.1)
+        ub.conv[2].running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    x = torch.randn(B, cin, h, w, generator=g)
+    with torch.no_grad():
+        want = ub.double().conv(x.double()).float()
+    ub = ub.float().to(device)
+    keep = forward_pm.UPCONV_FOLD
+    forward_pm.UPCONV_FOLD = None                                   # every block
+    try:
+        with torch.no_grad():
+            got = forward_pm.up_block(ub, x.to(device).permute(0, 2, 3, 1).contiguous().to(dt))
+    finally:
+        forward_pm.UPCONV_FOLD = keep
+    assert got.shape == (B, 2 * h, 2 * w, cout) and got.dtype == dt
+    got = got.float().permute(0, 3, 1, 2).cpu()
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max()) / scale
+    print("folded upconv", (B, cin, cout, h, w), dt, "max err / range %.2e" % err)
+    assert err <= (1e-5 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("B,N,K,cout,idt", [(2, 3072, 16, 32, torch.int64), (1, 12288, 16, 16, torch.int32), (8, 48, 16, 128, torch.int64),
+                                            (3, 17, 5, 24, torch.int64), (1, 1, 1, 8, torch.int64)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_posenc_mlp_matches_encoding_then_fp64_matmul(device, B, N, K, cout, idt, dt):
+    """mlp1(relative_pos_encoding(.)) (RandLANet.py:196-199, 216-223) in one pass against the float64 product of the
+    standalone encoding kernel's (bit-exact, test above) output."""
+    if dt == torch.bfloat16 and cout % 8:
+        pytest.skip("bf16 rows come in 8-channel units")
+    g = torch.Generator().manual_seed(N + cout)
+    xyz = torch.randn(B, N, 3, generator=g).to(device)
+    idx = torch.randint(0, N, (B, N, K), generator=g).to(idt).to(device)
+    w = torch.zeros(cout, 16)
+    w[:, :10] = torch.randn(cout, 10, generator=g) * 0.5
+    w[:, 10:] = 3.0                                                 # padding columns must be ignored
+    bias = torch.randn(cout, generator=g)
+    enc = ops_pm.relative_pos_encoding(xyz, idx)[..., :10].double().cpu()
+    for act, f in ((0, lambda v: v), (1, torch.relu), (2, lambda v: torch.nn.functional.leaky_relu(v, 0.2))):
+        want = f(enc @ w[:, :10].double().t() + bias.double())
+        got = ops_pm.posenc_mlp(xyz, idx, w.to(device), bias.to(device), act, dtype=dt)
+        assert got.shape == (B, N, K, cout) and got.dtype == dt
+        err = float((got.double().cpu() - want).abs().max()) / float(want.abs().max())
+        assert err <= (1e-5 if dt == torch.float32 else 1e-2), (act, err)
