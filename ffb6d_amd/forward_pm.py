@@ -100,9 +100,9 @@ def fc_weight(att, dt=F32):
 # ----------------------------------------------------------------------------------------------------
 # point branch
 # ----------------------------------------------------------------------------------------------------
-# FFB6D_POSENC_FUSED=1: relative_pos_encoding + lfa.mlp1 as one vector-ALU pass (csrc/posenc.hip) instead of the padded
-# encoding tensor + a K = 16 GEMM
-POSENC_FUSED = __import__("os").environ.get("FFB6D_POSENC_FUSED", "0").strip() not in ("", "0")
+# relative_pos_encoding + lfa.mlp1 as one vector-ALU pass (csrc/posenc.hip; default) instead of the padded encoding tensor +
+# a K = 16 GEMM (FFB6D_POSENC_FUSED=0, kept for A/B: profiles/r02_opt_in_forms_ab.json)
+POSENC_FUSED = __import__("os").environ.get("FFB6D_POSENC_FUSED", "1").strip() not in ("", "0")
 
 
 def building_block(bb, xyz, f_pc, nei):
@@ -186,11 +186,15 @@ def pyramid_pooling(pp, x):
     return ops_pm.mlp(x, wx, pp.bottleneck.bias.detach().float(), ops.ACT_RELU, add=prior)
 
 
-# Input widths of the PSPUpsample blocks that run in the folded form (csrc/upconv.hip).  FFB6D_UPCONV_FOLD: "0" = none,
-# "1" = every block, or a comma-separated list of input widths ("1024,256").
+# Which PSPUpsample blocks run in the folded form (csrc/upconv.hip).  FFB6D_UPCONV_FOLD: "auto" (default) = every block in
+# fp32, none in bf16 (measured, profiles/r02_opt_in_forms_ab.json: fp32 step 28.8 -> 23.8 ms; in bf16 MIOpen's convolution of
+# the up-sampled map is faster than the z GEMM + the tap blend, 17.2 -> 18.1 ms); "0" = none, "1" = every block in both
+# precisions, or a comma-separated list of input widths ("1024,256").
 def _fold_setting():
     import os
-    v = os.environ.get("FFB6D_UPCONV_FOLD", "0").strip()
+    v = os.environ.get("FFB6D_UPCONV_FOLD", "auto").strip()
+    if v == "auto":
+        return "auto"
     if v in ("", "0"):
         return frozenset()
     if v == "1":
@@ -199,6 +203,12 @@ def _fold_setting():
 
 
 UPCONV_FOLD = _fold_setting()
+
+
+def _fold_block(cin, dtype):
+    if UPCONV_FOLD == "auto":
+        return dtype == torch.float32
+    return UPCONV_FOLD is None or cin in UPCONV_FOLD
 
 
 def upconv_folded(ub, dt=F32):
@@ -228,7 +238,7 @@ def up_block(ub, x):
     and `upconv_combine` blends the tap planes, adds the BatchNorm shift and applies the PReLU in one pass."""
     B, h, w_, cin = x.shape
     cv, bn, prelu = ub.conv[1], ub.conv[2], ub.conv[3]
-    if (UPCONV_FOLD is None or cin in UPCONV_FOLD) and cv.kernel_size == (3, 3) and cv.padding == (1, 1) \
+    if _fold_block(cin, x.dtype) and cv.kernel_size == (3, 3) and cv.padding == (1, 1) \
             and cv.stride == (1, 1) and cv.dilation == (1, 1) and cv.groups == 1:
         w9, shift, slope = upconv_folded(ub, x.dtype)
         z = ops_pm.mlp(x, w9)                                                                 # [B,h,w,9*cout]
