@@ -47,7 +47,7 @@ extern "C" int ffb6d_posenc_mlp_pm(int dtype, const float* xyz, const void* idx,
     int64_t per_block = BLK;
     while (per_block % a.q) per_block += BLK;                  // threads per stride unit: multiple of 256 and of q
     const int64_t units = a.pairs * a.q;
-    int64_t blocks = std::min<int64_t>(ceil_div(units, BLK), (int64_t)256 * 8);
+    int64_t blocks = std::min<int64_t>(ceil_div(units, 4 * BLK), (int64_t)256 * 8);      // 4 pairs per thread and iteration
     blocks = std::max<int64_t>(ceil_div(blocks * BLK, per_block) * (per_block / BLK), per_block / BLK);
     const dim3 grid((unsigned)blocks);
     hipStream_t st = as_stream(stream);

@@ -48,27 +48,43 @@ __host__ __device__ __forceinline__ void mlp_body(const MlpArgs& a, long long ti
         bias[e] = a.bias ? a.bias[u * U::VL + e] : 0.f;
     }
     const IdxT* idx = static_cast<const IdxT*>(a.idx);
-    for (long long pr = tid / a.q; pr < a.pairs; pr += stride) {
-        const unsigned pair = (unsigned)pr;               // pairs < 2^31 (launcher): 32-bit divisions
-        const unsigned pn = pair / (unsigned)a.K;         // b * N + n
-        const unsigned b = pn / (unsigned)a.N;
-        const long long j = (long long)idx[pair];
-        const float* p = a.xyz + (size_t)pn * 3;
-        const float* qv = a.xyz + ((size_t)b * a.N + j) * 3;
-        const float px = p[0], py = p[1], pz = p[2];
-        const float qx = qv[0], qy = qv[1], qz = qv[2];
-        const float dx = px - qx, dy = py - qy, dz = pz - qz;
-        const float s = ((dx * dx) + (dy * dy)) + (dz * dz);          // compiled with -ffp-contract=off: no fusion
-        const float enc[10] = {sqrtf(s), dx, dy, dz, px, py, pz, qx, qy, qz};
-        U o;
+    // UN pairs per iteration: their index and coordinate loads are independent and in flight together (the chain
+    // index -> neighbour coordinates -> store of one pair is two memory latencies long)
+    constexpr int UN = 4;
+    for (long long pr0 = tid / a.q; pr0 < a.pairs; pr0 += UN * stride) {
+        float enc[UN][10];
+        bool live[UN];
 #pragma unroll
-        for (int e = 0; e < U::VL; ++e) {
-            float v = bias[e];
+        for (int n = 0; n < UN; ++n) {
+            const long long pr = pr0 + n * stride;
+            live[n] = pr < a.pairs;
+            const unsigned pair = live[n] ? (unsigned)pr : 0u;     // pairs < 2^31 (launcher): 32-bit divisions
+            const unsigned pn = pair / (unsigned)a.K;              // b * N + n
+            const unsigned b = pn / (unsigned)a.N;
+            const long long j = (long long)idx[pair];
+            const float* p = a.xyz + (size_t)pn * 3;
+            const float* qv = a.xyz + ((size_t)b * a.N + j) * 3;
+            const float px = p[0], py = p[1], pz = p[2];
+            const float qx = qv[0], qy = qv[1], qz = qv[2];
+            const float dx = px - qx, dy = py - qy, dz = pz - qz;
+            const float s = ((dx * dx) + (dy * dy)) + (dz * dz);      // compiled with -ffp-contract=off: no fusion
+            const float row[10] = {sqrtf(s), dx, dy, dz, px, py, pz, qx, qy, qz};
 #pragma unroll
-            for (int t = 0; t < 10; ++t) v = fmaf(w[e][t], enc[t], v);
-            o.v[e] = fmaxf(v, a.slope * v);
+            for (int t = 0; t < 10; ++t) enc[n][t] = row[t];
         }
-        o.store(a.out, (size_t)pair * a.q + u);
+#pragma unroll
+        for (int n = 0; n < UN; ++n) {
+            if (!live[n]) continue;
+            U o;
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) {
+                float v = bias[e];
+#pragma unroll
+                for (int t = 0; t < 10; ++t) v = fmaf(w[e][t], enc[n][t], v);
+                o.v[e] = fmaxf(v, a.slope * v);
+            }
+            o.store(a.out, (size_t)(pr0 + n * stride) * a.q + u);
+        }
     }
 }
 

@@ -7,6 +7,9 @@
 // quarter of the flops, on the hand-written MFMA kernel) and this file's kernel gathers the nine tap planes back together:
 // HBM-bound, z is read once from HBM (every element is used by ~16 output pixels: L1/L2 hits), the result written once,
 // with the BatchNorm shift and the PReLU in the same pass (the separate bilinear, BatchNorm and PReLU passes disappear).
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 #include "ffb6d_ops.h"
 #include "upconv_body.h"
@@ -23,6 +26,24 @@ __global__ void __launch_bounds__(BLK)
 upconv_combine_pm_kernel(const upconv::CombineArgs a)
 {
     upconv::combine_body<T>(a, (int)blockIdx.y, (int)(blockIdx.x * BLK + threadIdx.x));
+}
+
+// register-blocked form (exact x2 maps): blockIdx.y = (b, pair of output rows), thread = (block of 4 output columns, unit)
+template <typename T>
+__global__ void __launch_bounds__(BLK)
+upconv_combine_block_pm_kernel(const upconv::CombineArgs a)
+{
+    upconv::combine_block_body<T, 2, 4>(a, (int)blockIdx.y, (int)(blockIdx.x * BLK + threadIdx.x));
+}
+
+// FFB6D_UPCONV_COMBINE=simple forces the one-pixel-per-thread kernel (A/B); default: blocked wherever it applies
+bool blocked_allowed()
+{
+    static const bool ok = [] {
+        const char* v = getenv("FFB6D_UPCONV_COMBINE");
+        return !(v && strcmp(v, "simple") == 0);
+    }();
+    return ok;
 }
 
 }  // namespace
@@ -51,11 +72,17 @@ extern "C" int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* sh
     a.rh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;       // ATen area_pixel_compute_scale, align_corners
     a.rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
     a.slope = slope;
-    const dim3 grid((unsigned)ceil_div(OW * (int64_t)a.q, BLK), (unsigned)(B * OH));
-    if (dtype == 1)
-        hipLaunchKernelGGL((upconv_combine_pm_kernel<__bf16>), grid, dim3(BLK), 0, as_stream(stream), a);
-    else
-        hipLaunchKernelGGL((upconv_combine_pm_kernel<float>), grid, dim3(BLK), 0, as_stream(stream), a);
+    if (OH == 2 * IH && OW == 2 * IW && OW % 4 == 0 && dtype == 0 && blocked_allowed()) {
+        // fp32 rows only: with 8-channel bf16 units the 2 x 4 block does not fit the register file without spilling
+        const dim3 grid((unsigned)ceil_div(OW / 4 * (int64_t)a.q, BLK), (unsigned)(B * OH / 2));
+        hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float>), grid, dim3(BLK), 0, as_stream(stream), a);
+    } else {
+        const dim3 grid((unsigned)ceil_div(OW * (int64_t)a.q, BLK), (unsigned)(B * OH));
+        if (dtype == 1)
+            hipLaunchKernelGGL((upconv_combine_pm_kernel<__bf16>), grid, dim3(BLK), 0, as_stream(stream), a);
+        else
+            hipLaunchKernelGGL((upconv_combine_pm_kernel<float>), grid, dim3(BLK), 0, as_stream(stream), a);
+    }
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }

@@ -15,6 +15,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef FFB6D_UPCONV_KX_UNROLL
+#define FFB6D_UPCONV_KX_UNROLL _Pragma("unroll 1")
+#endif
+
 namespace ffb6d {
 namespace upconv {
 
@@ -126,6 +130,142 @@ __host__ __device__ __forceinline__ void combine_body(const CombineArgs& a, int 
         }
     }
     o.store(a.out, (size_t)row * a.OW * a.q + t);
+}
+
+// Register-blocked form for the exact x2 case (OH = 2 IH, OW = 2 IW, OW % BX == 0): a thread owns BY x BX = 2 x 4 output
+// pixels of one 16-byte channel unit.  combine_body issues 36 sixteen-byte loads per output unit and is bound by the L1
+// (64 B/clk/CU: measured 1.9 TB/s of algorithmic bytes); here the BY x BX taps of one (ky, kx) share a window of NR x NC =
+// 3 x 4 low-resolution pixels (scale < 1/2: two consecutive rows of the up-sampled map start at most one source row apart,
+// four consecutive columns at most two source columns), i.e. 12 loads per 8 outputs and tap instead of 32.
+// Every output is produced by the same operations in the same order as in combine_body -- horizontal blend of the two
+// source rows, vertical blend, tap by tap -- with the operands picked out of the window by selects: bit-identical results
+// (tests/test_hostsim_cpu.py), NaN / Inf stay confined to the pixels the reference spreads them to.
+template <typename T, int BY, int BX>
+__host__ __device__ __forceinline__ void combine_block_body(const CombineArgs& a, int rowblk, int t)
+{
+    using U = Unit<T>;
+    constexpr int NR = BY / 2 + 2, NC = BX / 2 + 2;
+    const int XB = a.OW / BX, RB = a.OH / BY;
+    if (t >= XB * a.q) return;
+    const int yb = rowblk % RB, b = rowblk / RB;
+    const int xb = t / a.q;
+    const int c = t - xb * a.q;
+    const int Y0 = yb * BY, X0 = xb * BX;
+    const size_t q9 = (size_t)9 * a.q;
+    float acc[BY][BX][U::VL];
+#pragma unroll
+    for (int i = 0; i < BY; ++i)
+#pragma unroll
+        for (int j = 0; j < BX; ++j)
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) acc[i][j][e] = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+        // the BY rows of the up-sampled map this tap reads, their source rows and weights (as combine_body)
+        bool y_in[BY];
+        int ra[BY], rb[BY];                         // window rows of the two source rows of output row i
+        float h0l[BY], h1l[BY];
+        int hb = 0;
+#pragma unroll
+        for (int i = 0; i < BY; ++i) {
+            const int yr = Y0 + i + ky - 1;
+            y_in[i] = yr >= 0 && yr < a.OH;
+            const int yp = y_in[i] ? yr : Y0 + i;
+            const float h1r = a.rh * (float)yp;
+            const int h1 = (int)h1r;
+            const int h1p = (h1 < a.IH - 1) ? 1 : 0;
+            h1l[i] = h1r - (float)h1;
+            h0l[i] = 1.f - h1l[i];
+            if (i == 0) hb = h1;
+            ra[i] = h1 - hb;
+            rb[i] = ra[i] + h1p;
+        }
+FFB6D_UPCONV_KX_UNROLL
+        for (int kx = 0; kx < 3; ++kx) {
+            bool x_in[BX];
+            int ca[BX], cb[BX];
+            float w0l[BX], w1l[BX];
+            int wb = 0;
+#pragma unroll
+            for (int j = 0; j < BX; ++j) {
+                const int xr = X0 + j + kx - 1;
+                x_in[j] = xr >= 0 && xr < a.OW;
+                const int xp = x_in[j] ? xr : X0 + j;
+                const float w1r = a.rw * (float)xp;
+                const int w1 = (int)w1r;
+                const int w1p = (w1 < a.IW - 1) ? 1 : 0;
+                w1l[j] = w1r - (float)w1;
+                w0l[j] = 1.f - w1l[j];
+                if (j == 0) wb = w1;
+                ca[j] = w1 - wb;
+                cb[j] = ca[j] + w1p;
+            }
+            // the window of this tap: NR x NC low-resolution pixels from (hb, wb), clamped to the map (a clamped
+            // element is never selected: the second source row / column coincides with the first one at the border)
+            U win[NR][NC];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int hr = hb + r < a.IH ? hb + r : a.IH - 1;
+                const size_t rowoff = ((size_t)b * a.IH + hr) * a.IW * q9 + (size_t)(ky * 3 + kx) * a.q + c;
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    const int wc = wb + cc < a.IW ? wb + cc : a.IW - 1;
+                    win[r][cc] = U::load(a.z, rowoff + (size_t)wc * q9);
+                }
+            }
+            // horizontal blend of every window row for the BX output columns
+            float s[NR][BX][U::VL];
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int j = 0; j < BX; ++j)
+#pragma unroll
+                    for (int e = 0; e < U::VL; ++e) {
+                        float pa = win[r][0].v[e], pb = win[r][0].v[e];
+#pragma unroll
+                        for (int cc = 1; cc < NC; ++cc) {
+                            pa = ca[j] == cc ? win[r][cc].v[e] : pa;
+                            pb = cb[j] == cc ? win[r][cc].v[e] : pb;
+                        }
+                        s[r][j][e] = w0l[j] * pa + w1l[j] * pb;
+                    }
+#pragma unroll
+            for (int i = 0; i < BY; ++i)
+#pragma unroll
+                for (int j = 0; j < BX; ++j) {
+                    const bool in = y_in[i] && x_in[j];
+#pragma unroll
+                    for (int e = 0; e < U::VL; ++e) {
+                        float sa = s[0][j][e], sb = s[0][j][e];
+#pragma unroll
+                        for (int r = 1; r < NR; ++r) {
+                            sa = ra[i] == r ? s[r][j][e] : sa;
+                            sb = rb[i] == r ? s[r][j][e] : sb;
+                        }
+                        const float v = h0l[i] * sa + h1l[i] * sb;
+                        acc[i][j][e] += in ? v : 0.f;
+                    }
+                }
+        }
+    }
+    float sh[U::VL];
+#pragma unroll
+    for (int e = 0; e < U::VL; e += 4) {
+        const float4 s4 = *reinterpret_cast<const float4*>(a.shift + (size_t)c * U::VL + e);
+        sh[e] = s4.x; sh[e + 1] = s4.y; sh[e + 2] = s4.z; sh[e + 3] = s4.w;
+    }
+#pragma unroll
+    for (int i = 0; i < BY; ++i)
+#pragma unroll
+        for (int j = 0; j < BX; ++j) {
+            U o;
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) {
+                const float v = acc[i][j][e] + sh[e];
+                o.v[e] = v >= 0.f ? v : a.slope * v;        // PReLU
+            }
+            o.store(a.out, ((size_t)(b * a.OH + Y0 + i) * a.OW + X0 + j) * a.q + c);
+        }
 }
 
 }  // namespace upconv

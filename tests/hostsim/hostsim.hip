@@ -11,7 +11,7 @@
 #include "upconv_body.h"
 
 extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shift, float slope, void* out, int64_t B, int64_t IH,
-                                      int64_t IW, int64_t OH, int64_t OW, int64_t C)
+                                      int64_t IW, int64_t OH, int64_t OW, int64_t C, int blocked)
 {
     using namespace ffb6d::upconv;
     const int VL = dtype == 1 ? 8 : 4;
@@ -23,6 +23,16 @@ extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shi
     a.rh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;       // as the launcher in csrc/upconv.hip
     a.rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
     a.slope = slope;
+    if (blocked) {                                                  // the launcher's rule (csrc/upconv.hip)
+        if (OH != 2 * IH || OW != 2 * IW || OW % 4) return -2;
+        const int threads = (int)((OW / 4 * a.q + 255) / 256 * 256);
+        for (int rb = 0; rb < (int)(B * OH / 2); ++rb)
+            for (int t = 0; t < threads; ++t) {
+                if (dtype == 1) combine_block_body<__bf16, 2, 4>(a, rb, t);
+                else combine_block_body<float, 2, 4>(a, rb, t);
+            }
+        return 0;
+    }
     const int threads = (int)((OW * a.q + 255) / 256 * 256);        // whole workgroups: the surplus threads must bail out
     for (int row = 0; row < (int)(B * OH); ++row)
         for (int t = 0; t < threads; ++t) {

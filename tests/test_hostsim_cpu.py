@@ -20,7 +20,7 @@ def sim():
     lib = ctypes.CDLL(build.build())
     vp, i64 = ctypes.c_void_p, ctypes.c_int64
     lib.hostsim_upconv_combine.restype = ctypes.c_int
-    lib.hostsim_upconv_combine.argtypes = [ctypes.c_int, vp, vp, ctypes.c_float, vp, i64, i64, i64, i64, i64, i64]
+    lib.hostsim_upconv_combine.argtypes = [ctypes.c_int, vp, vp, ctypes.c_float, vp, i64, i64, i64, i64, i64, i64, ctypes.c_int]
     return lib
 
 
@@ -37,7 +37,7 @@ def _up_block(cin, cout, seed):
     return ub
 
 
-def _folded_on_host(sim, ub, x, dt):
+def _folded_on_host(sim, ub, x, dt, blocked=0):
     """the folded up-convolution exactly as forward_pm.up_block runs it, with torch for the GEMM and the host simulation of
     upconv_combine_pm_kernel for the second half; x [B,cin,h,w] float32 -> [B,cout,2h,2w] float32"""
     B, cin, h, w = x.shape
@@ -47,7 +47,7 @@ def _folded_on_host(sim, ub, x, dt):
     cout = shift.numel()
     out = torch.empty(B, 2 * h, 2 * w, cout, dtype=dt)
     rc = sim.hostsim_upconv_combine(1 if dt == torch.bfloat16 else 0, z.data_ptr(), shift.data_ptr(), slope, out.data_ptr(),
-                                    B, h, w, 2 * h, 2 * w, cout)
+                                    B, h, w, 2 * h, 2 * w, cout, blocked)
     assert rc == 0
     return out.float().permute(0, 3, 1, 2)
 
@@ -64,6 +64,33 @@ def test_folded_upconv_equals_upsample_conv_bn_prelu(sim, B, cin, cout, h, w):
     assert float((got - want).abs().max()) <= 1e-5 * scale
     # the negative (PReLU) side and the border taps are exercised
     assert float(want.min()) < 0 and got.shape == want.shape
+
+
+@pytest.mark.parametrize("B,cin,cout,h,w", [(2, 16, 8, 5, 6), (1, 8, 16, 1, 2), (1, 24, 4, 2, 10), (3, 8, 12, 7, 4), (1, 8, 8, 9, 14)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_register_blocked_combine_is_bit_identical_to_the_simple_form(sim, B, cin, cout, h, w, dt):
+    """combine_block_body (2 x 4 output pixels per thread, window of 3 x 4 source pixels per tap) against combine_body:
+    the same operations in the same order per output -> equal bits, on maps with every border case (1 .. 9 source rows)."""
+    if dt == torch.bfloat16 and cout % 8:
+        pytest.skip("bf16 rows come in 8-channel units")
+    ub = _up_block(cin, cout, seed=h + w)
+    x = torch.randn(B, cin, h, w, generator=torch.Generator().manual_seed(h * w))
+    with torch.no_grad():
+        simple = _folded_on_host(sim, ub, x, dt, blocked=0)
+        blocked = _folded_on_host(sim, ub, x, dt, blocked=1)
+    assert torch.equal(simple, blocked)
+
+
+def test_register_blocked_combine_keeps_nan_where_the_simple_form_puts_it(sim):
+    """a NaN source pixel reaches exactly the outputs whose taps blend it (operands are selected, not weighted by zero)"""
+    ub = _up_block(8, 8, seed=5)
+    x = torch.randn(1, 8, 6, 8, generator=torch.Generator().manual_seed(1))
+    x[0, :, 2, 5] = float("nan")
+    with torch.no_grad():
+        simple = _folded_on_host(sim, ub, x, torch.float32, blocked=0)
+        blocked = _folded_on_host(sim, ub, x, torch.float32, blocked=1)
+    assert torch.equal(torch.isnan(simple), torch.isnan(blocked)) and 0 < int(torch.isnan(simple).sum()) < simple.numel() // 4
+    assert torch.equal(torch.nan_to_num(simple), torch.nan_to_num(blocked))
 
 
 def test_folded_upconv_bf16_rows(sim):
