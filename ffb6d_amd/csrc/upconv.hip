@@ -29,21 +29,25 @@ upconv_combine_pm_kernel(const upconv::CombineArgs a)
 }
 
 // register-blocked form (exact x2 maps): blockIdx.y = (b, pair of output rows), thread = (block of 4 output columns, unit)
-template <typename T>
+template <typename T, bool STATIC>
 __global__ void __launch_bounds__(BLK)
 upconv_combine_block_pm_kernel(const upconv::CombineArgs a)
 {
-    upconv::combine_block_body<T, 2, 4>(a, (int)blockIdx.y, (int)(blockIdx.x * BLK + threadIdx.x));
+    upconv::combine_block_body<T, STATIC>(a, (int)blockIdx.y, (int)(blockIdx.x * BLK + threadIdx.x));
 }
 
-// FFB6D_UPCONV_COMBINE=simple forces the one-pixel-per-thread kernel (A/B); default: blocked wherever it applies
-bool blocked_allowed()
+// FFB6D_UPCONV_COMBINE = simple | select | static (A/B): one pixel per thread; 2 x 4 block with operand selects (the form
+// measured at 2.5 TB/s, profiles/r02_bench_default_run.json); the same block with the compile-time operand pattern wherever
+// a thread's positions follow it (default)
+int combine_form()
 {
-    static const bool ok = [] {
+    static const int form = [] {
         const char* v = getenv("FFB6D_UPCONV_COMBINE");
-        return !(v && strcmp(v, "simple") == 0);
+        if (v && strcmp(v, "simple") == 0) return 0;
+        if (v && strcmp(v, "select") == 0) return 1;
+        return 2;
     }();
-    return ok;
+    return form;
 }
 
 }  // namespace
@@ -72,10 +76,14 @@ extern "C" int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* sh
     a.rh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;       // ATen area_pixel_compute_scale, align_corners
     a.rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
     a.slope = slope;
-    if (OH == 2 * IH && OW == 2 * IW && OW % 4 == 0 && dtype == 0 && blocked_allowed()) {
+    const int form = combine_form();
+    if (OH == 2 * IH && OW == 2 * IW && OW % 4 == 0 && dtype == 0 && form > 0) {
         // fp32 rows only: with 8-channel bf16 units the 2 x 4 block does not fit the register file without spilling
         const dim3 grid((unsigned)ceil_div(OW / 4 * (int64_t)a.q, BLK), (unsigned)(B * OH / 2));
-        hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float>), grid, dim3(BLK), 0, as_stream(stream), a);
+        if (form == 2)
+            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, true>), grid, dim3(BLK), 0, as_stream(stream), a);
+        else
+            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, false>), grid, dim3(BLK), 0, as_stream(stream), a);
     } else {
         const dim3 grid((unsigned)ceil_div(OW * (int64_t)a.q, BLK), (unsigned)(B * OH));
         if (dtype == 1)

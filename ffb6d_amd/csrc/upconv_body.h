@@ -15,10 +15,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#ifndef FFB6D_UPCONV_KX_UNROLL
-#define FFB6D_UPCONV_KX_UNROLL _Pragma("unroll 1")
-#endif
-
 namespace ffb6d {
 namespace upconv {
 
@@ -132,120 +128,180 @@ __host__ __device__ __forceinline__ void combine_body(const CombineArgs& a, int 
     o.store(a.out, (size_t)row * a.OW * a.q + t);
 }
 
-// Register-blocked form for the exact x2 case (OH = 2 IH, OW = 2 IW, OW % BX == 0): a thread owns BY x BX = 2 x 4 output
-// pixels of one 16-byte channel unit.  combine_body issues 36 sixteen-byte loads per output unit and is bound by the L1
-// (64 B/clk/CU: measured 1.9 TB/s of algorithmic bytes); here the BY x BX taps of one (ky, kx) share a window of NR x NC =
-// 3 x 4 low-resolution pixels (scale < 1/2: two consecutive rows of the up-sampled map start at most one source row apart,
-// four consecutive columns at most two source columns), i.e. 12 loads per 8 outputs and tap instead of 32.
+// Register-blocked form for the exact x2 case (OH = 2 IH, OW = 2 IW, OW % 4 == 0): a thread owns 2 x 4 output pixels of one
+// 16-byte channel unit.  combine_body issues 36 sixteen-byte loads per output unit and is bound by the L1 (64 B/clk/CU:
+// measured 1.9 TB/s of algorithmic bytes); here the 2 x 4 positions one filter tap reads share a window of at most 3 x 4
+// low-resolution pixels (scale < 1/2: two consecutive rows of the up-sampled map start at most one source row apart, four
+// consecutive columns at most two source columns).
 // Every output is produced by the same operations in the same order as in combine_body -- horizontal blend of the two
-// source rows, vertical blend, tap by tap -- with the operands picked out of the window by selects: bit-identical results
-// (tests/test_hostsim_cpu.py), NaN / Inf stay confined to the pixels the reference spreads them to.
-template <typename T, int BY, int BX>
+// source rows, vertical blend, tap by tap -- so the results are bit-identical (tests/test_hostsim_cpu.py) and NaN / Inf
+// stay confined to the pixels the reference spreads them to.  Two ways to pick the operands out of the window:
+//   * tap_select: per-element selects on the window position of each operand (any block; ~900 vector instructions per tap);
+//   * tap_static: in exact arithmetic position 2m of the up-sampled axis reads source pixels (m-1, m) and 2m+1 reads
+//     (m, m+1), so for an aligned block the window positions are compile-time constants (and the window shrinks to 2..3 rows
+//     x 3..4 columns: 70 loads per thread instead of 108).  The float arithmetic of ATen can deviate from that pattern only
+//     where a source index lands on an integer (the last row / column), and the first block of an axis is clamped: a thread
+//     takes the static path for a tap only after checking that the positions it computed ARE the pattern, else tap_select.
+struct Axis2 { bool in[2]; int a[2], b[2]; float l0[2], l1[2]; int base; };
+struct Axis4 { bool in[4]; int a[4], b[4]; float l0[4], l1[4]; int base; };
+
+// positions P0 + n + k - 1 (n < B) of an up-sampled axis of length O over a source axis of length I: inside the map?, window
+// offsets of the two source pixels, blend weights (ATen upsample_bilinear2d, align_corners: as combine_body)
+template <int B, typename AX>
+__host__ __device__ __forceinline__ void tap_axis(AX& ax, int P0, int k, int O, int I, float scale)
+{
+#pragma unroll
+    for (int n = 0; n < B; ++n) {
+        const int pr = P0 + n + k - 1;
+        ax.in[n] = pr >= 0 && pr < O;
+        const int pp = ax.in[n] ? pr : P0 + n;
+        const float sr = scale * (float)pp;
+        const int s1 = (int)sr;
+        const int s1p = (s1 < I - 1) ? 1 : 0;
+        ax.l1[n] = sr - (float)s1;
+        ax.l0[n] = 1.f - ax.l1[n];
+        if (n == 0) ax.base = s1;
+        ax.a[n] = s1 - ax.base;
+        ax.b[n] = ax.a[n] + s1p;
+    }
+}
+
+template <typename T>
+__host__ __device__ __forceinline__ void tap_select(const CombineArgs& a, const Axis2& ay, const Axis4& ax, size_t tapoff,
+                                                    size_t q9, int b, float (&acc)[2][4][Unit<T>::VL])
+{
+    using U = Unit<T>;
+    constexpr int NR = 3, NC = 4;
+    // the window of this tap: NR x NC low-resolution pixels from (base row, base column), clamped to the map (a clamped
+    // element is never selected: the second source row / column coincides with the first one at the border)
+    U win[NR][NC];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int hr = ay.base + r < a.IH ? ay.base + r : a.IH - 1;
+        const size_t rowoff = ((size_t)b * a.IH + hr) * a.IW * q9 + tapoff;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            const int wc = ax.base + cc < a.IW ? ax.base + cc : a.IW - 1;
+            win[r][cc] = U::load(a.z, rowoff + (size_t)wc * q9);
+        }
+    }
+    float s[NR][4][U::VL];                           // horizontal blend of every window row for the 4 output columns
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) {
+                float pa = win[r][0].v[e], pb = win[r][0].v[e];
+#pragma unroll
+                for (int cc = 1; cc < NC; ++cc) {
+                    pa = ax.a[j] == cc ? win[r][cc].v[e] : pa;
+                    pb = ax.b[j] == cc ? win[r][cc].v[e] : pb;
+                }
+                s[r][j][e] = ax.l0[j] * pa + ax.l1[j] * pb;
+            }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = ay.in[i] && ax.in[j];
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) {
+                float sa = s[0][j][e], sb = s[0][j][e];
+#pragma unroll
+                for (int r = 1; r < NR; ++r) {
+                    sa = ay.a[i] == r ? s[r][j][e] : sa;
+                    sb = ay.b[i] == r ? s[r][j][e] : sb;
+                }
+                const float v = ay.l0[i] * sa + ay.l1[i] * sb;
+                acc[i][j][e] += in ? v : 0.f;
+            }
+        }
+}
+
+// the pattern of an aligned block: tap k = 1 starts on an even position (offsets 0,1,1,2..), taps 0 and 2 on an odd one (0,0,1,1..)
+__host__ __device__ constexpr int pattern_a(bool mid, int n) { return mid ? (n + 1) >> 1 : n >> 1; }
+
+template <typename T, bool KYM, bool KXM>
+__host__ __device__ __forceinline__ void tap_static(const CombineArgs& a, const Axis2& ay, const Axis4& ax, size_t tapoff,
+                                                    size_t q9, int b, float (&acc)[2][4][Unit<T>::VL])
+{
+    using U = Unit<T>;
+    constexpr int NR = KYM ? 3 : 2, NC = KXM ? 4 : 3;
+    U win[NR][NC];                                   // every element of it is a source pixel of some output: inside the map
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const size_t rowoff = ((size_t)b * a.IH + ay.base + r) * a.IW * q9 + tapoff;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) win[r][cc] = U::load(a.z, rowoff + (size_t)(ax.base + cc) * q9);
+    }
+    float s[NR][4][U::VL];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e)
+                s[r][j][e] = ax.l0[j] * win[r][pattern_a(KXM, j)].v[e] + ax.l1[j] * win[r][pattern_a(KXM, j) + 1].v[e];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = ay.in[i] && ax.in[j];
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) {
+                const float v = ay.l0[i] * s[pattern_a(KYM, i)][j][e] + ay.l1[i] * s[pattern_a(KYM, i) + 1][j][e];
+                acc[i][j][e] += in ? v : 0.f;
+            }
+        }
+}
+
+// rowblk = b * (OH / 2) + pair of output rows, t = (block of 4 output columns) * q + unit
+template <typename T, bool STATIC>
 __host__ __device__ __forceinline__ void combine_block_body(const CombineArgs& a, int rowblk, int t)
 {
     using U = Unit<T>;
-    constexpr int NR = BY / 2 + 2, NC = BX / 2 + 2;
-    const int XB = a.OW / BX, RB = a.OH / BY;
+    const int XB = a.OW / 4, RB = a.OH / 2;
     if (t >= XB * a.q) return;
     const int yb = rowblk % RB, b = rowblk / RB;
     const int xb = t / a.q;
     const int c = t - xb * a.q;
-    const int Y0 = yb * BY, X0 = xb * BX;
+    const int Y0 = yb * 2, X0 = xb * 4;
     const size_t q9 = (size_t)9 * a.q;
-    float acc[BY][BX][U::VL];
+    float acc[2][4][U::VL];
 #pragma unroll
-    for (int i = 0; i < BY; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < BX; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < U::VL; ++e) acc[i][j][e] = 0.f;
+    // the tap loops stay rolled: unrolled, the compiler keeps the loads of all nine windows in flight and spills
 #pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
-        // the BY rows of the up-sampled map this tap reads, their source rows and weights (as combine_body)
-        bool y_in[BY];
-        int ra[BY], rb[BY];                         // window rows of the two source rows of output row i
-        float h0l[BY], h1l[BY];
-        int hb = 0;
+        Axis2 ay;
+        tap_axis<2>(ay, Y0, ky, a.OH, a.IH, a.rh);
+        bool rows_ok = STATIC;
 #pragma unroll
-        for (int i = 0; i < BY; ++i) {
-            const int yr = Y0 + i + ky - 1;
-            y_in[i] = yr >= 0 && yr < a.OH;
-            const int yp = y_in[i] ? yr : Y0 + i;
-            const float h1r = a.rh * (float)yp;
-            const int h1 = (int)h1r;
-            const int h1p = (h1 < a.IH - 1) ? 1 : 0;
-            h1l[i] = h1r - (float)h1;
-            h0l[i] = 1.f - h1l[i];
-            if (i == 0) hb = h1;
-            ra[i] = h1 - hb;
-            rb[i] = ra[i] + h1p;
-        }
-FFB6D_UPCONV_KX_UNROLL
+        for (int i = 0; i < 2; ++i) rows_ok = rows_ok && ay.a[i] == pattern_a(ky == 1, i) && ay.b[i] == ay.a[i] + 1;
+#pragma unroll 1
         for (int kx = 0; kx < 3; ++kx) {
-            bool x_in[BX];
-            int ca[BX], cb[BX];
-            float w0l[BX], w1l[BX];
-            int wb = 0;
+            Axis4 ax;
+            tap_axis<4>(ax, X0, kx, a.OW, a.IW, a.rw);
+            bool ok = rows_ok;
 #pragma unroll
-            for (int j = 0; j < BX; ++j) {
-                const int xr = X0 + j + kx - 1;
-                x_in[j] = xr >= 0 && xr < a.OW;
-                const int xp = x_in[j] ? xr : X0 + j;
-                const float w1r = a.rw * (float)xp;
-                const int w1 = (int)w1r;
-                const int w1p = (w1 < a.IW - 1) ? 1 : 0;
-                w1l[j] = w1r - (float)w1;
-                w0l[j] = 1.f - w1l[j];
-                if (j == 0) wb = w1;
-                ca[j] = w1 - wb;
-                cb[j] = ca[j] + w1p;
-            }
-            // the window of this tap: NR x NC low-resolution pixels from (hb, wb), clamped to the map (a clamped
-            // element is never selected: the second source row / column coincides with the first one at the border)
-            U win[NR][NC];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int hr = hb + r < a.IH ? hb + r : a.IH - 1;
-                const size_t rowoff = ((size_t)b * a.IH + hr) * a.IW * q9 + (size_t)(ky * 3 + kx) * a.q + c;
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) {
-                    const int wc = wb + cc < a.IW ? wb + cc : a.IW - 1;
-                    win[r][cc] = U::load(a.z, rowoff + (size_t)wc * q9);
+            for (int j = 0; j < 4; ++j) ok = ok && ax.a[j] == pattern_a(kx == 1, j) && ax.b[j] == ax.a[j] + 1;
+            const size_t tapoff = (size_t)(ky * 3 + kx) * a.q + c;
+            if (STATIC && ok) {
+                if (ky == 1) {
+                    if (kx == 1) tap_static<T, true, true>(a, ay, ax, tapoff, q9, b, acc);
+                    else tap_static<T, true, false>(a, ay, ax, tapoff, q9, b, acc);
+                } else {
+                    if (kx == 1) tap_static<T, false, true>(a, ay, ax, tapoff, q9, b, acc);
+                    else tap_static<T, false, false>(a, ay, ax, tapoff, q9, b, acc);
                 }
+            } else {
+                tap_select<T>(a, ay, ax, tapoff, q9, b, acc);
             }
-            // horizontal blend of every window row for the BX output columns
-            float s[NR][BX][U::VL];
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-#pragma unroll
-                for (int j = 0; j < BX; ++j)
-#pragma unroll
-                    for (int e = 0; e < U::VL; ++e) {
-                        float pa = win[r][0].v[e], pb = win[r][0].v[e];
-#pragma unroll
-                        for (int cc = 1; cc < NC; ++cc) {
-                            pa = ca[j] == cc ? win[r][cc].v[e] : pa;
-                            pb = cb[j] == cc ? win[r][cc].v[e] : pb;
-                        }
-                        s[r][j][e] = w0l[j] * pa + w1l[j] * pb;
-                    }
-#pragma unroll
-            for (int i = 0; i < BY; ++i)
-#pragma unroll
-                for (int j = 0; j < BX; ++j) {
-                    const bool in = y_in[i] && x_in[j];
-#pragma unroll
-                    for (int e = 0; e < U::VL; ++e) {
-                        float sa = s[0][j][e], sb = s[0][j][e];
-#pragma unroll
-                        for (int r = 1; r < NR; ++r) {
-                            sa = ra[i] == r ? s[r][j][e] : sa;
-                            sb = rb[i] == r ? s[r][j][e] : sb;
-                        }
-                        const float v = h0l[i] * sa + h1l[i] * sb;
-                        acc[i][j][e] += in ? v : 0.f;
-                    }
-                }
         }
     }
     float sh[U::VL];
@@ -255,9 +311,9 @@ FFB6D_UPCONV_KX_UNROLL
         sh[e] = s4.x; sh[e + 1] = s4.y; sh[e + 2] = s4.z; sh[e + 3] = s4.w;
     }
 #pragma unroll
-    for (int i = 0; i < BY; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < BX; ++j) {
+        for (int j = 0; j < 4; ++j) {
             U o;
 #pragma unroll
             for (int e = 0; e < U::VL; ++e) {

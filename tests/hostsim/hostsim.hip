@@ -28,8 +28,8 @@ extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shi
         const int threads = (int)((OW / 4 * a.q + 255) / 256 * 256);
         for (int rb = 0; rb < (int)(B * OH / 2); ++rb)
             for (int t = 0; t < threads; ++t) {
-                if (dtype == 1) combine_block_body<__bf16, 2, 4>(a, rb, t);
-                else combine_block_body<float, 2, 4>(a, rb, t);
+                if (dtype == 1) { if (blocked == 2) combine_block_body<__bf16, true>(a, rb, t); else combine_block_body<__bf16, false>(a, rb, t); }
+                else { if (blocked == 2) combine_block_body<float, true>(a, rb, t); else combine_block_body<float, false>(a, rb, t); }
             }
         return 0;
     }
@@ -61,4 +61,29 @@ extern "C" int hostsim_posenc_mlp(int dtype, const float* xyz, const void* idx, 
         else { if (idx_bits == 64) mlp_body<float, int64_t>(a, tid, nthreads); else mlp_body<float, int32_t>(a, tid, nthreads); }
     }
     return 0;
+}
+
+// share of (2 x 4 block, filter tap) pairs of one frame whose source positions follow the compile-time pattern, i.e. that
+// combine_block_body<T, true> sends down tap_static (the same checks, on the launcher's scales)
+extern "C" double hostsim_upconv_static_share(int64_t IH, int64_t IW)
+{
+    using namespace ffb6d::upconv;
+    const int OH = (int)(2 * IH), OW = (int)(2 * IW);
+    const float rh = (float)(IH - 1) / (float)(OH - 1), rw = (float)(IW - 1) / (float)(OW - 1);
+    long long fast = 0, all = 0;
+    for (int Y0 = 0; Y0 < OH; Y0 += 2)
+        for (int X0 = 0; X0 < OW; X0 += 4)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    Axis2 ay;
+                    Axis4 ax;
+                    tap_axis<2>(ay, Y0, ky, OH, (int)IH, rh);
+                    tap_axis<4>(ax, X0, kx, OW, (int)IW, rw);
+                    bool ok = true;
+                    for (int i = 0; i < 2; ++i) ok = ok && ay.a[i] == pattern_a(ky == 1, i) && ay.b[i] == ay.a[i] + 1;
+                    for (int j = 0; j < 4; ++j) ok = ok && ax.a[j] == pattern_a(kx == 1, j) && ax.b[j] == ax.a[j] + 1;
+                    fast += ok;
+                    ++all;
+                }
+    return (double)fast / (double)all;
 }

@@ -66,18 +66,20 @@ def test_folded_upconv_equals_upsample_conv_bn_prelu(sim, B, cin, cout, h, w):
     assert float(want.min()) < 0 and got.shape == want.shape
 
 
-@pytest.mark.parametrize("B,cin,cout,h,w", [(2, 16, 8, 5, 6), (1, 8, 16, 1, 2), (1, 24, 4, 2, 10), (3, 8, 12, 7, 4), (1, 8, 8, 9, 14)])
+@pytest.mark.parametrize("B,cin,cout,h,w", [(2, 16, 8, 5, 6), (1, 8, 16, 1, 2), (1, 24, 4, 2, 10), (3, 8, 12, 7, 4), (1, 8, 8, 9, 14), (1, 8, 8, 60, 80)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_register_blocked_combine_is_bit_identical_to_the_simple_form(sim, B, cin, cout, h, w, dt):
-    """combine_block_body (2 x 4 output pixels per thread, window of 3 x 4 source pixels per tap) against combine_body:
-    the same operations in the same order per output -> equal bits, on maps with every border case (1 .. 9 source rows)."""
+@pytest.mark.parametrize("form", [1, 2])
+def test_register_blocked_combine_is_bit_identical_to_the_simple_form(sim, B, cin, cout, h, w, dt, form):
+    """combine_block_body (2 x 4 output pixels per thread, window of 3 x 4 source pixels per tap; form 1 = operand selects,
+    form 2 = compile-time operand pattern where a thread's positions follow it) against combine_body: the same operations in
+    the same order per output -> equal bits, on maps with every border case (1 .. 9 source rows)."""
     if dt == torch.bfloat16 and cout % 8:
         pytest.skip("bf16 rows come in 8-channel units")
     ub = _up_block(cin, cout, seed=h + w)
     x = torch.randn(B, cin, h, w, generator=torch.Generator().manual_seed(h * w))
     with torch.no_grad():
         simple = _folded_on_host(sim, ub, x, dt, blocked=0)
-        blocked = _folded_on_host(sim, ub, x, dt, blocked=1)
+        blocked = _folded_on_host(sim, ub, x, dt, blocked=form)
     assert torch.equal(simple, blocked)
 
 
@@ -88,7 +90,8 @@ def test_register_blocked_combine_keeps_nan_where_the_simple_form_puts_it(sim):
     x[0, :, 2, 5] = float("nan")
     with torch.no_grad():
         simple = _folded_on_host(sim, ub, x, torch.float32, blocked=0)
-        blocked = _folded_on_host(sim, ub, x, torch.float32, blocked=1)
+        blocked = _folded_on_host(sim, ub, x, torch.float32, blocked=2)
+        assert torch.equal(torch.nan_to_num(blocked), torch.nan_to_num(_folded_on_host(sim, ub, x, torch.float32, blocked=1)))
     assert torch.equal(torch.isnan(simple), torch.isnan(blocked)) and 0 < int(torch.isnan(simple).sum()) < simple.numel() // 4
     assert torch.equal(torch.nan_to_num(simple), torch.nan_to_num(blocked))
 
@@ -159,3 +162,14 @@ def test_fused_posenc_mlp_equals_encoding_then_shared_mlp(sim_posenc, B, N, K, c
                                            bias.data_ptr(), 2, outb.data_ptr(), B, N, K, cout, blocks)
         assert rc == 0
         assert float((outb.double() - want).abs().max()) <= 1e-2 * float(want.abs().max())
+
+
+def test_static_operand_pattern_covers_the_interior_of_the_real_maps(sim):
+    """the compile-time operand pattern of the blocked tap blend must hold for all but the border blocks of the three
+    PSPUpsample maps (60x80, 120x160, 240x320 sources): else the fast path would silently never run"""
+    sim.hostsim_upconv_static_share.restype = ctypes.c_double
+    sim.hostsim_upconv_static_share.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    for ih, iw, least in ((60, 80, 0.90), (120, 160, 0.95), (240, 320, 0.97)):
+        share = sim.hostsim_upconv_static_share(ih, iw)
+        print("static share", ih, iw, share)
+        assert share >= least, (ih, iw, share)
