@@ -19,21 +19,25 @@ namespace {
 
 constexpr int BLK = 256;
 
-// blockIdx.y = output row (b, Y): the vertical taps, source rows and weights are wave-uniform scalars;
-// blockIdx.x * 256 + thread = (output column, 16-byte unit) of that row
+// logical workgroup (bx, by) through the XCD-aware order (upconv::xcd_band_block): by = output row (b, Y) -- the vertical
+// taps, source rows and weights are wave-uniform scalars -- and bx * 256 + thread = (output column, 16-byte unit) of that row
 template <typename T>
 __global__ void __launch_bounds__(BLK)
 upconv_combine_pm_kernel(const upconv::CombineArgs a)
 {
-    upconv::combine_body<T>(a, (int)blockIdx.y, (int)(blockIdx.x * BLK + threadIdx.x));
+    unsigned bx, by;
+    if (!upconv::xcd_band_block(blockIdx.x, a.nbx, a.nby, bx, by)) return;
+    upconv::combine_body<T>(a, (int)by, (int)(bx * BLK + threadIdx.x));
 }
 
-// register-blocked form (exact x2 maps): blockIdx.y = (b, pair of output rows), thread = (block of 4 output columns, unit)
+// register-blocked form (exact x2 maps): by = (b, pair of output rows), bx * 256 + thread = (block of 4 output columns, unit)
 template <typename T, bool STATIC>
 __global__ void __launch_bounds__(BLK)
 upconv_combine_block_pm_kernel(const upconv::CombineArgs a)
 {
-    upconv::combine_block_body<T, STATIC>(a, (int)blockIdx.y, (int)(blockIdx.x * BLK + threadIdx.x));
+    unsigned bx, by;
+    if (!upconv::xcd_band_block(blockIdx.x, a.nbx, a.nby, bx, by)) return;
+    upconv::combine_block_body<T, STATIC>(a, (int)by, (int)(bx * BLK + threadIdx.x));
 }
 
 // FFB6D_UPCONV_COMBINE = simple | select | static (A/B): one pixel per thread; 2 x 4 block with operand selects (the form
@@ -67,7 +71,7 @@ extern "C" int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* sh
     FFB6D_REQUIRE(z && shift && out && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(out) |
                                          reinterpret_cast<uintptr_t>(shift)) & 15) == 0,
                   "upconv_combine_pm: null or unaligned pointer");
-    FFB6D_REQUIRE(B * OH < 65536, "upconv_combine_pm: B * OH must stay below 65536 (grid y)");
+    FFB6D_REQUIRE(ceil_div(OW * (C / VL), BLK) * B * OH < (1LL << 31) - 8, "upconv_combine_pm: too many workgroups");
     FFB6D_REQUIRE(OW * (C / VL) < (1LL << 31), "upconv_combine_pm: row too long");
     upconv::CombineArgs a;
     a.z = z; a.shift = shift; a.out = out;
@@ -79,13 +83,17 @@ extern "C" int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* sh
     const int form = combine_form();
     if (OH == 2 * IH && OW == 2 * IW && OW % 4 == 0 && dtype == 0 && form > 0) {
         // fp32 rows only: with 8-channel bf16 units the 2 x 4 block does not fit the register file without spilling
-        const dim3 grid((unsigned)ceil_div(OW / 4 * (int64_t)a.q, BLK), (unsigned)(B * OH / 2));
+        a.nbx = (unsigned)ceil_div(OW / 4 * (int64_t)a.q, BLK);
+        a.nby = (unsigned)(B * OH / 2);
+        const dim3 grid((unsigned)(8 * ceil_div((int64_t)a.nbx * a.nby, 8)));
         if (form == 2)
             hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, true>), grid, dim3(BLK), 0, as_stream(stream), a);
         else
             hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, false>), grid, dim3(BLK), 0, as_stream(stream), a);
     } else {
-        const dim3 grid((unsigned)ceil_div(OW * (int64_t)a.q, BLK), (unsigned)(B * OH));
+        a.nbx = (unsigned)ceil_div(OW * (int64_t)a.q, BLK);
+        a.nby = (unsigned)(B * OH);
+        const dim3 grid((unsigned)(8 * ceil_div((int64_t)a.nbx * a.nby, 8)));
         if (dtype == 1)
             hipLaunchKernelGGL((upconv_combine_pm_kernel<__bf16>), grid, dim3(BLK), 0, as_stream(stream), a);
         else

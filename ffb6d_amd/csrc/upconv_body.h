@@ -59,6 +59,20 @@ template <> struct Unit<__bf16> {
     }
 };
 
+// XCD-aware order of a 2-D launch (MI355X: 8 XCDs with private L2s, workgroup i of a 1-D grid runs on XCD i % 8 -- observed
+// dispatch rule, speed only): XCD x gets the x-th contiguous eighth of the row-major (by, bx) blocks, i.e. a band of
+// consecutive output rows, so the source rows a band re-reads stay in ONE L2 instead of being fetched by all eight.
+// `id` = index in a grid of 8 * ceil(nbx * nby / 8) workgroups; false = surplus workgroup.
+__host__ __device__ __forceinline__ bool xcd_band_block(unsigned id, unsigned nbx, unsigned nby, unsigned& bx, unsigned& by)
+{
+    const unsigned nb = nbx * nby, per = (nb + 7u) >> 3;
+    const unsigned l = (id & 7u) * per + (id >> 3);
+    if ((id >> 3) >= per || l >= nb) return false;
+    by = l / nbx;
+    bx = l - by * nbx;
+    return true;
+}
+
 struct CombineArgs {
     const void* z;        // [B, IH, IW, 9, C] rows of T: tap-major blocks of C channels per low-resolution pixel
     const float* shift;   // [C] fp32: BatchNorm shift + BatchNorm scale * conv bias
@@ -67,6 +81,7 @@ struct CombineArgs {
     int q;                // 16-byte units per C channels
     float rh, rw;         // ATen's align_corners scales (IH-1)/(OH-1), (IW-1)/(OW-1)
     float slope;          // PReLU slope (one parameter)
+    unsigned nbx, nby;    // logical launch: workgroups along the row of threads, output rows (or row pairs) of all frames
 };
 
 // row = b * OH + Y (uniform over a workgroup), t = X * q + unit

@@ -6,6 +6,7 @@
 // so that index arithmetic and numerics of a kernel can be checked against torch on a machine without a GPU.
 // Nothing in the product path loads this library.
 #include <cstdint>
+#include <vector>
 
 #include "posenc_body.h"
 #include "upconv_body.h"
@@ -86,4 +87,28 @@ extern "C" double hostsim_upconv_static_share(int64_t IH, int64_t IW)
                     ++all;
                 }
     return (double)fast / (double)all;
+}
+
+// the XCD-aware launch order (upconv::xcd_band_block): every logical workgroup exactly once over the padded 1-D grid, and the
+// workgroups of one XCD (id % 8) form one contiguous row-major range.  0 = ok.
+extern "C" int hostsim_xcd_band_check(unsigned nbx, unsigned nby)
+{
+    using namespace ffb6d::upconv;
+    const unsigned nb = nbx * nby, grid = 8 * ((nb + 7) / 8);
+    std::vector<int> seen(nb, 0);
+    std::vector<long long> lo(8, -1), hi(8, -1), cnt(8, 0);
+    for (unsigned id = 0; id < grid; ++id) {
+        unsigned bx = ~0u, by = ~0u;
+        if (!xcd_band_block(id, nbx, nby, bx, by)) continue;
+        if (bx >= nbx || by >= nby) return 1;
+        const long long l = (long long)by * nbx + bx;
+        if (seen[l]++) return 2;
+        const unsigned x = id & 7;
+        if (lo[x] < 0 || l < lo[x]) lo[x] = l;
+        if (l > hi[x]) hi[x] = l;
+        ++cnt[x];
+    }
+    for (unsigned l = 0; l < nb; ++l) if (seen[l] != 1) return 3;
+    for (int x = 0; x < 8; ++x) if (cnt[x] && hi[x] - lo[x] + 1 != cnt[x]) return 4;
+    return 0;
 }

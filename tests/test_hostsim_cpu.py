@@ -173,3 +173,10 @@ def test_static_operand_pattern_covers_the_interior_of_the_real_maps(sim):
         share = sim.hostsim_upconv_static_share(ih, iw)
         print("static share", ih, iw, share)
         assert share >= least, (ih, iw, share)
+
+
+@pytest.mark.parametrize("nbx,nby", [(10, 1920), (40, 960), (1, 1), (3, 5), (7, 1), (1, 9), (40, 3840), (2, 4)])
+def test_xcd_band_order_is_a_bijection_with_one_contiguous_band_per_xcd(sim, nbx, nby):
+    sim.hostsim_xcd_band_check.restype = ctypes.c_int
+    sim.hostsim_xcd_band_check.argtypes = [ctypes.c_uint, ctypes.c_uint]
+    assert sim.hostsim_xcd_band_check(nbx, nby) == 0
