@@ -19,49 +19,15 @@
 
 #include "common.h"
 #include "ffb6d_ops.h"
+#include "row_unit.h"
 
 namespace ffb6d {
 namespace {
 
 constexpr int BLK = 256;
 
-// a 16-byte unit of a row: VL consecutive channels, held as fp32 in registers
-template <typename T> struct Unit;
-template <> struct Unit<float> {
-    static constexpr int VL = 4;
-    float v[4];
-    static __device__ __forceinline__ Unit load(const void* base, size_t unit)
-    {
-        const float4 f = static_cast<const float4*>(base)[unit];
-        Unit u; u.v[0] = f.x; u.v[1] = f.y; u.v[2] = f.z; u.v[3] = f.w;
-        return u;
-    }
-    __device__ __forceinline__ void store(void* base, size_t unit) const
-    {
-        static_cast<float4*>(base)[unit] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-};
-template <> struct Unit<__bf16> {
-    static constexpr int VL = 8;
-    float v[8];
-    static __device__ __forceinline__ Unit load(const void* base, size_t unit)
-    {
-        const uint4 w = static_cast<const uint4*>(base)[unit];
-        const unsigned int x[4] = {w.x, w.y, w.z, w.w};
-        Unit u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { u.v[2 * i] = __uint_as_float(x[i] << 16); u.v[2 * i + 1] = __uint_as_float(x[i] & 0xffff0000u); }
-        return u;
-    }
-    __device__ __forceinline__ void store(void* base, size_t unit) const
-    {
-        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-        bf16x8 b;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) b[i] = (__bf16)v[i];
-        static_cast<bf16x8*>(base)[unit] = b;
-    }
-};
+// a 16-byte unit of a row: VL consecutive channels, held as fp32 in registers (csrc/row_unit.h)
+template <typename T> using Unit = RowUnit<T>;
 // fp32 per-channel parameters (BatchNorm scale / shift) of a unit's VL channels
 template <int VL>
 __device__ __forceinline__ void load_params(const float* p, int unit, float (&out)[VL])

@@ -16,7 +16,7 @@
 
 #include <cmath>
 
-#include "upconv_body.h"     // upconv::Unit<T>
+#include "row_unit.h"
 
 namespace ffb6d {
 namespace posenc {
@@ -36,7 +36,7 @@ struct MlpArgs {
 template <typename T, typename IdxT>
 __host__ __device__ __forceinline__ void mlp_body(const MlpArgs& a, long long tid, long long nthreads)
 {
-    using U = upconv::Unit<T>;
+    using U = RowUnit<T>;
     const int u = (int)(tid % a.q);                       // nthreads % q == 0: the unit of a thread never changes
     const long long stride = nthreads / a.q;
     float w[U::VL][10], bias[U::VL];

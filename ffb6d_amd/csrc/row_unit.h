@@ -1,0 +1,49 @@
+// ffb6d_amd/csrc/row_unit.h -- a 16-byte unit of a point-major / pixel-major row: VL consecutive channels (4 float32 or
+// 8 bfloat16), held as fp32 in registers; stores round to nearest even.  __host__ __device__: the per-thread kernel bodies
+// that use it (csrc/*_body.h) also run on the CPU in tests/hostsim.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ffb6d {
+
+template <typename T> struct RowUnit;
+template <> struct RowUnit<float> {
+    static constexpr int VL = 4;
+    float v[4];
+    static __host__ __device__ __forceinline__ RowUnit load(const void* base, size_t unit)
+    {
+        const float4 f = static_cast<const float4*>(base)[unit];
+        RowUnit u; u.v[0] = f.x; u.v[1] = f.y; u.v[2] = f.z; u.v[3] = f.w;
+        return u;
+    }
+    __host__ __device__ __forceinline__ void store(void* base, size_t unit) const
+    {
+        static_cast<float4*>(base)[unit] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct RowUnit<__bf16> {
+    static constexpr int VL = 8;
+    float v[8];
+    static __host__ __device__ __forceinline__ RowUnit load(const void* base, size_t unit)
+    {
+        const uint4 w = static_cast<const uint4*>(base)[unit];
+        const unsigned int x[4] = {w.x, w.y, w.z, w.w};
+        RowUnit u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u.v[2 * i] = __builtin_bit_cast(float, x[i] << 16);
+            u.v[2 * i + 1] = __builtin_bit_cast(float, x[i] & 0xffff0000u);
+        }
+        return u;
+    }
+    __host__ __device__ __forceinline__ void store(void* base, size_t unit) const
+    {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        bf16x8 b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = (__bf16)v[i];       // round to nearest even
+        static_cast<bf16x8*>(base)[unit] = b;
+    }
+};
+
+}  // namespace ffb6d

@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(BLK)
 upconv_combine_pm_kernel(const upconv::CombineArgs a)
 {
     unsigned bx, by;
-    if (!upconv::xcd_band_block(blockIdx.x, a.nbx, a.nby, bx, by)) return;
+    if (!upconv::xcd_band_block(blockIdx.x, a.nbx, a.nby, bx, by, a.banded != 0)) return;
     upconv::combine_body<T>(a, (int)by, (int)(bx * BLK + threadIdx.x));
 }
 
@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(BLK)
 upconv_combine_block_pm_kernel(const upconv::CombineArgs a)
 {
     unsigned bx, by;
-    if (!upconv::xcd_band_block(blockIdx.x, a.nbx, a.nby, bx, by)) return;
+    if (!upconv::xcd_band_block(blockIdx.x, a.nbx, a.nby, bx, by, a.banded != 0)) return;
     upconv::combine_block_body<T, STATIC>(a, (int)by, (int)(bx * BLK + threadIdx.x));
 }
 
@@ -81,6 +81,8 @@ extern "C" int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* sh
     a.rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
     a.slope = slope;
     const int form = combine_form();
+    static const bool banded = [] { const char* v = getenv("FFB6D_UPCONV_XCD"); return !(v && strcmp(v, "0") == 0); }();
+    a.banded = banded ? 1 : 0;
     if (OH == 2 * IH && OW == 2 * IW && OW % 4 == 0 && dtype == 0 && form > 0) {
         // fp32 rows only: with 8-channel bf16 units the 2 x 4 block does not fit the register file without spilling
         a.nbx = (unsigned)ceil_div(OW / 4 * (int64_t)a.q, BLK);

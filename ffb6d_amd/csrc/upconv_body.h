@@ -15,57 +15,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "row_unit.h"
+
 namespace ffb6d {
 namespace upconv {
 
-// a 16-byte unit of a row: VL consecutive channels, held as fp32 (the twin of ops_pm.hip's Unit, host-callable)
-template <typename T> struct Unit;
-template <> struct Unit<float> {
-    static constexpr int VL = 4;
-    float v[4];
-    static __host__ __device__ __forceinline__ Unit load(const void* base, size_t unit)
-    {
-        const float4 f = static_cast<const float4*>(base)[unit];
-        Unit u; u.v[0] = f.x; u.v[1] = f.y; u.v[2] = f.z; u.v[3] = f.w;
-        return u;
-    }
-    __host__ __device__ __forceinline__ void store(void* base, size_t unit) const
-    {
-        static_cast<float4*>(base)[unit] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-};
-template <> struct Unit<__bf16> {
-    static constexpr int VL = 8;
-    float v[8];
-    static __host__ __device__ __forceinline__ Unit load(const void* base, size_t unit)
-    {
-        const uint4 w = static_cast<const uint4*>(base)[unit];
-        const unsigned int x[4] = {w.x, w.y, w.z, w.w};
-        Unit u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u.v[2 * i] = __builtin_bit_cast(float, x[i] << 16);
-            u.v[2 * i + 1] = __builtin_bit_cast(float, x[i] & 0xffff0000u);
-        }
-        return u;
-    }
-    __host__ __device__ __forceinline__ void store(void* base, size_t unit) const
-    {
-        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-        bf16x8 b;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) b[i] = (__bf16)v[i];       // round to nearest even
-        static_cast<bf16x8*>(base)[unit] = b;
-    }
-};
+template <typename T> using Unit = RowUnit<T>;      // csrc/row_unit.h
 
 // XCD-aware order of a 2-D launch (MI355X: 8 XCDs with private L2s, workgroup i of a 1-D grid runs on XCD i % 8 -- observed
 // dispatch rule, speed only): XCD x gets the x-th contiguous eighth of the row-major (by, bx) blocks, i.e. a band of
 // consecutive output rows, so the source rows a band re-reads stay in ONE L2 instead of being fetched by all eight.
 // `id` = index in a grid of 8 * ceil(nbx * nby / 8) workgroups; false = surplus workgroup.
-__host__ __device__ __forceinline__ bool xcd_band_block(unsigned id, unsigned nbx, unsigned nby, unsigned& bx, unsigned& by)
+__host__ __device__ __forceinline__ bool xcd_band_block(unsigned id, unsigned nbx, unsigned nby, unsigned& bx, unsigned& by,
+                                                        bool banded = true)
 {
     const unsigned nb = nbx * nby, per = (nb + 7u) >> 3;
+    if (!banded) {                                   // plain row-major order (A/B)
+        by = id / nbx;
+        bx = id - by * nbx;
+        return id < nb;
+    }
     const unsigned l = (id & 7u) * per + (id >> 3);
     if ((id >> 3) >= per || l >= nb) return false;
     by = l / nbx;
@@ -81,6 +50,7 @@ struct CombineArgs {
     int q;                // 16-byte units per C channels
     float rh, rw;         // ATen's align_corners scales (IH-1)/(OH-1), (IW-1)/(OW-1)
     float slope;          // PReLU slope (one parameter)
+    int banded;           // 1: XCD-band workgroup order (default), 0: row-major (FFB6D_UPCONV_XCD=0, A/B)
     unsigned nbx, nby;    // logical launch: workgroups along the row of threads, output rows (or row pairs) of all frames
 };
 

@@ -24,6 +24,7 @@ extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shi
     a.rh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;       // as the launcher in csrc/upconv.hip
     a.rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
     a.slope = slope;
+    a.banded = 1; a.nbx = a.nby = 0;                                // launch order: not used by the bodies
     if (blocked) {                                                  // the launcher's rule (csrc/upconv.hip)
         if (OH != 2 * IH || OW != 2 * IW || OW % 4) return -2;
         const int threads = (int)((OW / 4 * a.q + 255) / 256 * 256);
