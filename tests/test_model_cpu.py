@@ -175,3 +175,33 @@ def test_forward_on_cpu_tensors_fails_loudly():
     net = M.FFB6D(n_classes=5, n_pts=1024).eval()
     with torch.no_grad(), pytest.raises(_lib.FFB6DNativeError):
         net(inputs)
+
+
+def test_upconv_fold_switch_parsing(monkeypatch):
+    """FFB6D_UPCONV_FOLD: auto (fp32 only, default) / 0 / 1 / list of input widths (forward_pm._fold_setting)"""
+    import torch
+    from ffb6d_amd import forward_pm
+    for env, want32, want16, want_other in (("auto", True, False, True), (None, True, False, True), ("0", False, False, False),
+                                            ("1", True, True, True), ("1024,256", True, True, False)):
+        if env is None:
+            monkeypatch.delenv("FFB6D_UPCONV_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("FFB6D_UPCONV_FOLD", env)
+        monkeypatch.setattr(forward_pm, "UPCONV_FOLD", forward_pm._fold_setting())
+        assert forward_pm._fold_block(1024, torch.float32) is want32
+        assert forward_pm._fold_block(1024, torch.bfloat16) is want16
+        assert forward_pm._fold_block(64, torch.float32) is want_other
+
+
+def test_upconv_folded_without_conv_bias_and_with_per_channel_prelu():
+    import pytest
+    import torch
+    from ffb6d_amd import forward_pm, model
+    ub = model.UpBlock(8, 4).eval()
+    ub.conv[1] = torch.nn.Conv2d(8, 4, 3, padding=1, bias=False)
+    w9, shift, slope = forward_pm.upconv_folded(ub)
+    bn = ub.conv[2]
+    assert w9.shape == (36, 8) and torch.allclose(shift, (bn.bias - bn.running_mean * bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach())
+    ub.conv[3] = torch.nn.PReLU(4)
+    with pytest.raises(NotImplementedError):
+        forward_pm.upconv_folded(ub)
