@@ -1,0 +1,56 @@
+"""Builds tests/simt/libsimt_ffb6d.so: wave-level kernels of the product library (csrc/mlp_pm.hip: the point-major GEMM family
+and the fused attentive pooling) compiled for the HOST against the SIMT emulator (tests/simt/simt.*, fake/hip/hip_runtime.h).
+The kernel sources are used as they are, except for mechanical substitutions made on a scratch copy:
+  * the declaration of the dynamic shared array becomes a pointer to the emulator's buffer;
+  * where a wave reads LDS data that OTHER lanes of the same wave wrote without any instruction in between that the emulator
+    treats as a rendezvous (hardware runs a wave in lock step, fibers do not), a `simt::wave_sync()` is inserted: one place,
+    between the epilogue of mlp_pm_stream_kernel (lanes deposit result rows in the wave's LDS image) and the whole-row stores.
+Test infrastructure only."""
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "ffb6d_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libsimt_ffb6d.so")
+KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip"]
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+# statements after which a wave relies on lock-step execution for LDS traffic between its lanes
+LOCKSTEP_AFTER = {"mlp_pm.hip": ["stream_epilogue<T, TM, LSM>(p, acc, img, OS, r0, l31, kh);"]}
+DYN_SHARED = re.compile(r"extern\s+__shared__\s+__attribute__\(\(aligned\(16\)\)\)\s+unsigned char\s+(\w+)\[\];")
+
+
+def transformed(name):
+    with open(os.path.join(CSRC, name)) as fh:
+        src = fh.read()
+    src = DYN_SHARED.sub(r"unsigned char* \1 = simt::dyn_shared();", src)
+    for anchor in LOCKSTEP_AFTER.get(name, []):
+        if src.count(anchor) != 1:
+            raise RuntimeError(f"{name}: lock-step anchor not found exactly once: {anchor}")
+        src = src.replace(anchor, anchor + "\n        simt::wave_sync();      // inserted by tests/simt/build.py")
+    dst = os.path.join(OUT, name.replace(".hip", ".simt.cpp"))
+    with open(dst, "w") as fh:
+        fh.write(src)
+    return dst
+
+
+def build():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, f) for f in ("simt.cpp", "simt.h", "build.py")] + \
+        [os.path.join(HERE, "fake", "hip", "hip_runtime.h")]
+    if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    os.makedirs(OUT, exist_ok=True)
+    srcs = [transformed(n) for n in KERNEL_SOURCES] + [os.path.join(HERE, "simt.cpp")]
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value",
+           "-Wno-unknown-attributes", "-I" + os.path.join(HERE, "fake"), "-I" + HERE, "-I" + os.path.join(ROOT, "include"),
+           "-I" + CSRC] + srcs + ["-o", LIB + ".tmp"]
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build())

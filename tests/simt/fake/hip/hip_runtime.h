@@ -1,0 +1,157 @@
+// tests/simt/fake/hip/hip_runtime.h -- TEST INFRASTRUCTURE: the slice of the HIP device / runtime vocabulary that the
+// product kernels use, re-defined for the HOST on top of the SIMT emulator (tests/simt/simt.h), so that the unmodified kernel
+// sources compile with the host compiler (clang++ -x c++) and run on the CPU.  Only what csrc/*.hip needs is here.
+//
+// gfx950 semantics restated:
+//   v_mfma_f32_32x32x2_f32   lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; accumulator register r of
+//                            lane l is D[i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][j = l & 31]
+//   v_mfma_f32_32x32x16_bf16 same accumulator layout; lane l supplies A[i = l & 31][k = 8 (l >> 5) .. + 7] and the same of B
+//   raw buffer load / store  per dword: in range iff voffset + 4 d < num_records (the scalar offset is not range checked);
+//                            out-of-range loads return zero, stores are dropped
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "simt.h"
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static                      /* one workgroup runs at a time: a static array IS workgroup-shared */
+#define __restrict__
+
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct int2 { int x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+
+typedef simt::Dim3 dim3;
+#define threadIdx simt::g_thread
+#define blockIdx simt::g_block
+#define gridDim simt::g_grid
+#define blockDim simt::g_bdim
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "simt"; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 2; return hipSuccess; }
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) simt::launch(kernel, grid, block, shmem, __VA_ARGS__)
+
+static inline float __uint_as_float(unsigned u) { return __builtin_bit_cast(float, u); }
+static inline unsigned __float_as_uint(float f) { return __builtin_bit_cast(unsigned, f); }
+static inline void __syncthreads() { simt::block_sync(); }
+static inline int min(int a, int b) { return a < b ? a : b; }                 /* HIP's device-side overloads */
+static inline int max(int a, int b) { return a > b ? a : b; }
+
+namespace simt {
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct Rsrc { unsigned char* base; unsigned size; };
+
+template <typename V> inline V* scratch() { return static_cast<V*>(wave_scratch()); }
+
+inline float shfl_xor(float v, int mask)
+{
+    float* s = scratch<float>();
+    s[lane()] = v;
+    wave_sync();
+    const float r = s[(lane() ^ mask) & 63];
+    wave_sync();
+    return r;
+}
+
+inline f32x16_t mfma_32x32x2_f32(float a, float b, f32x16_t c)
+{
+    struct Op { float a, b; };
+    Op* s = scratch<Op>();
+    const int l = lane();
+    s[l] = Op{a, b};
+    wave_sync();
+    const int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(s[i + 32 * k].a, s[j + 32 * k].b, acc);
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+
+inline f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c)
+{
+    struct Op { float a[8], b[8]; };
+    Op* s = scratch<Op>();
+    const int l = lane();
+    for (int e = 0; e < 8; ++e) { s[l].a[e] = (float)a[e]; s[l].b[e] = (float)b[e]; }
+    wave_sync();
+    const int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) acc = fmaf(s[i + 32 * h].a[e], s[j + 32 * h].b[e], acc);
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+
+inline u32x4_t buffer_load_b128(Rsrc rs, int voffset, int soffset)
+{
+    wave_sync();                                     // a wave issues it in lock step (wave-synchronous LDS idioms rely on that)
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    const unsigned vo = (unsigned)voffset;
+    for (int d = 0; d < 4; ++d) {
+        const unsigned off = vo + 4u * d;
+        if (off < rs.size && vo <= 0xffffffffu - 16u) {
+            unsigned w;
+            memcpy(&w, rs.base + (ptrdiff_t)soffset + off, 4);
+            v[d] = w;
+        }
+    }
+    return v;
+}
+
+inline void buffer_store_b128(u32x4_t v, Rsrc rs, int voffset, int soffset)
+{
+    wave_sync();
+    const unsigned vo = (unsigned)voffset;
+    for (int d = 0; d < 4; ++d) {
+        const unsigned off = vo + 4u * d;
+        if (off < rs.size && vo <= 0xffffffffu - 16u) {
+            const unsigned w = v[d];
+            memcpy(rs.base + (ptrdiff_t)soffset + off, &w, 4);
+        }
+    }
+}
+
+}  // namespace simt
+
+typedef simt::Rsrc __amdgpu_buffer_rsrc_t;
+#define __builtin_amdgcn_make_buffer_rsrc(ptr, stride, num, flags) simt::Rsrc{reinterpret_cast<unsigned char*>(ptr), (unsigned)(num)}
+#define __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, aux) simt::buffer_load_b128(rs, vo, so)
+#define __builtin_amdgcn_raw_buffer_store_b128(v, rs, vo, so, aux) simt::buffer_store_b128(v, rs, vo, so)
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) simt::mfma_32x32x2_f32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) simt::mfma_32x32x16_bf16(a, b, c)
+#define __builtin_amdgcn_readfirstlane(x) (x)   /* the kernels only pass wave-uniform values */
+#define __builtin_amdgcn_sched_barrier(x) simt::wave_sync()
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __shfl_xor(v, mask, width) simt::shfl_xor(v, mask)

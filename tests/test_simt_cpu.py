@@ -1,0 +1,165 @@
+"""Wave-level kernels of the product library executed on the CPU by the SIMT emulator of tests/simt (fibers for threads,
+rendezvous at MFMA / shuffle / barrier / buffer instructions): the point-major GEMM family of csrc/mlp_pm.hip in all of its
+forms (tile kernels, K-split, stream form, LDS-tiled form; fp32 and bf16) and the fused attentive pooling, driven through the
+package's own host wrappers (ffb6d_amd/ops_pm.py: argument marshalling, strides, per-frame gather bookkeeping) and checked
+against float64.  The same cases run on the GPU in tests/test_pm_gpu.py; here they need no GPU."""
+import contextlib
+import ctypes
+import os
+
+import pytest
+import torch
+
+from ffb6d_amd import _lib, ops, ops_pm
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs ROCm's clang++ to build the emulated library")
+
+
+@pytest.fixture(scope="module")
+def emu(request):
+    """ops_pm.mlp / ops_pm.att_pool bound to the emulated library, with the GPU guards of the wrappers lifted"""
+    from tests.simt import build
+    lib = ctypes.CDLL(build.build())
+    for name in ("ffb6d_mlp_pm_f32", "ffb6d_mlp_pm_bf16", "ffb6d_att_pool_pm_f32", "ffb6d_att_pool_pm_bf16", "ffb6d_mlp_pm_choice",
+                 "ffb6d_mlp_pm_tile", "ffb6d_last_error"):
+        res, args = _lib.SIGNATURES[name]
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    mp = pytest.MonkeyPatch()
+    mp.setattr(_lib, "_LIB", lib)
+    mp.setattr(ops_pm, "_need_gpu", lambda *ts: None)
+    mp.setattr(ops_pm, "_stream", lambda t: None)
+    mp.setattr(torch.cuda, "device", lambda dev: contextlib.nullcontext())
+    request.addfinalizer(mp.undo)
+    return lib
+
+
+def _ref(x1, w, bias, act, x2=None, add=None, gather=None, x1_gather=None):
+    if x1_gather is not None:
+        x1 = torch.gather(x1, 1, x1_gather.long().unsqueeze(2).expand(-1, -1, x1.shape[2]))
+    x = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+    y = x.double() @ w.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    if gather is not None:
+        Y, idx = gather
+        y = y + torch.gather(Y.double(), 1, idx.long().unsqueeze(2).expand(-1, -1, Y.shape[2]))
+    if add is not None:
+        y = y + add.double()
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = torch.nn.functional.leaky_relu(y, 0.2)
+    elif act == 3:
+        y = torch.log_softmax(y, dim=-1)
+    return y
+
+
+# (B, P, K1, K2, Cout, act, py [>0 gathered epilogue rows, <0 added rows], tile_hint); sizes an emulated run finishes in a moment
+CASES = [(2, 130, 24, 8, 37, 1, 13, h) for h in (1, 2, 3, 4, 5)]                      # every tile kernel, ragged rows / channels
+CASES += [(1, 300, 64, 0, 64, 1, 0, 6), (2, 201, 24, 0, 16, 0, 0, 6), (1, 260, 32, 96, 100, 2, 70, 6), (1, 130, 128, 0, 128, 1, -1, 6)]  # stream form
+CASES += [(1, 300, 96, 0, 40, 0, 0, 7), (2, 140, 32, 32, 72, 2, 50, 7), (1, 257, 256, 0, 200, 1, -1, 7), (8, 24, 512, 256, 256, 2, 0, 7)]  # LDS-tiled form
+CASES += [(8, 48, 1024, 0, 64, 1, 0, 5), (1, 33, 8, 8, 5, 1, 0, 0), (1, 1, 8, 0, 8, 0, 0, 0), (2, 64, 128, 0, 22, 0, 0, 0)]      # K split, tiny, automatic choice
+
+
+@pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", CASES)
+def test_mlp_pm_fp32_on_the_emulator_matches_fp64(emu, B, P, K1, K2, Cout, act, py, hint):
+    g = torch.Generator().manual_seed(K1 + Cout + P)
+    x1 = torch.randn(B, P, K1, generator=g)
+    x2 = torch.randn(B, P, K2, generator=g) if K2 else None
+    w = torch.randn(Cout, K1 + K2, generator=g) / (K1 + K2) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    gather = (torch.randn(B, py, Cout, generator=g), torch.randint(0, py, (B, P), generator=g)) if py > 0 else None
+    add = torch.randn(B, P, Cout, generator=g) if py < 0 else None
+    want = _ref(x1, w, bias, act, x2=x2, add=add, gather=gather)
+    got = ops_pm.mlp(x1, w, bias, act, x2=x2, add=add, gather=gather, tile_hint=hint)
+    assert got.shape == want.shape
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("hint", [2, 3, 6])
+def test_log_softmax_epilogue_on_the_emulator(emu, hint):
+    """pspnet.py:108-112 `final`: the wave's tile spans all channels, a point's channels sit in lanes l and l ^ 32"""
+    cout = 32 if hint == 3 else 64
+    g = torch.Generator().manual_seed(hint)
+    x = torch.randn(1, 300, 64, generator=g)
+    w = torch.randn(cout, 64, generator=g) / 8
+    bias = torch.randn(cout, generator=g)
+    want = _ref(x, w, bias, 3)
+    got = ops_pm.mlp(x, w, bias, ops_pm.ACT_LOG_SOFTMAX, tile_hint=hint)
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("hint", [1, 2, 7])
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+def test_operand_gather_on_the_emulator(emu, hint, idt):
+    """`choose` (ffb6d.py:309-312): the gather of the picked pixel rows IS the operand load of the head GEMM"""
+    g = torch.Generator().manual_seed(5)
+    B, M, P, K1, K2, Cout = 2, 500, 150, 32, 32, 48
+    img = torch.randn(B, M, K1, generator=g)
+    pts = torch.randn(B, P, K2, generator=g)
+    pick = torch.randint(0, M, (B, P), generator=g).to(idt)
+    w = torch.randn(Cout, K1 + K2, generator=g) / 8
+    bias = torch.randn(Cout, generator=g)
+    want = _ref(img, w, bias, 1, x2=pts, x1_gather=pick)
+    got = ops_pm.mlp(img, w, bias, 1, x2=pts, x1_gather=pick, tile_hint=hint)
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_kernel_forms_are_bit_identical_on_the_emulator(emu):
+    """DESIGN 4a' / 4a'': stream form and LDS-tiled form feed every accumulator the same products in the same k order as the
+    tile kernels -- equal bits (the emulated MFMA is deterministic, so any difference would be one of operand order)"""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 300, 128, generator=g)
+    w = torch.randn(96, 128, generator=g) / 11
+    bias = torch.randn(96, generator=g)
+    outs = [ops_pm.mlp(x, w, bias, 1, tile_hint=h) for h in (1, 2, 4, 6, 7)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("hint", [1, 2, 5, 6, 7])
+def test_mlp_pm_bf16_on_the_emulator(emu, hint):
+    """bf16 rows, fp32 accumulation (v_mfma_f32_32x32x16_bf16): against float64 on the bf16-rounded operands, bar = one bf16
+    rounding of the output"""
+    g = torch.Generator().manual_seed(hint)
+    BF = torch.bfloat16
+    x1 = torch.randn(2, 140, 64, generator=g).to(BF)
+    x2 = torch.randn(2, 140, 64, generator=g).to(BF)
+    w = (torch.randn(80, 128, generator=g) / 11).to(BF)
+    bias = torch.randn(80, generator=g)
+    gather = (torch.randn(2, 30, 80, generator=g).to(BF), torch.randint(0, 30, (2, 140), generator=g))
+    want = _ref(x1, w, bias, 2, x2=x2, gather=gather)
+    got = ops_pm.mlp(x1, w, bias, 2, x2=x2, gather=gather, tile_hint=hint)
+    assert got.dtype == BF
+    assert float((got.double() - want).abs().max()) <= 1e-2 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("B,N,C1,C2,idt", [(2, 50, 16, 16, torch.int64), (1, 37, 32, 32, torch.int32), (1, 20, 64, 64, torch.int64),
+                                           (3, 9, 8, 24, torch.int64)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_att_pool_pm_on_the_emulator(emu, B, N, C1, C2, idt, dt):
+    """Att_pooling.forward up to the pooled tensor (RandLANet.py:243-248) with the neighbour gather fused in: the softmax over
+    the 16 neighbours is in-lane arithmetic on the accumulator registers (slot permutation of csrc/mlp_pm.hip)"""
+    if dt == torch.bfloat16 and (C1 % 16 or C2 % 16):
+        pytest.skip("bf16 rows: 16-channel operands")
+    g = torch.Generator().manual_seed(N + C1)
+    f = torch.randn(B, N, C1, generator=g).to(dt)
+    nei = torch.randint(0, N, (B, N, 16), generator=g).to(idt)
+    gp = torch.randn(B, N, 16, C2, generator=g).to(dt)
+    d = C1 + C2
+    w = (torch.randn(d, d, generator=g) / d ** 0.5).to(dt)
+    got = ops_pm.att_pool(f, nei, gp, w)
+    fn = torch.gather(f.double().unsqueeze(1).expand(-1, N, -1, -1), 2, nei.long().unsqueeze(3).expand(-1, -1, -1, C1))   # [B,N,16,C1]
+    s = torch.cat([fn, gp.double()], dim=3)                                                                                 # feature set
+    want = (s * torch.softmax(s @ w.double().t(), dim=2)).sum(dim=2)
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max())
+
+
+def test_emulated_library_reports_argument_errors_like_the_product(emu):
+    x = torch.randn(1, 10, 12)                       # K = 12 is not a multiple of 8
+    w = torch.randn(8, 12)
+    with pytest.raises(_lib.FFB6DNativeError, match="multiples of 8"):
+        ops_pm.mlp(x, w)
+    assert ops.ACT_RELU == 1
