@@ -649,6 +649,23 @@ mlp_pm_lds_kernel(const PmParams p)
 
     struct Step { u32x4 w[4], x[4]; };                // one step of loads: 8 x 16 bytes per thread
     auto gload = [&](int s, Step& v) {
+        if constexpr (SZ == 2) {
+            const int seg = s * CB;
+            // bf16: branch-free (descriptor and offsets selected; a step past the last one reads at an out-of-range offset =
+            // zeros, never used).  hipcc counts outstanding loads only through straight-line code: behind the wave-uniform
+            // branches below it parks a step after s_waitcnt vmcnt(0), i.e. it also waits for the steps fetched after it.
+            // Harmless in fp32 (a step is ~4 us of MFMA per SIMD, longer than the memory latency), but a bf16 step is ~0.5 us
+            // and the prefetch would be one step deep instead of three.
+            const bool live = s < nstage, first = seg < kb1;
+            const __amdgpu_buffer_rsrc_t rx = first ? rs_x1 : rs_x2;
+            const int xseg = first ? seg : seg - kb1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, live ? w_off[i] : OOB, seg, 0);
+                v.x[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, live ? (first ? x1_off[i] : x2_off[i]) : OOB, xseg, 0);
+            }
+            return;
+        }
         if (s >= nstage) return;                      // prefetch past the last step
         const int seg = s * CB;
         if (seg < kb1) {

@@ -135,6 +135,22 @@ def test_mlp_pm_bf16_on_the_emulator(emu, hint):
     assert float((got.double() - want).abs().max()) <= 1e-2 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("K1,K2,cout,rows", [(256, 0, 72, 300), (128, 64, 130, 200), (64, 0, 128, 129), (1024, 0, 40, 64)])
+def test_lds_tiled_bf16_prefetch_past_the_last_step(emu, K1, K2, cout, rows):
+    """mlp_pm_lds_kernel<bf16> fetches three steps ahead with branch-free loads: steps past the last one read at an
+    out-of-range offset; one to sixteen steps, one or two sources, ragged rows and channels; also equal to the tile kernel"""
+    g = torch.Generator().manual_seed(K1 + cout)
+    BF = torch.bfloat16
+    x1 = torch.randn(1, rows, K1, generator=g).to(BF)
+    x2 = torch.randn(1, rows, K2, generator=g).to(BF) if K2 else None
+    w = (torch.randn(cout, K1 + K2, generator=g) / (K1 + K2) ** 0.5).to(BF)
+    bias = torch.randn(cout, generator=g)
+    want = _ref(x1, w, bias, 1, x2=x2)
+    got = ops_pm.mlp(x1, w, bias, 1, x2=x2, tile_hint=7)
+    assert float((got.double() - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    assert torch.equal(got, ops_pm.mlp(x1, w, bias, 1, x2=x2, tile_hint=1))
+
+
 @pytest.mark.parametrize("B,N,C1,C2,idt", [(2, 50, 16, 16, torch.int64), (1, 37, 32, 32, torch.int32), (1, 20, 64, 64, torch.int64),
                                            (3, 9, 8, 24, torch.int64)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
