@@ -1,5 +1,5 @@
-"""Builds tests/simt/libsimt_ffb6d.so: wave-level kernels of the product library (csrc/mlp_pm.hip: the point-major GEMM family
-and the fused attentive pooling) compiled for the HOST against the SIMT emulator (tests/simt/simt.*, fake/hip/hip_runtime.h).
+"""Builds tests/simt/libsimt_ffb6d.so: kernels of the product library (csrc/mlp_pm.hip: the point-major GEMM family and the fused
+attentive pooling; csrc/upconv.hip and csrc/posenc.hip with their launchers) compiled for the HOST against the SIMT emulator (tests/simt/simt.*, fake/hip/hip_runtime.h).
 The kernel sources are used as they are, except for mechanical substitutions made on a scratch copy:
   * the declaration of the dynamic shared array becomes a pointer to the emulator's buffer;
   * where a wave reads LDS data that OTHER lanes of the same wave wrote without any instruction in between that the emulator
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "ffb6d_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libsimt_ffb6d.so")
-KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip"]
+KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip", "upconv.hip", "posenc.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 # statements after which a wave relies on lock-step execution for LDS traffic between its lanes

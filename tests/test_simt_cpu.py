@@ -21,7 +21,7 @@ def emu(request):
     from tests.simt import build
     lib = ctypes.CDLL(build.build())
     for name in ("ffb6d_mlp_pm_f32", "ffb6d_mlp_pm_bf16", "ffb6d_att_pool_pm_f32", "ffb6d_att_pool_pm_bf16", "ffb6d_mlp_pm_choice",
-                 "ffb6d_mlp_pm_tile", "ffb6d_last_error"):
+                 "ffb6d_mlp_pm_tile", "ffb6d_last_error", "ffb6d_upconv_combine_pm", "ffb6d_posenc_mlp_pm"):
         res, args = _lib.SIGNATURES[name]
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
@@ -179,3 +179,42 @@ def test_emulated_library_reports_argument_errors_like_the_product(emu):
     with pytest.raises(_lib.FFB6DNativeError, match="multiples of 8"):
         ops_pm.mlp(x, w)
     assert ops.ACT_RELU == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launch paths of the per-thread kernels (csrc/upconv.hip, csrc/posenc.hip): grid arithmetic, XCD-band workgroup order and
+# kernel-form selection run here exactly as on the GPU (their bodies alone: tests/test_hostsim_cpu.py)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,cin,cout,h,w", [(2, 16, 8, 6, 8), (1, 8, 64, 3, 10), (3, 8, 12, 5, 7), (1, 8, 8, 1, 1)])
+def test_folded_up_block_through_the_real_launchers(emu, B, cin, cout, h, w):
+    """forward_pm.up_block in the folded form (z GEMM on the emulated MFMA kernel + upconv_combine through its launcher:
+    blocked form where the map is an exact x2 with OW % 4 == 0, one-pixel form elsewhere) against torch's modules"""
+    from ffb6d_amd import forward_pm, model
+    g = torch.Generator().manual_seed(cin + cout + h)
+    ub = model.UpBlock(cin, cout).eval()
+    with torch.no_grad():
+        for p in ub.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+        ub.conv[2].running_mean.copy_(torch.randn(cout, generator=g) * 0.1)
+        ub.conv[2].running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+        ub.conv[3].weight.fill_(0.3)
+    x = torch.randn(B, cin, h, w, generator=g)
+    with torch.no_grad():
+        want = ub.conv(x)
+        got = forward_pm.up_block(ub, x.permute(0, 2, 3, 1).contiguous())
+    assert got.shape == (B, 2 * h, 2 * w, cout)
+    assert float((got.permute(0, 3, 1, 2) - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("B,N,K,cout,dt", [(2, 40, 16, 16, torch.float32), (1, 33, 16, 128, torch.bfloat16), (3, 17, 5, 24, torch.float32)])
+def test_posenc_mlp_through_the_real_launcher(emu, B, N, K, cout, dt):
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(N + cout)
+    xyz = torch.randn(B, N, 3, generator=g)
+    idx = torch.randint(0, N, (B, N, K), generator=g)
+    w = torch.randn(cout, 10, generator=g) * 0.5
+    bias = torch.randn(cout, generator=g)
+    want = torch.relu(ops_ref.relative_pos_encoding(xyz, idx).double() @ w.double().t() + bias.double())
+    got = ops_pm.posenc_mlp(xyz, idx, w, bias, 1, dtype=dt)
+    assert got.shape == (B, N, K, cout) and got.dtype == dt
+    assert float((got.double() - want).abs().max()) <= (1e-5 if dt == torch.float32 else 1e-2) * float(want.abs().max())
