@@ -55,6 +55,11 @@ static inline unsigned __float_as_uint(float f) { return __builtin_bit_cast(unsi
 static inline void __syncthreads() { simt::block_sync(); }
 static inline int min(int a, int b) { return a < b ? a : b; }                 /* HIP's device-side overloads */
 static inline int max(int a, int b) { return a > b ? a : b; }
+/* round-to-nearest arithmetic that the compiler must not contract (this library is built with -ffp-contract=off) */
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fsub_rn(float a, float b) { return a - b; }
+static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fsqrt_rn(float a) { return sqrtf(a); }
 
 namespace simt {
 

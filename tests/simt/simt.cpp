@@ -2,12 +2,37 @@
 #include "simt.h"
 
 #include <sys/mman.h>
-#include <ucontext.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+// Context switch of the fibers: callee-saved registers + stack pointer (System V x86-64).  ucontext would do, but its
+// swapcontext makes a sigprocmask system call per switch and an emulated MFMA costs ~130 switches.
+extern "C" void simt_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl simt_switch
+    .type simt_switch,@function
+simt_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size simt_switch, .-simt_switch
+)");
 
 namespace simt {
 
@@ -19,12 +44,12 @@ constexpr size_t STACK = 512 << 10;
 constexpr int WAVE = 64;
 
 struct Wave { int live = 0, arrived = 0; unsigned gen = 0; alignas(16) unsigned char scratch[WAVE * 256]; };
-struct Fiber { ucontext_t ctx; bool done = false; int tid = 0; };
+struct Fiber { void* sp = nullptr; bool done = false; int tid = 0; };
 
 std::vector<Fiber> fibers;
 std::vector<Wave> waves;
 std::vector<unsigned char*> stacks;
-ucontext_t sched_ctx;
+void* sched_sp = nullptr;
 int cur = -1;
 int block_live = 0, block_arrived = 0;
 unsigned block_gen = 0;
@@ -40,7 +65,7 @@ void release_block_if_complete()
     if (block_live > 0 && block_arrived == block_live) { block_arrived = 0; ++block_gen; }
 }
 
-void yield() { swapcontext(&fibers[cur].ctx, &sched_ctx); }
+void yield() { simt_switch(&fibers[cur].sp, sched_sp); }
 
 void fiber_main()
 {
@@ -52,7 +77,8 @@ void fiber_main()
     --block_live;
     release_wave_if_complete(w);        // lanes that left no longer take part in rendezvous
     release_block_if_complete();
-    swapcontext(&f.ctx, &sched_ctx);
+    simt_switch(&f.sp, sched_sp);
+    abort();                            // a finished fiber is never resumed
 }
 
 }  // namespace
@@ -101,11 +127,13 @@ void run_grid(Dim3 grid, Dim3 block, size_t dyn_shared_bytes, const std::functio
                     Fiber& f = fibers[t];
                     f.tid = t;
                     ++waves[t / WAVE].live;
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = stacks[t];
-                    f.ctx.uc_stack.ss_size = STACK;
-                    f.ctx.uc_link = nullptr;
-                    makecontext(&f.ctx, fiber_main, 0);
+                    // initial frame: six callee-saved registers, the entry point simt_switch "returns" to, and a slot
+                    // that stands for the return address of a call (stack alignment at function entry)
+                    void** top = reinterpret_cast<void**>(stacks[t] + STACK);
+                    top[-1] = nullptr;
+                    top[-2] = reinterpret_cast<void*>(&fiber_main);
+                    for (int r = 3; r <= 8; ++r) top[-r] = nullptr;
+                    f.sp = top - 8;
                 }
                 int remaining = n;
                 while (remaining > 0) {
@@ -115,7 +143,7 @@ void run_grid(Dim3 grid, Dim3 block, size_t dyn_shared_bytes, const std::functio
                         cur = t;
                         g_block = Dim3(bx, by, bz);
                         g_thread = Dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-                        swapcontext(&sched_ctx, &fibers[t].ctx);
+                        simt_switch(&sched_sp, fibers[t].sp);
                         if (!fibers[t].done) ++remaining;
                     }
                 }
