@@ -46,12 +46,18 @@ enum { hipSuccess = 0 };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "simt"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 2; return hipSuccess; }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) simt::launch(kernel, grid, block, shmem, __VA_ARGS__)
 
 static inline float __uint_as_float(unsigned u) { return __builtin_bit_cast(float, u); }
 static inline unsigned __float_as_uint(float f) { return __builtin_bit_cast(unsigned, f); }
+static inline float __int_as_float(int i) { return __builtin_bit_cast(float, i); }
+static inline int __float_as_int(float f) { return __builtin_bit_cast(int, f); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int atomicAdd(int* p, int v) { const int old = *p; *p = old + v; return old; }   /* fibers never run concurrently */
+static inline float unsafeAtomicAdd(float* p, float v) { const float old = *p; *p = old + v; return old; }
 static inline void __syncthreads() { simt::block_sync(); }
 static inline int min(int a, int b) { return a < b ? a : b; }                 /* HIP's device-side overloads */
 static inline int max(int a, int b) { return a > b ? a : b; }
@@ -79,6 +85,38 @@ inline float shfl_xor(float v, int mask)
     const float r = s[(lane() ^ mask) & 63];
     wave_sync();
     return r;
+}
+
+// v_mov_b32_dpp with a row control (rows of 16 lanes): row_shl:n 0x100+n, row_shr:n 0x110+n, row_ror:n 0x120+n.
+// Lane i of a row receives lane i+n (shl), i-n (shr) or (i-n) mod 16 (ror) of the same row; a lane whose source falls off
+// the row keeps `old` (bound_ctrl = false) or gets 0 (true).  row_mask / bank_mask 0xf only.
+inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    int* s = scratch<int>();
+    const int l = lane();
+    s[l] = src;
+    wave_sync();
+    const int i = l & 15, n = ctrl & 15, kind = ctrl & 0x1f0;
+    int from = -1;
+    if (kind == 0x100) from = i + n;
+    else if (kind == 0x110) from = i - n;
+    else if (kind == 0x120) from = (i - n) & 15;
+    else { fprintf(stderr, "simt: DPP control 0x%x is not emulated\n", ctrl); abort(); }
+    if (row_mask != 0xf || bank_mask != 0xf) { fprintf(stderr, "simt: DPP row/bank masks are not emulated\n"); abort(); }
+    const int r = (from >= 0 && from < 16) ? s[(l & ~15) + from] : (bound_ctrl ? 0 : old);
+    wave_sync();
+    return r;
+}
+
+inline unsigned long long ballot(int pred)
+{
+    int* s = scratch<int>();
+    s[lane()] = pred ? 1 : 0;
+    wave_sync();
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) m |= (unsigned long long)(s[l] & 1) << l;
+    wave_sync();
+    return m;
 }
 
 inline f32x16_t mfma_32x32x2_f32(float a, float b, f32x16_t c)
@@ -160,3 +198,5 @@ typedef simt::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __shfl_xor(v, mask, width) simt::shfl_xor(v, mask)
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt::update_dpp(old, src, ctrl, rm, bm, bc)
+#define __ballot(p) simt::ballot(p)

@@ -270,3 +270,58 @@ def test_whole_fused_forward_on_the_emulator_matches_the_plain_torch_restatement
             assert float(err.max()) <= 1e-5 * scale, (k, float(err.max()) / scale)
         else:
             assert float(err.max()) <= 5e-2 * scale and float(err.mean()) <= 8e-3 * scale, (k, float(err.max()) / scale)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the drop-in boundary, executed: the UNMODIFIED reference model with our operators patched in
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.reference
+def test_reference_model_with_our_operators_patched_in_equals_the_reference(emu):
+    """patch.patch_reference on the reference's own FFB6D (ffb6d/models/ffb6d.py, RandLANet.py): random_sample,
+    nearest_interpolation, gather_neighbour, relative_pos_encoding and Att_pooling.forward become ffb6d_amd.ops (the
+    channel-major kernels of csrc/neighbour_ops.hip, run here on the emulator); everything else -- modules, weights, the
+    forward's control flow -- stays the reference's.  Same frame, same weights: the patched forward must reproduce the
+    unpatched one (gathers / max pooling exactly, the attentive pooling's softmax-sum to fp32 rounding)."""
+    import numpy as np
+    from ffb6d_amd import patch, synth
+    from oracle import knn as oknn
+    from oracle import pyramid as opyr
+    from oracle import ref_harness as rh
+    m_ffb6d, m_randla, _ = rh.reference_modules()
+    frames = synth.make_batch(7, 1, n_points=1024, height=120, width=160)
+    inputs = {"rgb": torch.from_numpy(frames["rgb"].astype(np.float32)), "cld_rgb_nrm": torch.from_numpy(frames["cld_rgb_nrm"]),
+              "choose": torch.from_numpy(frames["choose"].astype(np.int64))}
+    for k, v in opyr.build_batch(frames, oknn.knn_search).items():
+        inputs[k] = torch.from_numpy(v.astype(np.int64) if v.dtype == np.int32 else v)
+    ref_model = rh.build_reference_model(n_classes=5, n_pts=1024)
+    ref_model.load_state_dict(synth.synth_state_dict(ref_model, 0))
+    ref_model.eval()
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in ref_model(dict(inputs)).items()}
+    mp = pytest.MonkeyPatch()
+    mp.setattr(ops, "_need_gpu", lambda *ts: None)
+    mp.setattr(ops, "_stream", lambda t: None)
+    calls = {}
+    for name in ("ffb6d_random_sample_f32", "ffb6d_nearest_interpolation_f32", "ffb6d_gather_neighbour_f32",
+                 "ffb6d_relative_pos_encoding_f32", "ffb6d_att_pool_f32"):
+        def counted(*a, _fn=getattr(emu, name), _name=name):
+            calls[_name] = calls.get(_name, 0) + 1
+            return _fn(*a)
+        mp.setattr(emu, name, counted, raising=False)
+    undo = patch.patch_reference(m_ffb6d, m_randla)
+    try:
+        with torch.no_grad():
+            got = ref_model(dict(inputs))
+    finally:
+        undo()
+        mp.undo()
+    # the patched forward really went through the five native entry points (ffb6d.py:240-312, RandLANet.py:196-250):
+    # 4 + 7 max poolings (sub-sampling, r2p), 4 + 7 interpolations (decoder, p2r), 2 x 4 feature gathers, 4 encodings, 2 x 4 attentive poolings
+    assert calls == {"ffb6d_random_sample_f32": 11, "ffb6d_nearest_interpolation_f32": 11, "ffb6d_gather_neighbour_f32": 8,
+                     "ffb6d_relative_pos_encoding_f32": 4, "ffb6d_att_pool_f32": 8}, calls
+    assert sorted(got) == sorted(want)
+    for k in want:
+        scale = float(want[k].abs().max())
+        err = float((got[k] - want[k]).abs().max()) / scale
+        print(k, "patched reference vs reference: max err / range %.2e" % err)
+        assert err <= 1e-5, (k, err)
