@@ -15,18 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "ffb6d_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libsimt_ffb6d.so")
-KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip", "upconv.hip", "posenc.hip", "ops_pm.hip", "neighbour_ops.hip"]
+KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip", "upconv.hip", "posenc.hip", "ops_pm.hip", "neighbour_ops.hip", "knn.hip", "knn_pruned.hip", "knn_pick.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 # statements after which a wave relies on lock-step execution for LDS traffic between its lanes
 LOCKSTEP_AFTER = {"mlp_pm.hip": ["stream_epilogue<T, TM, LSM>(p, acc, img, OS, r0, l31, kh);"]}
-DYN_SHARED = re.compile(r"extern\s+__shared__\s+__attribute__\(\(aligned\(16\)\)\)\s+unsigned char\s+(\w+)\[\];")
+DYN_SHARED = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(16\)\)\)\s+)?((?:unsigned )?\w+)\s+(\w+)\[\];")
 
 
 def transformed(name):
     with open(os.path.join(CSRC, name)) as fh:
         src = fh.read()
-    src = DYN_SHARED.sub(r"unsigned char* \1 = simt::dyn_shared();", src)
+    src = DYN_SHARED.sub(r"\1* \2 = reinterpret_cast<\1*>(simt::dyn_shared());", src)
     for anchor in LOCKSTEP_AFTER.get(name, []):
         if src.count(anchor) != 1:
             raise RuntimeError(f"{name}: lock-step anchor not found exactly once: {anchor}")
@@ -39,7 +39,7 @@ def transformed(name):
 
 def build():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, f) for f in ("simt.cpp", "simt.h", "build.py")] + \
-        [os.path.join(HERE, "fake", "hip", "hip_runtime.h")]
+        [os.path.join(HERE, "fake", "hip", "hip_runtime.h"), os.path.join(HERE, "fake", "rocprim", "rocprim.hpp")]
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     os.makedirs(OUT, exist_ok=True)

@@ -46,16 +46,30 @@ enum { hipSuccess = 0 };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "simt"; }
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s_, size_t n, hipMemcpyKind) { memcpy(d, s_, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s_, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+#define HIP_SYMBOL(x) (&(x))
+static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n) { memcpy(sym, src, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 2; return hipSuccess; }
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) simt::launch(kernel, grid, block, shmem, __VA_ARGS__)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) simt::launch(#kernel, kernel, grid, block, shmem, __VA_ARGS__)
 
 static inline float __uint_as_float(unsigned u) { return __builtin_bit_cast(float, u); }
 static inline unsigned __float_as_uint(float f) { return __builtin_bit_cast(unsigned, f); }
 static inline float __int_as_float(int i) { return __builtin_bit_cast(float, i); }
 static inline int __float_as_int(float f) { return __builtin_bit_cast(int, f); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long old = *p; *p = old + v; return old; }
 static inline int atomicAdd(int* p, int v) { const int old = *p; *p = old + v; return old; }   /* fibers never run concurrently */
 static inline float unsafeAtomicAdd(float* p, float v) { const float old = *p; *p = old + v; return old; }
 static inline void __syncthreads() { simt::block_sync(); }
@@ -77,15 +91,20 @@ struct Rsrc { unsigned char* base; unsigned size; };
 
 template <typename V> inline V* scratch() { return static_cast<V*>(wave_scratch()); }
 
-inline float shfl_xor(float v, int mask)
+// __shfl_xor: value of lane l ^ mask; overloaded like HIP's (an int must not travel as a float)
+inline unsigned long long shfl_xor(unsigned long long v, int mask)
 {
-    float* s = scratch<float>();
+    unsigned long long* s = scratch<unsigned long long>();
     s[lane()] = v;
     wave_sync();
-    const float r = s[(lane() ^ mask) & 63];
+    const unsigned long long r = s[(lane() ^ mask) & 63];
     wave_sync();
     return r;
 }
+inline long long shfl_xor(long long v, int mask) { return (long long)shfl_xor((unsigned long long)v, mask); }
+inline int shfl_xor(int v, int mask) { return (int)shfl_xor((unsigned long long)(unsigned)v, mask); }
+inline unsigned shfl_xor(unsigned v, int mask) { return (unsigned)shfl_xor((unsigned long long)v, mask); }
+inline float shfl_xor(float v, int mask) { return __builtin_bit_cast(float, shfl_xor(__builtin_bit_cast(unsigned, v), mask)); }
 
 // v_mov_b32_dpp with a row control (rows of 16 lanes): row_shl:n 0x100+n, row_shr:n 0x110+n, row_ror:n 0x120+n.
 // Lane i of a row receives lane i+n (shl), i-n (shr) or (i-n) mod 16 (ror) of the same row; a lane whose source falls off
@@ -108,16 +127,43 @@ inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, b
     return r;
 }
 
+// lanes [base, base + width) meet; with a 16-lane rendezvous the other rows' bits read as 0
 inline unsigned long long ballot(int pred)
 {
     int* s = scratch<int>();
     s[lane()] = pred ? 1 : 0;
     wave_sync();
+    const int base = lane() & ~(width() - 1);
     unsigned long long m = 0;
-    for (int l = 0; l < 64; ++l) m |= (unsigned long long)(s[l] & 1) << l;
+    for (int l = base; l < base + width(); ++l) m |= (unsigned long long)(s[l] & 1) << l;
     wave_sync();
     return m;
 }
+
+// __shfl(v, src, w): value of lane (l & ~(w-1)) + src % w
+inline int shfl(int v, int src, int w)
+{
+    int* s = scratch<int>();
+    const int l = lane();
+    s[l] = v;
+    wave_sync();
+    const int r = s[(l & ~(w - 1)) + (src & (w - 1))];
+    wave_sync();
+    return r;
+}
+// __shfl_up(v, d, w): value of lane l - d of the same w-wide group; lanes whose source falls off keep their own value
+inline int shfl_up(int v, int d, int w)
+{
+    int* s = scratch<int>();
+    const int l = lane();
+    s[l] = v;
+    wave_sync();
+    const int r = ((l & (w - 1)) >= d) ? s[l - d] : v;
+    wave_sync();
+    return r;
+}
+inline float shfl(float v, int src, int w) { return __builtin_bit_cast(float, shfl(__builtin_bit_cast(int, v), src, w)); }
+inline unsigned shfl(unsigned v, int src, int w) { return (unsigned)shfl((int)v, src, w); }
 
 inline f32x16_t mfma_32x32x2_f32(float a, float b, f32x16_t c)
 {
@@ -200,3 +246,10 @@ typedef simt::Rsrc __amdgpu_buffer_rsrc_t;
 #define __shfl_xor(v, mask, width) simt::shfl_xor(v, mask)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt::update_dpp(old, src, ctrl, rm, bm, bc)
 #define __ballot(p) simt::ballot(p)
+#define __any(p) (simt::ballot(p) != 0)
+#define __shfl(v, src, w) simt::shfl(v, src, w)
+#define __shfl_up(v, d, w) simt::shfl_up(v, d, w)
+#define __threadfence_block() ((void)0)
+#define __builtin_amdgcn_readlane(v, l) simt::shfl((int)(v), l, 64)
+#define __builtin_amdgcn_wave_barrier() simt::wave_sync()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)

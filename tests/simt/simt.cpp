@@ -41,9 +41,9 @@ Dim3 g_thread, g_block, g_grid, g_bdim;
 namespace {
 
 constexpr size_t STACK = 512 << 10;
-constexpr int WAVE = 64;
+int WAVE = 64;                           // rendezvous width of the running launch (64 or 16)
 
-struct Wave { int live = 0, arrived = 0; unsigned gen = 0; alignas(16) unsigned char scratch[WAVE * 256]; };
+struct Wave { int live = 0, arrived = 0; unsigned gen = 0; alignas(16) unsigned char scratch[64 * 256]; };
 struct Fiber { void* sp = nullptr; bool done = false; int tid = 0; };
 
 std::vector<Fiber> fibers;
@@ -83,7 +83,8 @@ void fiber_main()
 
 }  // namespace
 
-int lane() { return fibers[cur].tid % WAVE; }
+int lane() { return fibers[cur].tid % 64; }      // lane of the 64-wide wavefront, whatever the rendezvous width
+int width() { return WAVE; }
 unsigned char* dyn_shared() { return shared_mem; }
 void* wave_scratch() { return waves[fibers[cur].tid / WAVE].scratch; }
 
@@ -104,8 +105,9 @@ void block_sync()
     while (block_gen == gen) yield();
 }
 
-void run_grid(Dim3 grid, Dim3 block, size_t dyn_shared_bytes, const std::function<void()>& thread_body)
+void run_grid(Dim3 grid, Dim3 block, size_t dyn_shared_bytes, const std::function<void()>& thread_body, int width)
 {
+    WAVE = width;
     const int n = (int)(block.x * block.y * block.z);
     if (dyn_shared_bytes > sizeof(shared_mem)) { fprintf(stderr, "simt: %zu bytes of shared memory requested\n", dyn_shared_bytes); abort(); }
     while ((int)stacks.size() < n) {

@@ -325,3 +325,88 @@ def test_reference_model_with_our_operators_patched_in_equals_the_reference(emu)
         err = float((got[k] - want[k]).abs().max()) / scale
         print(k, "patched reference vs reference: max err / range %.2e" % err)
         assert err <= 1e-5, (k, err)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# exact KNN (the reference's C ABI knn_.h:4-27) on the emulator: Morton preparation, tile-pruned row search
+# (one DPP row per query: 16-lane rendezvous), K = 1 pruned search, LDS scan, distance pick -- bit-exact indices
+# ---------------------------------------------------------------------------------------------------------------
+def test_knn_through_the_reference_c_abi_on_the_emulator_matches_the_reference_goldens(emu):
+    """tests/golden/knn_small.npz = output of the reference's own nanoflann build (knn_.cxx:104-135): every case through
+    cpp_knn_batch[_omp] with host pointers (what knn.pyx binds), executed by the emulated kernels"""
+    import numpy as np
+    from conftest import GOLDEN
+    from ffb6d_amd import nearest_neighbors as nn
+    from oracle import knn as oknn
+    z = np.load(os.path.join(GOLDEN, "knn_small.npz"))
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        sup, qry, K, want = z[name + "/support"], z[name + "/query"], int(z[name + "/K"]), z[name + "/idx"]
+        for omp in (False, True):
+            got = nn.knn_batch(sup, qry, K, omp=omp)
+            assert got.dtype == np.int64
+            np.testing.assert_array_equal(got, want, err_msg=name)         # the golden cases are tie-free
+    one = nn.knn(z["self_k16/support"][0], z["self_k16/query"][0][:100], 16)
+    np.testing.assert_array_equal(one, z["self_k16/idx"][0][:100])
+
+
+@pytest.mark.parametrize("B,S,Q,K", [(1, 3000, 500, 16), (2, 2500, 700, 1), (1, 5000, 300, 5), (1, 100, 50, 16), (2, 4000, 4000, 2)])
+def test_knn_kernels_on_the_emulator_are_bit_exact_against_the_oracle(emu, B, S, Q, K):
+    """pruned searches (S >= 2048: row kernel for 2 <= K <= 16, lane-per-query kernel for K = 1) and the LDS scan, incl. a
+    cloud with duplicated points and (0,0,0) pixels (the ties of linemod_dataset.py:198, 276-277: lowest index wins)"""
+    import numpy as np
+    from ffb6d_amd import nearest_neighbors as nn
+    from oracle import knn as oknn
+    g = np.random.default_rng(S + K)
+    sup = g.standard_normal((B, S, 3)).astype(np.float32)
+    sup[:, S // 2:S // 2 + 40] = sup[:, :40]                 # duplicates
+    sup[:, -25:] = 0.0                                       # invalid-depth pixels
+    qry = g.standard_normal((B, Q, 3)).astype(np.float32)
+    qry[:, :10] = sup[:, :10]
+    np.testing.assert_array_equal(nn.knn_batch(sup, qry, K, omp=True), oknn.knn_batch(sup, qry, K))
+
+
+@pytest.mark.reference
+def test_knn_on_the_emulator_equals_the_reference_nanoflann(emu):
+    """the reference's knn_.cxx + nanoflann compiled in place (oracle/_ref) on the same clouds, tie runs canonicalised"""
+    import numpy as np
+    from ffb6d_amd import nearest_neighbors as nn
+    from oracle import knn as oknn
+    from oracle import ref_harness as rh
+    g = np.random.default_rng(3)
+    sup = g.standard_normal((2, 3500, 3)).astype(np.float32)
+    qry = g.standard_normal((2, 900, 3)).astype(np.float32)
+    for K in (1, 16):
+        got, want = nn.knn_batch(sup, qry, K, omp=True), rh.ref_knn_batch(sup, qry, K, omp=True)
+        for b in range(sup.shape[0]):
+            np.testing.assert_array_equal(oknn.canonical_ties(got[b], sup[b], qry[b])[0], oknn.canonical_ties(want[b], sup[b], qry[b])[0])
+
+
+def test_distance_pick_on_the_emulator_matches_the_reference_goldens(emu, monkeypatch):
+    """cpp_knn_batch_distance_pick (knn_.h:21-27, knn_.cxx:138-271; std::mt19937 restated in the kernel): the reference's own
+    output with the clock pinned (tests/golden/knn_pick_small.npz)"""
+    import numpy as np
+    from conftest import GOLDEN
+    from ffb6d_amd import nearest_neighbors as nn
+    z = np.load(os.path.join(GOLDEN, "knn_pick_small.npz"))
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        pts, K, seed = z[name + "/pts"], int(z[name + "/K"]), int(z[name + "/seed"])
+        monkeypatch.setenv("FFB6D_KNN_PICK_SEED", str(seed))
+        idx, q = nn.knn_batch_distance_pick(pts, z[name + "/idx"].shape[1], K)
+        np.testing.assert_array_equal(idx, z[name + "/idx"], err_msg=name)
+        np.testing.assert_array_equal(q, z[name + "/queries"], err_msg=name)
+
+
+def test_index_pyramid_of_a_frame_on_the_emulator_equals_the_oracle(emu):
+    """the 22 searches of a frame (linemod_dataset.py:299-353; 120x160 image, 1024 points) through our helper_tool mirror
+    (DataProcessing.knn_search -> cpp_knn_batch_omp) -- all 26 index tensors and 4 xyz levels equal the CPU oracle's"""
+    import numpy as np
+    from ffb6d_amd import synth
+    from ffb6d_amd.helper_tool import DataProcessing
+    from oracle import knn as oknn
+    from oracle import pyramid as opyr
+    frames = synth.make_batch(3, 2, n_points=1024, height=120, width=160)
+    got = opyr.build_batch(frames, DataProcessing.knn_search)
+    want = opyr.build_batch(frames, oknn.knn_search)
+    assert sorted(got) == sorted(want) and len(want) == 30           # 26 index tensors + 4 xyz levels
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
