@@ -40,3 +40,40 @@ def device():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no ROCm device is visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def emu(request):
+    """The package bound to the SIMT-emulated library (tests/simt: the product's kernel sources compiled for the host and run
+    by a fiber-per-thread emulator), with the GPU guards of the host wrappers lifted so that CPU tensors reach the kernels:
+    `_need_gpu` / `_stream` of the wrapper modules, `Tensor.is_cuda` (inline checks), and the handful of torch.cuda calls the
+    wrappers make (device context, current stream).  Everything is undone when the module's tests are over."""
+    import contextlib
+    import ctypes
+
+    import torch
+
+    from ffb6d_amd import _lib, ops, ops_pm, pose
+    from tests.simt import build
+    lib = ctypes.CDLL(build.build())
+    for name, (res, args) in _lib.SIGNATURES.items():        # every entry point the emulated sources export
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    mp = pytest.MonkeyPatch()
+    mp.setattr(_lib, "_LIB", lib)
+    for mod in (ops, ops_pm, pose):
+        mp.setattr(mod, "_need_gpu", lambda *ts: None)
+        mp.setattr(mod, "_stream", lambda t: None)
+    mp.setattr(torch.cuda, "device", lambda dev: contextlib.nullcontext())
+
+    class OneStream:                                         # forward_pm.forward(two_streams=False) only enters it
+        cuda_stream = None
+    one_stream = OneStream()
+    mp.setattr(torch.cuda, "current_stream", lambda dev=None: one_stream)
+    mp.setattr(torch.cuda, "current_device", lambda: 0)
+    mp.setattr(torch.cuda, "stream", lambda st: contextlib.nullcontext())
+    mp.setattr(torch.cuda, "synchronize", lambda dev=None: None)
+    mp.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+    request.addfinalizer(mp.undo)
+    return lib

@@ -1,7 +1,8 @@
 """Builds tests/simt/libsimt_ffb6d.so: kernels of the product library (csrc/mlp_pm.hip: the point-major GEMM family and the fused
 attentive pooling; csrc/upconv.hip and csrc/posenc.hip with their launchers) compiled for the HOST against the SIMT emulator (tests/simt/simt.*, fake/hip/hip_runtime.h).
 The kernel sources are used as they are, except for mechanical substitutions made on a scratch copy:
-  * the declaration of the dynamic shared array becomes a pointer to the emulator's buffer;
+  * the declaration of the dynamic shared array becomes a pointer to the emulator's buffer; `kernel<<<...>>>(...)` launches are
+    rewritten into the hipLaunchKernelGGL macro (which the fake runtime maps to the emulator);
   * where a wave reads LDS data that OTHER lanes of the same wave wrote without any instruction in between that the emulator
     treats as a rendezvous (hardware runs a wave in lock step, fibers do not), a `simt::wave_sync()` is inserted: one place,
     between the epilogue of mlp_pm_stream_kernel (lanes deposit result rows in the wave's LDS image) and the whole-row stores.
@@ -15,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "ffb6d_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libsimt_ffb6d.so")
-KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip", "upconv.hip", "posenc.hip", "ops_pm.hip", "neighbour_ops.hip", "knn.hip", "knn_pruned.hip", "knn_pick.hip"]
+KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip", "upconv.hip", "posenc.hip", "ops_pm.hip", "neighbour_ops.hip", "knn.hip", "knn_pruned.hip", "knn_pick.hip", "pose.hip", "inputs.hip", "holefill.hip", "resize.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 # statements after which a wave relies on lock-step execution for LDS traffic between its lanes
@@ -23,9 +24,57 @@ LOCKSTEP_AFTER = {"mlp_pm.hip": ["stream_epilogue<T, TM, LSM>(p, acc, img, OS, r
 DYN_SHARED = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(16\)\)\)\s+)?((?:unsigned )?\w+)\s+(\w+)\[\];")
 
 
+def _split_top(text):
+    parts, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    parts.append(cur.strip())
+    return parts
+
+
+def chevrons_to_launch_macro(src):
+    """kernel<T><<<grid, block, shmem, stream>>>(args)  ->  hipLaunchKernelGGL((kernel<T>), dim3(grid), dim3(block), shmem, stream, args)"""
+    out, pos = "", 0
+    while True:
+        i = src.find("<<<", pos)
+        if i < 0:
+            return out + src[pos:]
+        j = src.index(">>>", i)
+        k = i                                    # kernel expression: identifier [+ one template argument list] before <<<
+        if src[k - 1] == ">":
+            depth = 0
+            while True:
+                k -= 1
+                depth += {">": 1, "<": -1}.get(src[k], 0)
+                if depth == 0:
+                    break
+        while k > 0 and (src[k - 1].isalnum() or src[k - 1] in "_:"):
+            k -= 1
+        cfg = _split_top(src[i + 3:j]) + ["0", "0"]
+        a = src.index("(", j)
+        depth, e = 0, a
+        while True:
+            depth += {"(": 1, ")": -1}.get(src[e], 0)
+            if depth == 0:
+                break
+            e += 1
+        out += src[pos:k] + "hipLaunchKernelGGL((%s), dim3(%s), dim3(%s), %s, %s, %s)" % (
+            src[k:i], cfg[0], cfg[1], cfg[2], cfg[3], src[a + 1:e])
+        pos = e + 1
+
+
 def transformed(name):
     with open(os.path.join(CSRC, name)) as fh:
         src = fh.read()
+    src = chevrons_to_launch_macro(src)
     src = DYN_SHARED.sub(r"\1* \2 = reinterpret_cast<\1*>(simt::dyn_shared());", src)
     for anchor in LOCKSTEP_AFTER.get(name, []):
         if src.count(anchor) != 1:

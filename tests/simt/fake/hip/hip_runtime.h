@@ -69,6 +69,10 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+template <typename T> static inline T atomicMax(T* p, T v) { const T old = *p; if (v > old) *p = v; return old; }
+template <typename T> static inline T atomicMin(T* p, T v) { const T old = *p; if (v < old) *p = v; return old; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned old = *p; *p = old + v; return old; }
+static inline float atomicAdd(float* p, float v) { const float old = *p; *p = old + v; return old; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long old = *p; *p = old + v; return old; }
 static inline int atomicAdd(int* p, int v) { const int old = *p; *p = old + v; return old; }   /* fibers never run concurrently */
 static inline float unsafeAtomicAdd(float* p, float v) { const float old = *p; *p = old + v; return old; }
@@ -243,7 +247,7 @@ typedef simt::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_sched_barrier(x) simt::wave_sync()
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-#define __shfl_xor(v, mask, width) simt::shfl_xor(v, mask)
+#define __shfl_xor(v, mask, ...) simt::shfl_xor(v, mask)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt::update_dpp(old, src, ctrl, rm, bm, bc)
 #define __ballot(p) simt::ballot(p)
 #define __any(p) (simt::ballot(p) != 0)

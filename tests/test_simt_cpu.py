@@ -3,8 +3,6 @@ rendezvous at MFMA / shuffle / barrier / buffer instructions): the point-major G
 forms (tile kernels, K-split, stream form, LDS-tiled form; fp32 and bf16) and the fused attentive pooling, driven through the
 package's own host wrappers (ffb6d_amd/ops_pm.py: argument marshalling, strides, per-frame gather bookkeeping) and checked
 against float64.  The same cases run on the GPU in tests/test_pm_gpu.py; here they need no GPU."""
-import contextlib
-import ctypes
 import os
 
 import pytest
@@ -13,29 +11,6 @@ import torch
 from ffb6d_amd import _lib, ops, ops_pm
 
 pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs ROCm's clang++ to build the emulated library")
-
-
-@pytest.fixture(scope="module")
-def emu(request):
-    """ops_pm.mlp / ops_pm.att_pool bound to the emulated library, with the GPU guards of the wrappers lifted"""
-    from tests.simt import build
-    lib = ctypes.CDLL(build.build())
-    for name, (res, args) in _lib.SIGNATURES.items():        # every entry point the emulated sources export
-        if hasattr(lib, name):
-            fn = getattr(lib, name)
-            fn.restype, fn.argtypes = res, args
-    mp = pytest.MonkeyPatch()
-    mp.setattr(_lib, "_LIB", lib)
-    mp.setattr(ops_pm, "_need_gpu", lambda *ts: None)
-    mp.setattr(ops_pm, "_stream", lambda t: None)
-    mp.setattr(torch.cuda, "device", lambda dev: contextlib.nullcontext())
-    # one stream: forward_pm.forward(two_streams=False) only asks for the current stream and enters it
-    one_stream = object()
-    mp.setattr(torch.cuda, "current_stream", lambda dev=None: one_stream)
-    mp.setattr(torch.cuda, "stream", lambda st: contextlib.nullcontext())
-    mp.setattr(torch.cuda, "synchronize", lambda dev=None: None)
-    request.addfinalizer(mp.undo)
-    return lib
 
 
 def _ref(x1, w, bias, act, x2=None, add=None, gather=None, x1_gather=None):
