@@ -187,6 +187,52 @@ affine_act_pm_kernel(const void* __restrict__ x, const float* __restrict__ scale
 }
 
 // ------------------------------------------------------------------------------------------------
+// stem of the colour branch (extractors.py: conv1 -> bn1 -> relu -> MaxPool2d(3, 2, 1), ffb6d.py:222): BatchNorm + ReLU + the
+// 3x3 / stride-2 max pooling in ONE pass over the convolution's output -- the normalised map (157 MB at bs=8) is never written:
+//     out[b, oy, ox, :] = max over the window's pixels INSIDE the map of relu(scale * x + shift)
+// (torch pads with -inf, i.e. ignores the outside; NaN propagates like ATen's max_pool2d).  blockIdx.y = output row (b, oy),
+// thread = (output column, 16-byte unit); every input pixel is read by up to four windows, out of L1 / L2.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(BLK)
+affine_relu_maxpool_pm_kernel(const void* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                              void* __restrict__ out, int IH, int IW, int OH, int OW, int q)
+{
+    using U = Unit<T>;
+    const int row = blockIdx.y;                  // b * OH + oy
+    const int oy = row % OH, b = row / OH;
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    if (t >= OW * q) return;
+    const int ox = t / q, c = t - ox * q;
+    float s[U::VL], sh[U::VL];
+    load_params<U::VL>(scale, c, s);
+    load_params<U::VL>(shift, c, sh);
+    float m[U::VL];
+#pragma unroll
+    for (int e = 0; e < U::VL; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        if (iy < 0 || iy >= IH) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox + kx - 1;
+            if (ix < 0 || ix >= IW) continue;
+            const U v = U::load(x, (((size_t)b * IH + iy) * IW + ix) * q + c);
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) {
+                const float a = v.v[e] * s[e] + sh[e];
+                m[e] = max_nan(m[e], a > 0.f ? a : (a == a ? 0.f : a));   // relu; NaN stays NaN
+            }
+        }
+    }
+    U o;
+#pragma unroll
+    for (int e = 0; e < U::VL; ++e) o.v[e] = m[e];
+    o.store(out, (size_t)row * OW * q + t);
+}
+
+// ------------------------------------------------------------------------------------------------
 // bilinear resize of [B, IH, IW, C] -> [B, OH, OW, C]; lane = one 16-byte unit of one output pixel;
 // ATen's upsample_bilinear2d arithmetic (area_pixel_compute_source_index + the lambda blend), as csrc/resize.hip
 // ------------------------------------------------------------------------------------------------
@@ -446,6 +492,26 @@ int ffb6d_affine_act_pm(int dtype, const void* x, const float* scale, const floa
     DISPATCH_DT(dtype, T, {
         hipLaunchKernelGGL((affine_act_pm_kernel<T>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, as_stream(stream), x,
                            scale, shift, res, rscale, rshift, out, (int)(C / VL), total, sl);
+    })
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+int ffb6d_affine_relu_maxpool_pm(int dtype, const void* x, const float* scale, const float* shift, void* out, int64_t B, int64_t IH,
+                                 int64_t IW, int64_t C, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(dt_ok(dtype), "affine_relu_maxpool_pm: dtype must be 0 (f32) or 1 (bf16)");
+    const int VL = vl_of(dtype);
+    FFB6D_REQUIRE(B >= 0 && IH >= 1 && IW >= 1 && C >= VL && C % VL == 0, "affine_relu_maxpool_pm: bad shape");
+    if (B == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(x && scale && shift && out && al16(x) && al16(out) && al16(scale) && al16(shift),
+                  "affine_relu_maxpool_pm: null or unaligned pointer");
+    const int64_t OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;          // floor((I + 2 - 3) / 2) + 1
+    FFB6D_REQUIRE(B * OH < 65536 && IH < (1 << 24) && IW < (1 << 24), "affine_relu_maxpool_pm: too large (grid y = B * OH < 65536)");
+    const int q = (int)(C / VL);
+    DISPATCH_DT(dtype, T, {
+        hipLaunchKernelGGL((affine_relu_maxpool_pm_kernel<T>), dim3((unsigned)ceil_div(OW * (int64_t)q, BLK), (unsigned)(B * OH)),
+                           dim3(BLK), 0, as_stream(stream), x, scale, shift, out, (int)IH, (int)IW, (int)OH, (int)OW, q);
     })
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;

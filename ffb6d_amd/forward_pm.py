@@ -103,6 +103,8 @@ def fc_weight(att, dt=F32):
 # relative_pos_encoding + lfa.mlp1 as one vector-ALU pass (csrc/posenc.hip; default) instead of the padded encoding tensor +
 # a K = 16 GEMM (FFB6D_POSENC_FUSED=0, kept for A/B: profiles/r02_opt_in_forms_ab.json)
 POSENC_FUSED = __import__("os").environ.get("FFB6D_POSENC_FUSED", "1").strip() not in ("", "0")
+# BatchNorm + ReLU + MaxPool2d(3,2,1) of the colour stem as one kernel (FFB6D_STEM_FUSED=0: affine_act + torch's max pooling)
+STEM_FUSED = __import__("os").environ.get("FFB6D_STEM_FUSED", "1").strip() not in ("", "0")
 
 
 def building_block(bb, xyz, f_pc, nei):
@@ -397,8 +399,13 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
 
     # ---- stems ----
     rgb = inputs['rgb'].to(dt).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)   # [B,H,W,3] view
-    y = ops_pm.affine_act_(conv(rgb, net.cnn_pre_stages[0]), *ops.bn_fold(net.cnn_pre_stages[1]), act=ops.ACT_RELU)
-    rgb_emb = net.cnn_pre_stages[3](y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)                  # max pool, stays NHWC
+    pool = net.cnn_pre_stages[3]
+    if STEM_FUSED and (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False):
+        # BatchNorm + ReLU + max pooling in one pass: the normalised full-resolution map is never written
+        rgb_emb = ops_pm.affine_relu_maxpool(conv(rgb, net.cnn_pre_stages[0]), *ops.bn_fold(net.cnn_pre_stages[1]))
+    else:
+        y = ops_pm.affine_act_(conv(rgb, net.cnn_pre_stages[0]), *ops.bn_fold(net.cnn_pre_stages[1]), act=ops.ACT_RELU)
+        rgb_emb = pool(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)                                 # max pool, stays NHWC
     with on_side():
         raw = inputs['cld_rgb_nrm']                                                              # [B,9,N]
         x0 = torch.zeros(raw.shape[0], raw.shape[2], (raw.shape[1] + 15) // 16 * 16, dtype=dt, device=dev)

@@ -236,6 +236,23 @@ def affine_act_(x, scale, shift, act=ACT_NONE, slope=0.0, residual=None, res_aff
     return x
 
 
+def affine_relu_maxpool(x, scale, shift):
+    """BatchNorm (eval, folded to scale / shift) + ReLU + MaxPool2d(3, 2, 1) of the colour stem (extractors.py; ffb6d.py:222)
+    in one pass: x [B,H,W,C] -> [B,(H-1)//2+1,(W-1)//2+1,C]; the normalised full-resolution map is never written."""
+    _need_gpu(x)
+    lib = _lib.load()
+    xc = x.detach()
+    xc = xc if xc.is_contiguous() else xc.contiguous()
+    B, H, W, C = xc.shape
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
+    nbytes = x.element_size() * (xc.numel() + out.numel())
+    with torch.cuda.device(x.device), _lib.traced("affine_relu_maxpool_pm", nbytes, (C, H, W)):
+        rc = lib.ffb6d_affine_relu_maxpool_pm(_dt(xc), xc.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(), B, H, W, C,
+                                              _stream(xc))
+    _lib.check(rc, "ffb6d_affine_relu_maxpool_pm")
+    return out
+
+
 def bilinear_resize(x, size, align_corners):
     """x [B,IH,IW,C] -> [B,OH,OW,C], bilinear (pspnet.py:24-28 align_corners=False; :37-42 align_corners=True)."""
     _need_gpu(x)

@@ -201,6 +201,11 @@ int ffb6d_relative_pos_encoding_pm(int dtype, const float* xyz, const void* idx,
 int ffb6d_affine_act_pm(int dtype, const void* x, const float* scale, const float* shift, const void* res,
                         const float* rscale, const float* rshift, void* out, int64_t rows, int64_t C, int act, float slope,
                         ffb6d_stream_t stream);
+/* Stem of the colour branch in one pass (extractors.py conv1 -> bn1 -> relu -> MaxPool2d(3,2,1); ffb6d.py:222):
+ * out[b,oy,ox,:] = max over the 3x3 / stride-2 / pad-1 window (pixels inside the map) of relu(scale*x + shift);
+ * x [B,IH,IW,C] rows, out [B,(IH-1)/2+1,(IW-1)/2+1,C]; NaN propagates like torch.max_pool2d. */
+int ffb6d_affine_relu_maxpool_pm(int dtype, const void* x, const float* scale, const float* shift, void* out, int64_t B, int64_t IH,
+                                 int64_t IW, int64_t C, ffb6d_stream_t stream);
 /* Bilinear resize [B,IH,IW,C] -> [B,OH,OW,C] (ATen upsample_bilinear2d arithmetic; pspnet.py:24-28,37-42). */
 int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
                              int64_t C, int align_corners, ffb6d_stream_t stream);

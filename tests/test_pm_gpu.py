@@ -368,3 +368,19 @@ def test_fused_posenc_mlp_matches_encoding_then_fp64_matmul(device, B, N, K, cou
         assert got.shape == (B, N, K, cout) and got.dtype == dt
         err = float((got.double().cpu() - want).abs().max()) / float(want.abs().max())
         assert err <= (1e-5 if dt == torch.float32 else 1e-2), (act, err)
+
+
+@pytest.mark.parametrize("B,H,W,C,dt", [(8, 240, 320, 64, torch.float32), (2, 12, 16, 64, torch.float32), (1, 7, 9, 8, torch.float32),
+                                        (2, 60, 80, 64, torch.bfloat16)])
+def test_fused_stem_pass_matches_bn_relu_maxpool(device, B, H, W, C, dt):
+    """BatchNorm + ReLU + MaxPool2d(3, 2, 1) of the colour stem (ffb6d.py:222) in one kernel against torch on the same device"""
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, H, W, C, generator=g).to(dt).to(device)
+    scale, shift = (torch.rand(C, generator=g) + 0.5).to(device), torch.randn(C, generator=g).to(device)
+    want = torch.nn.functional.max_pool2d(torch.relu(x.float() * scale + shift).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    got = ops_pm.affine_relu_maxpool(x, scale, shift)
+    assert got.shape == want.shape and got.dtype == dt
+    if dt == torch.float32:
+        assert torch.equal(got, want)
+    else:
+        assert float((got.float() - want).abs().max()) <= 1e-2 * float(want.abs().max())

@@ -385,3 +385,24 @@ def test_index_pyramid_of_a_frame_on_the_emulator_equals_the_oracle(emu):
     assert sorted(got) == sorted(want) and len(want) == 30           # 26 index tensors + 4 xyz levels
     for k in want:
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+
+@pytest.mark.parametrize("B,H,W,C,dt", [(2, 12, 16, 64, torch.float32), (1, 7, 9, 8, torch.float32), (1, 1, 1, 16, torch.float32),
+                                        (2, 10, 6, 16, torch.bfloat16)])
+def test_fused_stem_pass_on_the_emulator(emu, B, H, W, C, dt):
+    """BatchNorm + ReLU + MaxPool2d(3, 2, 1) of the colour stem in one kernel against the torch modules (even and odd maps,
+    a NaN pixel: it reaches exactly the windows that contain it)"""
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, H, W, C, generator=g)
+    if H > 4:
+        x[0, 3, 2, 1] = float("nan")
+    x = x.to(dt)
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    want = torch.nn.functional.max_pool2d(torch.relu(x.float() * scale + shift).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    got = ops_pm.affine_relu_maxpool(x, scale, shift)
+    assert got.shape == want.shape and got.dtype == dt
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    if dt == torch.float32:
+        assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
+    else:
+        assert float((torch.nan_to_num(got.float()) - torch.nan_to_num(want)).abs().max()) <= 1e-2 * float(torch.nan_to_num(want).abs().max())
