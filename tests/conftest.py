@@ -11,6 +11,13 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--emulate", action="store_true", default=False,
+                     help="run the -m gpu tests WITHOUT a GPU: CPU tensors, the package bound to the SIMT-emulated library "
+                          "(tests/simt).  Functional pre-flight of the GPU suite; ~1e4 times slower than the device, so pick "
+                          "tests with -k (full-size frames take hours)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
@@ -34,9 +41,12 @@ def native_lib():
     return _lib.load()
 
 
-@pytest.fixture(scope="session")
-def device():
+@pytest.fixture(scope="module")
+def device(request):
     import torch
+    if request.config.getoption("--emulate"):
+        request.getfixturevalue("emu")          # binds the package to the emulated library for this module
+        return torch.device("cpu")
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no ROCm device is visible")
     return torch.device("cuda:0")
