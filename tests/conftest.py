@@ -77,10 +77,28 @@ def emu(request):
         mp.setattr(mod, "_stream", lambda t: None)
     mp.setattr(torch.cuda, "device", lambda dev: contextlib.nullcontext())
 
-    class OneStream:                                         # forward_pm.forward(two_streams=False) only enters it
-        cuda_stream = None
-    one_stream = OneStream()
+    class FakeStream:                                        # kernels run synchronously in program order: streams and
+        cuda_stream = None                                   # events only have to exist
+        def __init__(self, device=None, priority=0, **kw):
+            self.device = torch.device(device) if device is not None else torch.device("cpu")
+        def wait_stream(self, other): pass
+        def wait_event(self, event): pass
+        def synchronize(self): pass
+        def record_event(self, event=None): return event or FakeEvent()
+
+    class FakeEvent:
+        def __init__(self, enable_timing=False, **kw): pass
+        def record(self, stream=None): pass
+        def wait(self, stream=None): pass
+        def synchronize(self): pass
+        def query(self): return True
+        def elapsed_time(self, other): return 0.0
+
+    one_stream = FakeStream()
     mp.setattr(torch.cuda, "current_stream", lambda dev=None: one_stream)
+    mp.setattr(torch.cuda, "Stream", FakeStream)
+    mp.setattr(torch.cuda, "Event", FakeEvent)
+    mp.setattr(torch.Tensor, "record_stream", lambda self, stream: None, raising=False)
     mp.setattr(torch.cuda, "current_device", lambda: 0)
     mp.setattr(torch.cuda, "stream", lambda st: contextlib.nullcontext())
     mp.setattr(torch.cuda, "synchronize", lambda dev=None: None)
