@@ -31,24 +31,26 @@ upconv_combine_pm_kernel(const upconv::CombineArgs a)
 }
 
 // register-blocked form (exact x2 maps): by = (b, pair of output rows), bx * 256 + thread = (block of 4 output columns, unit)
-template <typename T, bool STATIC>
+template <typename T, int FORM>
 __global__ void __launch_bounds__(BLK)
 upconv_combine_block_pm_kernel(const upconv::CombineArgs a)
 {
     unsigned bx, by;
     if (!upconv::xcd_band_block(blockIdx.x, a.nbx, a.nby, bx, by, a.banded != 0)) return;
-    upconv::combine_block_body<T, STATIC>(a, (int)by, (int)(bx * BLK + threadIdx.x));
+    upconv::combine_block_body<T, FORM>(a, (int)by, (int)(bx * BLK + threadIdx.x));
 }
 
-// FFB6D_UPCONV_COMBINE = simple | select | static (A/B): one pixel per thread; 2 x 4 block with operand selects (the form
-// measured at 2.5 TB/s, profiles/r02_bench_default_run.json); the same block with the compile-time operand pattern wherever
-// a thread's positions follow it (default)
+// FFB6D_UPCONV_COMBINE = simple | select | static | row (A/B): one pixel per thread; 2 x 4 block with operand selects; the same
+// block with the compile-time operand pattern per tap (default: measured 2.2 - 2.7 TB/s, profiles/r02_upconv_blend_forms_ab.txt);
+// "row" = the pattern per filter row with the three taps' loads in flight together -- bit-identical on the host simulation,
+// but 346 registers (one wave per SIMD) and unmeasured: opt-in until a GPU says otherwise
 int combine_form()
 {
     static const int form = [] {
         const char* v = getenv("FFB6D_UPCONV_COMBINE");
         if (v && strcmp(v, "simple") == 0) return 0;
         if (v && strcmp(v, "select") == 0) return 1;
+        if (v && strcmp(v, "row") == 0) return 3;
         return 2;
     }();
     return form;
@@ -88,10 +90,12 @@ extern "C" int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* sh
         a.nbx = (unsigned)ceil_div(OW / 4 * (int64_t)a.q, BLK);
         a.nby = (unsigned)(B * OH / 2);
         const dim3 grid((unsigned)(8 * ceil_div((int64_t)a.nbx * a.nby, 8)));
-        if (form == 2)
-            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, true>), grid, dim3(BLK), 0, as_stream(stream), a);
+        if (form == 3)
+            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, 3>), grid, dim3(BLK), 0, as_stream(stream), a);
+        else if (form == 2)
+            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, 2>), grid, dim3(BLK), 0, as_stream(stream), a);
         else
-            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, false>), grid, dim3(BLK), 0, as_stream(stream), a);
+            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, 1>), grid, dim3(BLK), 0, as_stream(stream), a);
     } else {
         a.nbx = (unsigned)ceil_div(OW * (int64_t)a.q, BLK);
         a.nby = (unsigned)(B * OH);

@@ -30,8 +30,15 @@ extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shi
         const int threads = (int)((OW / 4 * a.q + 255) / 256 * 256);
         for (int rb = 0; rb < (int)(B * OH / 2); ++rb)
             for (int t = 0; t < threads; ++t) {
-                if (dtype == 1) { if (blocked == 2) combine_block_body<__bf16, true>(a, rb, t); else combine_block_body<__bf16, false>(a, rb, t); }
-                else { if (blocked == 2) combine_block_body<float, true>(a, rb, t); else combine_block_body<float, false>(a, rb, t); }
+                if (dtype == 1) {
+                    if (blocked == 3) combine_block_body<__bf16, 3>(a, rb, t);
+                    else if (blocked == 2) combine_block_body<__bf16, 2>(a, rb, t);
+                    else combine_block_body<__bf16, 1>(a, rb, t);
+                } else {
+                    if (blocked == 3) combine_block_body<float, 3>(a, rb, t);
+                    else if (blocked == 2) combine_block_body<float, 2>(a, rb, t);
+                    else combine_block_body<float, 1>(a, rb, t);
+                }
             }
         return 0;
     }
