@@ -109,7 +109,7 @@ MLP_KERNEL_NAMES = {"shared_mlp<128,frame>": "shared_mlp_pipe_kernel<128>", "sha
                     "mlp_pm<32x256>": "mlp_pm_kernel<1, 2, 1, 4, false>", "mlp_pm<64x64>": "mlp_pm_kernel<1, 1, 2, 2, false>",
                     "mlp_pm<64x32,ksplit>": "mlp_pm_kernel<2, 1, 2, 2, true>",
                     "mlp_pm<stream>": "mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>", "mlp_pm<lds128x128>": "mlp_pm_lds_kernel<T>",
-                    "att_pool_pm": "att_pool_pm_kernel<TM, TN>"}
+                    "att_pool_pm": "att_pool_pm_kernel<TM, TN>", "lfa_pm": "lfa_pm_kernel<T, D, MODE, P>"}
 PM_TILES = {1: "128x128", 2: "64x256", 3: "32x256", 4: "64x64", 5: "64x32,ksplit", 6: "stream", 7: "lds128x128"}
 
 
@@ -123,6 +123,8 @@ def gemm_flops(name, rec_tag, batch):
         return 2.0 * rec_tag[0] * rec_tag[0] * 16 * rec_tag[1] * batch     # (d, N): score GEMM d x d over 16 N pairs
     if name.startswith("att_score_pool"):
         return 2.0 * rec_tag[0] * rec_tag[0] * 16 * rec_tag[1] * batch
+    if name.startswith("lfa_pm"):
+        return float(rec_tag[4])                                           # (mode, d, N, dtype, flops): ops_pm.lfa_half
     return 0.0
 
 
@@ -409,7 +411,7 @@ def main():
         pyr_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["pyramid"]]))
         fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["forward"]]))
         def is_gemm(name):
-            return name.startswith(("shared_mlp", "mlp_pm", "att_pool_pm", "att_score_pool"))
+            return name.startswith(("shared_mlp", "mlp_pm", "att_pool_pm", "att_score_pool", "lfa_pm"))
 
         def mfma_bound(name):
             return is_gemm(name) and not name.endswith(",hbm>")
@@ -422,7 +424,7 @@ def main():
             if mfma_bound(op):
                 flops = sum(gemm_flops(op, t, args.batch) for _, _, _, t in tr.records[op])
                 ach = flops / sec / 1e12
-                peak = BF16_PEAK_TFLOPS if args.precision == "bf16" and op.startswith(("mlp_pm", "att_pool_pm")) else VALU_PEAK_TFLOPS
+                peak = BF16_PEAK_TFLOPS if args.precision == "bf16" and op.startswith(("mlp_pm", "att_pool_pm", "lfa_pm")) else VALU_PEAK_TFLOPS
                 return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                         "kernel": MLP_KERNEL_NAMES.get(op.replace(",mfma>", ">"), op) +
                         (" (bf16 MFMA 32x32x16)" if peak == BF16_PEAK_TFLOPS else " (fp32 MFMA 32x32x2)"),

@@ -107,9 +107,24 @@ POSENC_FUSED = __import__("os").environ.get("FFB6D_POSENC_FUSED", "1").strip() n
 STEM_FUSED = __import__("os").environ.get("FFB6D_STEM_FUSED", "1").strip() not in ("", "0")
 
 
+# One launch per half of the local feature aggregation (csrc/lfa_pm.hip; default): the per-pair tensors live in LDS only.
+# FFB6D_LFA_FUSED=0 keeps the round-2 chain posenc_mlp -> att_pool -> mlp (six launches, [B,N,16,d/2] through HBM) for A/B.
+LFA_FUSED = __import__("os").environ.get("FFB6D_LFA_FUSED", "1").strip() not in ("", "0")
+LFA_WIDTHS = (32, 64, 128, 256)
+
+
 def building_block(bb, xyz, f_pc, nei):
     """RandLANet.py:196-214 (Building_block.forward): f_pc [B,N,d/2] -> [B,N,d]."""
     dt = f_pc.dtype
+    if LFA_FUSED and 2 * f_pc.shape[-1] in LFA_WIDTHS and nei.shape[-1] == 16:
+        w1, b1 = folded(bb.mlp1)                                                   # fp32 [d/2, 10] in both precisions
+        a1, a2 = bb.att_pooling_1, bb.att_pooling_2
+        wm1, bm1 = folded(a1.mlp, dt=dt)
+        f_agg = ops_pm.lfa_half(1, xyz, nei, f_pc, w1, b1, bb.mlp1.act_code, fc_weight(a1, dt), wm1, bm1, a1.mlp.act_code)
+        w2, b2 = folded(bb.mlp2, dt=dt)
+        wm2, bm2 = folded(a2.mlp, dt=dt)
+        return ops_pm.lfa_half(2, xyz, nei, f_agg, w1, b1, bb.mlp1.act_code, fc_weight(a2, dt), wm2, bm2, a2.mlp.act_code,
+                               w2=w2, b2=b2, act2=bb.mlp2.act_code)
     if POSENC_FUSED:                                                               # encoding generated in registers
         w, b = folded(bb.mlp1)                                                     # fp32 [d/2, 10] in both precisions
         f_xyz = ops_pm.posenc_mlp(xyz, nei, w, b, bb.mlp1.act_code, dtype=dt)      # [B,N,16,d/2]

@@ -204,6 +204,80 @@ def test_att_pool_pm_matches_fp64_reference(device, B, N, C1, C2, dt):
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+def _lfa_case(B, N, d, mode, dt, idt, seed):
+    g = torch.Generator().manual_seed(seed)
+    h, cout = d // 2, (d // 2 if mode == 1 else d)
+    a = dict(xyz=torch.rand(B, N, 3, generator=g), nei=torch.randint(0, N, (B, N, 16), generator=g).to(idt),
+             f=torch.randn(B, N, h, generator=g).to(dt), w1=torch.randn(h, 10, generator=g) / 2, b1=torch.randn(h, generator=g) / 2,
+             wfc=(torch.randn(d, d, generator=g) / d ** 0.5 * 2).to(dt), wm=(torch.randn(cout, d, generator=g) / d ** 0.5).to(dt),
+             bm=torch.randn(cout, generator=g) / 2)
+    if mode == 2:
+        a.update(w2=(torch.randn(h, h, generator=g) / h ** 0.5).to(dt), b2=torch.randn(h, generator=g) / 2)
+    return a
+
+
+def _lfa_run(a, mode, device, p_hint=0):
+    kw = dict(w2=a["w2"].to(device), b2=a["b2"].to(device), act2=2) if mode == 2 else {}
+    return ops_pm.lfa_half(mode, a["xyz"].to(device), a["nei"].to(device), a["f"].to(device), a["w1"].to(device), a["b1"].to(device), 2,
+                           a["wfc"].to(device), a["wm"].to(device), a["bm"].to(device), 2, p_hint=p_hint, **kw)
+
+
+# (B, N, d, p_hint): the four widths of the network at (scaled-down) level shapes, ragged tails, groups straddling frames, both
+# group sizes; the last two are the real level-0 / level-3 shapes of BASELINE configuration 2
+LFA_CASES = [(2, 1000, 32, 1), (1, 777, 32, 2), (2, 771, 64, 0), (3, 193, 128, 1), (2, 190, 128, 2), (3, 47, 256, 1), (1, 50, 256, 2),
+             (8, 12288, 32, 0), (8, 192, 256, 0)]
+
+
+@pytest.mark.parametrize("B,N,d,p_hint", LFA_CASES)
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_lfa_half_matches_fp64_reference(device, B, N, d, p_hint, mode):
+    """Building_block.forward, RandLANet.py:196-214 -- one launch per half (csrc/lfa_pm.hip): neighbour gather + position encoding +
+    mlp1 (+ mlp2) + Att_pooling (fc, softmax over the 16 neighbours, weighted sum, mlp), pair rows in LDS only; against the
+    float64 restatement oracle/ops_ref.lfa_half, 1e-5 of the output range (the GEMM bar of this suite)"""
+    from oracle import ops_ref
+    idt = torch.int64 if (N + mode) % 2 else torch.int32
+    a = _lfa_case(B, N, d, mode, torch.float32, idt, seed=N + d + mode)
+    got = _lfa_run(a, mode, device, p_hint).cpu()
+    kw = dict(w2=a["w2"], b2=a["b2"], act2=2) if mode == 2 else {}
+    want = ops_ref.lfa_half(mode, a["xyz"], a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2, **kw)
+    err = float((got.double() - want).abs().max()) / float(want.abs().max())
+    assert got.shape == want.shape and err <= 1e-5, f"max err {err:.2e} of range"
+
+
+@pytest.mark.parametrize("B,N,d", [(2, 1000, 32), (2, 771, 64), (3, 193, 128), (3, 47, 256)])
+def test_fused_lfa_equals_the_unfused_chain(device, B, N, d):
+    """The fused halves against the round-2 chain of operators they replace (posenc_mlp -> att_pool -> mlp [-> mlp -> att_pool ->
+    mlp]), which has its own parity tests above: same arithmetic up to the summation order of the GEMMs"""
+    a = _lfa_case(B, N, d, 2, torch.float32, torch.int64, seed=d)
+    dev = {k: v.to(device) for k, v in a.items()}
+    g = torch.Generator().manual_seed(1)
+    wfc1 = (torch.randn(d, d, generator=g) / d ** 0.5 * 2).to(device)
+    wm1, bm1 = (torch.randn(d // 2, d, generator=g) / d ** 0.5).to(device), (torch.randn(d // 2, generator=g) / 2).to(device)
+    g1 = ops_pm.posenc_mlp(dev["xyz"], dev["nei"], dev["w1"], dev["b1"], 2)
+    agg = ops_pm.mlp(ops_pm.att_pool(dev["f"], dev["nei"], g1, wfc1), wm1, bm1, 2)
+    want = ops_pm.mlp(ops_pm.att_pool(agg, dev["nei"], ops_pm.mlp(g1, dev["w2"], dev["b2"], 2), dev["wfc"]), dev["wm"], dev["bm"], 2)
+    h1 = ops_pm.lfa_half(1, dev["xyz"], dev["nei"], dev["f"], dev["w1"], dev["b1"], 2, wfc1, wm1, bm1, 2)
+    got = ops_pm.lfa_half(2, dev["xyz"], dev["nei"], h1, dev["w1"], dev["b1"], 2, dev["wfc"], dev["wm"], dev["bm"], 2,
+                          w2=dev["w2"], b2=dev["b2"], act2=2)
+    assert float((h1 - agg).abs().max()) <= 1e-5 * float(agg.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("B,N,d", [(2, 1000, 32), (2, 192, 128), (1, 50, 256)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_lfa_half_bf16(device, B, N, d, mode):
+    """bf16 rows, fp32 accumulation: against float64 arithmetic on the same bf16 operands with the kernel's two store roundings
+    (pair rows, pooled rows) restated"""
+    from oracle import ops_ref
+    a = _lfa_case(B, N, d, mode, torch.bfloat16, torch.int64, seed=N + d + mode)
+    got = _lfa_run(a, mode, device).cpu()
+    kw = dict(w2=a["w2"], b2=a["b2"], act2=2) if mode == 2 else {}
+    want = ops_ref.lfa_half(mode, a["xyz"], a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2,
+                            store=lambda t: t.to(torch.bfloat16).to(torch.float64), **kw)
+    assert got.dtype == torch.bfloat16
+    assert float((got.double() - want).abs().max()) <= 2e-2 * float(want.abs().max())
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # bfloat16 rows (BASELINE.json configuration 5: mixed precision).  References are computed in float64 FROM THE SAME
 # bf16-rounded operands, so what is checked is the kernel (fp32 accumulation / arithmetic, one rounding at the store):

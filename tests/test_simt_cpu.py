@@ -152,6 +152,39 @@ def test_att_pool_pm_on_the_emulator(emu, B, N, C1, C2, idt, dt):
     assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max())
 
 
+def _lfa_case(B, N, d, mode, dt, idt, seed):
+    g = torch.Generator().manual_seed(seed)
+    h, cout = d // 2, (d // 2 if mode == 1 else d)
+    a = dict(xyz=torch.rand(B, N, 3, generator=g), nei=torch.randint(0, N, (B, N, 16), generator=g).to(idt),
+             f=torch.randn(B, N, h, generator=g).to(dt), w1=torch.randn(h, 10, generator=g) / 2, b1=torch.randn(h, generator=g) / 2,
+             wfc=(torch.randn(d, d, generator=g) / d ** 0.5 * 2).to(dt), wm=(torch.randn(cout, d, generator=g) / d ** 0.5).to(dt),
+             bm=torch.randn(cout, generator=g) / 2)
+    if mode == 2:
+        a.update(w2=(torch.randn(h, h, generator=g) / h ** 0.5).to(dt), b2=torch.randn(h, generator=g) / 2)
+    return a
+
+
+# one launch per half of the local feature aggregation (csrc/lfa_pm.hip): both halves, both group sizes of every width, both
+# index types, ragged tails (N not a multiple of the points per workgroup, groups that straddle two frames)
+@pytest.mark.parametrize("B,N,d,p_hint", [(2, 70, 32, 1), (1, 37, 32, 2), (2, 41, 64, 1), (1, 19, 64, 2), (2, 13, 128, 1), (1, 9, 128, 2),
+                                          (1, 7, 256, 1), (2, 3, 256, 2)])
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_lfa_half_on_the_emulator(emu, B, N, d, p_hint, mode, dt):
+    """Building_block.forward, RandLANet.py:196-214: gather + position encoding + mlp1 (+ mlp2) + attentive pooling + mlp in
+    one kernel, pair rows in LDS only -- against the float64 restatement (oracle/ops_ref.lfa_half)"""
+    from oracle import ops_ref
+    idt = torch.int64 if (N + mode) % 2 else torch.int32
+    a = _lfa_case(B, N, d, mode, dt, idt, seed=N + d + mode)
+    kw = dict(w2=a["w2"], b2=a["b2"], act2=2) if mode == 2 else {}
+    got = ops_pm.lfa_half(mode, a["xyz"], a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2, p_hint=p_hint, **kw)
+    store = None if dt == torch.float32 else (lambda t: t.to(torch.bfloat16).to(torch.float64))
+    want = ops_ref.lfa_half(mode, a["xyz"], a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2, store=store, **kw)
+    assert got.shape == want.shape and got.dtype == dt
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max())
+
+
 def test_emulated_library_reports_argument_errors_like_the_product(emu):
     x = torch.randn(1, 10, 12)                       # K = 12 is not a multiple of 8
     w = torch.randn(8, 12)
