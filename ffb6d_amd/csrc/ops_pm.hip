@@ -150,7 +150,7 @@ rel_pos_enc_pm_kernel(const float* __restrict__ xyz, const IdxT* __restrict__ id
 
 // ------------------------------------------------------------------------------------------------
 // per-channel affine + residual + activation on [rows, C]:
-//     out = act( scale[c]*x + shift[c] + (res ? rscale[c]*res + rshift[c] : 0) ),   act(v) = max(v, slope*v)
+//     out = act( scale[c]*x + shift[c] + (res ? rscale[c]*res + rshift[c] : 0) ),   act(v) = v > 0 ? v : slope*v
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(BLK)
@@ -182,7 +182,7 @@ affine_act_pm_kernel(const void* __restrict__ x, const float* __restrict__ scale
         }
     }
 #pragma unroll
-    for (int e = 0; e < U::VL; ++e) v.v[e] = fmaxf(v.v[e], slope * v.v[e]);
+    for (int e = 0; e < U::VL; ++e) v.v[e] = v.v[e] > 0.f ? v.v[e] : slope * v.v[e];     // exact PReLU for ANY learned slope (> 1, < 0)
     v.store(out, t);
 }
 

@@ -167,6 +167,10 @@ def test_colour_branch_glue_pm_matches_torch(device):
     want = torch.relu(x * sc + sh + res)
     got = ops_pm.affine_act_(d(x).clone(), d(sc), d(sh), ops.ACT_RELU, residual=d(res)).cpu()
     torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    for slope in (1.5, -0.3):          # a learned PReLU slope may leave [0, 1]: max(v, slope * v) would be wrong there
+        want = F.prelu(x * sc + sh, torch.tensor([slope]))
+        got = ops_pm.affine_act_(d(x).clone(), d(sc), d(sh), ops.ACT_LEAKY, slope).cpu()
+        torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
     for size, ac in (((24, 32), True), ((30, 41), False), ((12, 16), False)):
         want = F.interpolate(x.permute(0, 3, 1, 2), size=size, mode="bilinear", align_corners=ac).permute(0, 2, 3, 1)
         got = ops_pm.bilinear_resize(d(x), size, ac).cpu()
