@@ -16,8 +16,9 @@
 // indices.  Here a workgroup owns P consecutive points and builds their 16 P pair rows ONCE, in LDS:
 //
 //   * neighbour tiles staged in LDS: the gathered feature rows arrive as whole rows (consecutive lanes fetch consecutive 16-byte
-//     chunks of one row), the position-encoding half of a pair row is computed on the vector ALU (10-term FMA chain, the
-//     arithmetic of csrc/posenc_body.h) and -- half 2 -- pushed through lfa.mlp2 on the matrix cores; both land in one image
+//     chunks of one row), the position-encoding half of a pair row is generated in registers (the arithmetic of
+//     csrc/posenc_body.h), multiplied with lfa.mlp1 on the matrix cores (K = 10: five fp32 MFMAs, in both precisions) and
+//     -- half 2 -- pushed through lfa.mlp2 the same way; both land in one image
 //     [16 P rows][d] whose row order inside a 32-row tile is the slot order of att_pool_pm_kernel
 //         slot rho -> point (rho >> 2) & 1 of the tile, neighbour (rho & 3) + 4 * (rho >> 3),
 //     so that accumulator register r of lane l of the score GEMM is neighbour r of point (l >> 5), channel (l & 31): the softmax
@@ -32,6 +33,7 @@
 // Algorithmic bytes at the kernel's boundary: 12 B N (xyz) + idx + esz B N d/2 (point rows in) + esz B N cout (out) + weights.
 // Algorithmic flops: 2*16 B N d^2 (scores) + 2*16 B N 10 d/2 (mlp1) [+ 2*16 B N (d/2)^2 (mlp2)] + 2 B N d cout (output MLP).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "ffb6d_ops.h"
@@ -43,7 +45,7 @@ namespace {
 using namespace pm;
 
 struct LfaParams {
-    const float* xyz;     // [B * N, 3]
+    const float4* xyz4;   // [B, xfs] rows {x, y, z, -}: point n of frame b at b * xfs + n (xfs >= N: a level may be the prefix of a larger table)
     const void* nei;      // [B * N * 16] int32 / int64 neighbour indices inside the frame
     const void* f;        // [B * N, ldf] point rows of T, first d/2 elements used
     const float* w1;      // [d/2, ldw1] fp32 (BatchNorm folded), columns 0..9 used
@@ -51,55 +53,76 @@ struct LfaParams {
     const void* w2;       // MODE 2: [d/2, d/2] of T
     const float* b2;      // MODE 2: [d/2] fp32
     const void* wfc;      // [d, d] of T (no bias)
-    const void* wm;       // [cout, d] of T
+    const void* wm;       // [d / VL, cout, VL] of T: the output MLP's weight, k-chunked (VL = 16 bytes of consecutive k per channel)
     const float* bm;      // [cout] fp32
     void* out;            // [B * N, ldo] of T
-    int npts, N, ldf, ldo, ldw1, idx64;
+    int npts, N, ldf, ldo, ldw1, idx64, xfs;
     float slope1, slope2, slopem;      // act(v) = max(v, slope * v)
     int n_grp;            // point groups (workgroups with work)
 };
 
-template <typename T> __device__ __forceinline__ u32x4 pack_chunk(const float (&v)[16 / El<T>::SZ])
+// a 16-byte chunk of a row -> its VL values as fp32
+template <typename T> __device__ __forceinline__ void unpack_chunk(const u32x4 v, float (&o)[16 / El<T>::SZ])
 {
     if constexpr (El<T>::SZ == 4) {
-        return u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-    } else {
-        bf16x8 b;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) b[e] = (__bf16)v[e];        // round to nearest even
-        return __builtin_bit_cast(u32x4, b);
+        for (int e = 0; e < 4; ++e) o[e] = __uint_as_float(v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[2 * e] = __uint_as_float(v[e] << 16);
+            o[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+        }
     }
 }
 
-// acc[TA][TB] += A B over NSTEPS 32-byte steps; la(step, i) / lb(step, j) deliver the 16-byte fragment of this lane.  Three
-// register stages: the fragments of step s + 2 are requested before step s is multiplied (global fragments need the depth,
-// LDS fragments do not mind it); sched_barrier pins the order (hipcc otherwise sinks the loads below the MFMA groups).
-template <typename T, int NSTEPS, int TA, int TB, typename LA, typename LB>
-__device__ __forceinline__ void gemm_steps(f32x16 (&acc)[TA][TB], LA&& la, LB&& lb)
+// One GEMM phase of the kernel: acc[TA][TB] += A B over NSTEPS 32-byte steps, fragments through a ring of three register
+// stages (the fragments of step s + 2 are requested before step s is multiplied; sched_barrier pins the order -- hipcc
+// otherwise sinks the loads below the MFMA groups).  One operand comes from L2 (weights: the same for every group, so their
+// first two stages can be requested BEFORE the barrier that publishes the other operand), the other from the LDS images.
+// NSTEPS is a compile-time constant: the loop unrolls completely and the ring indices are static.
+template <int TA, int TB> struct Ring { u32x4 a[3][TA], b[3][TB]; };
+
+template <typename T, int NSTEPS, int TA, int TB, bool A_GLOBAL, typename LA, typename LB>
+__device__ __forceinline__ void gemm_early(Ring<TA, TB>& r, LA&& la, LB&& lb)
 {
-    u32x4 a0[TA], a1[TA], a2[TA], b0[TB], b1[TB], b2[TB];
-    auto load = [&](int s, u32x4 (&a)[TA], u32x4 (&b)[TB]) {
-        const int sc = s < NSTEPS ? s : NSTEPS - 1;             // surplus prefetch: re-read the last step (never used)
 #pragma unroll
-        for (int i = 0; i < TA; ++i) a[i] = la(sc, i);
+    for (int s = 0; s < 2 && s < NSTEPS; ++s) {
+        if constexpr (A_GLOBAL) {
 #pragma unroll
-        for (int j = 0; j < TB; ++j) b[j] = lb(sc, j);
-    };
-#define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
-    load(0, a0, b0);
-    load(1, a1, b1);
-    int st = 0;
-    for (; st + 3 <= NSTEPS; st += 3) {
-        load(st + 2, a2, b2);                  FFB6D_PIN();
-        mfma_step<T, TA, TB>(acc, a0, b0);     FFB6D_PIN();
-        load(st + 3, a0, b0);                  FFB6D_PIN();
-        mfma_step<T, TA, TB>(acc, a1, b1);     FFB6D_PIN();
-        load(st + 4, a1, b1);                  FFB6D_PIN();
-        mfma_step<T, TA, TB>(acc, a2, b2);     FFB6D_PIN();
+            for (int i = 0; i < TA; ++i) r.a[s][i] = la(s, i);
+        } else {
+#pragma unroll
+            for (int j = 0; j < TB; ++j) r.b[s][j] = lb(s, j);
+        }
     }
-#undef FFB6D_PIN
-    if (st < NSTEPS) mfma_step<T, TA, TB>(acc, a0, b0);
-    if (st + 1 < NSTEPS) mfma_step<T, TA, TB>(acc, a1, b1);
+}
+
+template <typename T, int NSTEPS, int TA, int TB, bool A_GLOBAL, typename LA, typename LB>
+__device__ __forceinline__ void gemm_run(f32x16 (&acc)[TA][TB], Ring<TA, TB>& r, LA&& la, LB&& lb)
+{
+#pragma unroll
+    for (int s = 0; s < 2 && s < NSTEPS; ++s) {           // the operand gemm_early did not fetch
+        if constexpr (!A_GLOBAL) {
+#pragma unroll
+            for (int i = 0; i < TA; ++i) r.a[s][i] = la(s, i);
+        } else {
+#pragma unroll
+            for (int j = 0; j < TB; ++j) r.b[s][j] = lb(s, j);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) {
+        if (s + 2 < NSTEPS) {
+#pragma unroll
+            for (int i = 0; i < TA; ++i) r.a[(s + 2) % 3][i] = la(s + 2, i);
+#pragma unroll
+            for (int j = 0; j < TB; ++j) r.b[(s + 2) % 3][j] = lb(s + 2, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step<T, TA, TB>(acc, r.a[s % 3], r.b[s % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int TA, int TB> __device__ __forceinline__ void zero(f32x16 (&acc)[TA][TB])
@@ -112,20 +135,28 @@ template <int TA, int TB> __device__ __forceinline__ void zero(f32x16 (&acc)[TA]
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
-template <typename T, int D, int P> struct LfaGeom {
+template <typename T, int D, int MODE, int P, bool WLDS> struct LfaGeom {
     static constexpr int SZ = El<T>::SZ;
+    static constexpr int H = D / 2, COUT = MODE == 1 ? H : D;
     static constexpr int RS = D * SZ + 16;            // image row stride: an odd multiple of 16 bytes (conflict-free ds_read_b128)
-    static constexpr int ROWS = 16 * P;               // pair rows of a workgroup
+    static constexpr int RS2 = H * SZ + 16;           // row stride of the W2 image
+    static constexpr int ROWS = 16 * P;               // pair rows of a point group
     static constexpr int S_BYTES = ROWS * RS;         // pair image
     static constexpr int PL_BYTES = P * RS;           // pooled rows
-    static constexpr int LDS = S_BYTES + PL_BYTES + 128;
+    static constexpr int SRC_BYTES = 2 * (ROWS + P) * 4;      // source rows of the pairs + coordinate-table shift of the points, x 2 groups
+    static constexpr int BIAS_BYTES = (2 * H + COUT) * 4;     // b1 | b2 | bm
+    // WLDS: the weights live in LDS for the life of the (persistent) workgroup, rows padded to whole 32-row tiles with zeros
+    static constexpr int WFC_BYTES = WLDS ? D * RS : 0;
+    static constexpr int WM_BYTES = WLDS ? COUT * RS : 0;
+    static constexpr int W2_BYTES = WLDS && MODE == 2 ? (H < 32 ? 32 : H) * RS2 : 0;
+    static constexpr int LDS = S_BYTES + PL_BYTES + SRC_BYTES + BIAS_BYTES + WFC_BYTES + WM_BYTES + W2_BYTES;
 };
 
-template <typename T, int D, int MODE, int P>
+template <typename T, int D, int MODE, int P, bool WLDS>
 __global__ void __launch_bounds__(BLK, 2)
 lfa_pm_kernel(const LfaParams p)
 {
-    using G = LfaGeom<T, D, P>;
+    using G = LfaGeom<T, D, MODE, P, WLDS>;
     constexpr int SZ = El<T>::SZ;
     constexpr int KSTEP = 32 / SZ;                    // k per 32-byte step
     constexpr int H = D / 2;
@@ -134,236 +165,400 @@ lfa_pm_kernel(const LfaParams p)
     constexpr int RS = G::RS, ROWS = G::ROWS;
     constexpr int NRT = P / 2;                        // row tiles (2 points x 16 neighbours)
     constexpr int NCT = D / 32;                       // channel tiles of the score GEMM
-    constexpr int NCH = ROWS * CPR / BLK;             // chunks per thread of the gather / of the encoding MLP
+    constexpr int NCH = ROWS * CPR / BLK;             // chunks per thread of the row gather
     constexpr int RPI = BLK / CPR;                    // pair rows covered by one chunk per thread
+    constexpr int NI = (ROWS + BLK - 1) / BLK;        // pair indices per thread
     constexpr int COUT = MODE == 1 ? H : D;
     constexpr int OOB = 0x7ffffff0;
     static_assert(D % 32 == 0 && P % 2 == 0 && P <= 32, "tile geometry");
     static_assert(H % KSTEP == 0, "half a pair row must be whole 32-byte steps");
     static_assert(BLK % CPR == 0 && (ROWS * CPR) % BLK == 0 && NCH >= 1, "chunks must divide evenly over the threads");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [pair image | pooled rows]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [pair image | pooled rows | source rows x 2 | biases | weights]
     unsigned char* const S = lds;
     unsigned char* const PL = lds + G::S_BYTES;
+    int* const SRC = reinterpret_cast<int*>(lds + G::S_BYTES + G::PL_BYTES);                   // [2][ROWS + P]
+    float* const B1 = reinterpret_cast<float*>(lds + G::S_BYTES + G::PL_BYTES + G::SRC_BYTES);  // b1 [H] | b2 [H] | bm [COUT]
+    float* const B2 = B1 + H;
+    float* const BM = B1 + 2 * H;
+    unsigned char* const WFC = lds + G::S_BYTES + G::PL_BYTES + G::SRC_BYTES + G::BIAS_BYTES;
+    unsigned char* const WM = WFC + G::WFC_BYTES;
+    unsigned char* const W2 = WM + G::WM_BYTES;
+    constexpr int RS2 = G::RS2, SRCN = ROWS + P;
 
-    // XCD x walks the x-th eighth of the point groups
+    // persistent workgroups: XCD x (blockIdx % 8) walks the x-th eighth of the point groups, its workgroups interleaved
     const int per_xcd = (p.n_grp + 7) >> 3;
-    const int g = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || g >= p.n_grp) return;
-    const int n0 = g * P;
+    const int xcd = blockIdx.x & 7, nwx = gridDim.x >> 3;
+    const int g_end = min(p.n_grp, (xcd + 1) * per_xcd);
+    int g = xcd * per_xcd + (int)(blockIdx.x >> 3);
+    if (g >= g_end) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---------------------------------------------------------------------------------------------------------------
-    // 1. pair rows: gathered point rows (registers for now) + position encoding -> mlp1 on the vector ALU
-    // ---------------------------------------------------------------------------------------------------------------
+    // wave -> tiles of the three GEMM phases
+    constexpr int CT1 = H / 32 > 0 ? H / 32 : 1;      // mlp1: channel tiles (H = 16: half a tile), row tiles wave, wave + 4, ..
+    constexpr int RT1 = (NRT + 3) / 4;
+    constexpr int NOT2 = CT1;                         // mlp2: output channel tiles, waves first along them
+    constexpr int WR2 = 4 / NOT2;
+    constexpr int RT2 = (NRT + WR2 - 1) / WR2;
+    constexpr int WC = NCT < 4 ? NCT : 4;             // scores: waves along the channel tiles, then along the row tiles
+    constexpr int WR = 4 / WC;
+    constexpr int TN = NCT / WC;
+    constexpr int TM = (NRT + WR - 1) / WR;
+    const int wc = wave % WC, wr = wave / WC;
+    const int ot2 = wave % NOT2, wr2 = wave / NOT2;
+
     const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.f, (unsigned)p.npts * (unsigned)p.ldf * SZ);
-    const int col = tid % CPR, row0 = tid / CPR;
-    u32x4 fch[NCH];
-    int lrow[NCH];                                    // image row (slot order) of chunk i
-    {
-        float w1[VL][10], b1[VL];
-#pragma unroll
-        for (int e = 0; e < VL; ++e) {
-            const float* wr = p.w1 + (size_t)(col * VL + e) * p.ldw1;
-#pragma unroll
-            for (int t = 0; t < 10; ++t) w1[e][t] = wr[t];
-            b1[e] = p.b1[col * VL + e];
-        }
-        int src[NCH];                                 // source point row (all frames) of chunk i, -1 = past the last point
-        int self[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int row = row0 + i * RPI, pp = row >> 4, nb = row & 15;
-            const int n = n0 + pp;
-            lrow[i] = (pp >> 1) * 32 + ((nb & 3) | ((pp & 1) << 2) | ((nb >> 2) << 3));
-            src[i] = -1;
-            self[i] = 0;
-            if (n < p.npts) {
-                const size_t pair = (size_t)n * 16 + nb;
-                const int nbi = p.idx64 ? (int)static_cast<const long long*>(p.nei)[pair] : static_cast<const int*>(p.nei)[pair];
-                src[i] = (n / p.N) * p.N + nbi;
-                self[i] = n;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-            fch[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_f, src[i] >= 0 ? src[i] * p.ldf * SZ + col * 16 : OOB, 0, 0);
-        // encoding + mlp1 (the arithmetic of csrc/posenc_body.h: separately rounded products and sums, IEEE sqrt, FMA chain in the
-        // order bias, dis, dx, dy, dz, p, q); points past the end compute on point 0 -- finite, never stored
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const float* pv = p.xyz + (size_t)self[i] * 3;
-            const float* qv = p.xyz + (size_t)(src[i] >= 0 ? src[i] : 0) * 3;
-            const float px = pv[0], py = pv[1], pz = pv[2];
-            const float qx = qv[0], qy = qv[1], qz = qv[2];
-            const float dx = px - qx, dy = py - qy, dz = pz - qz;
-            const float s2 = ((dx * dx) + (dy * dy)) + (dz * dz);       // -ffp-contract=off: no fusion
-            const float enc[10] = {sqrtf(s2), dx, dy, dz, px, py, pz, qx, qy, qz};
-            float o[VL];
-#pragma unroll
-            for (int e = 0; e < VL; ++e) {
-                float v = b1[e];
-#pragma unroll
-                for (int t = 0; t < 10; ++t) v = fmaf(w1[e][t], enc[t], v);
-                o[e] = activate(v, p.slope1);
-            }
-            // half 1: this IS the second half of the pair row; half 2: parked in the first half until mlp2 has consumed it
-            *reinterpret_cast<u32x4*>(S + lrow[i] * RS + (MODE == 1 ? H * SZ : 0) + col * 16) = pack_chunk<T>(o);
-        }
+    const __amdgpu_buffer_rsrc_t rs_fc = make_rsrc(p.wfc, (unsigned)(D * D * SZ));
+    const __amdgpu_buffer_rsrc_t rs_wm = make_rsrc(p.wm, (unsigned)(COUT * D * SZ));
+    const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(MODE == 2 ? p.w2 : p.wfc, (unsigned)(H * H * SZ));
+    const int fc_vo = (wc * TN * 32 + l31) * D * SZ + 16 * kh;
+    const int w2_vo = (ot2 * 32 + l31) * H * SZ + 16 * kh;              // rows past H: out of range -> zeros
+    // weight fragments: out of the LDS images (WLDS) or straight from L2
+    auto fc_frag = [&](int s, int j) {
+        if constexpr (WLDS) return *reinterpret_cast<const u32x4*>(WFC + ((wc * TN + j) * 32 + l31) * RS + s * 32 + 16 * kh);
+        else return __builtin_amdgcn_raw_buffer_load_b128(rs_fc, fc_vo + j * 32 * D * SZ + s * 32, 0, 0);
+    };
+    auto w2_frag = [&](int s, int) {
+        if constexpr (WLDS) return *reinterpret_cast<const u32x4*>(W2 + (ot2 * 32 + l31) * RS2 + s * 32 + 16 * kh);
+        else return __builtin_amdgcn_raw_buffer_load_b128(rs_w2, w2_vo + s * 32, 0, 0);
+    };
+    // biases (and, WLDS, the weight images) -> LDS, once; published by the first barrier below
+    for (int c = threadIdx.x; c < 2 * H + COUT; c += BLK)
+        B1[c] = c < H ? p.b1[c] : (c < 2 * H ? (MODE == 2 ? p.b2[c - H] : 0.f) : p.bm[c - 2 * H]);
+    if constexpr (WLDS) {
+        constexpr int CW = D * SZ / 16, CW2 = H * SZ / 16;              // 16-byte chunks of a weight row
+        for (int c = threadIdx.x; c < D * CW; c += BLK)
+            *reinterpret_cast<u32x4*>(WFC + (c / CW) * RS + (c % CW) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_fc, c * 16, 0, 0);
+        for (int c = threadIdx.x; c < COUT * CW; c += BLK)              // k-chunked table [k / VL][channel][VL] -> rows of the image
+            *reinterpret_cast<u32x4*>(WM + (c % COUT) * RS + (c / COUT) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_wm, c * 16, 0, 0);
+        if constexpr (MODE == 2)
+            for (int c = threadIdx.x; c < (H < 32 ? 32 : H) * CW2; c += BLK)
+                *reinterpret_cast<u32x4*>(W2 + (c / CW2) * RS2 + (c % CW2) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_w2, c * 16, 0, 0);
     }
 
-    if constexpr (MODE == 2) {
+    // lfa.mlp1 stays in registers for the life of the workgroup: W1[channel l31 of tile c][k = 2 t + kh], fp32
+    float wa[CT1][5];
+#pragma unroll
+    for (int c = 0; c < CT1; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int ch = c * 32 + l31;
+            wa[c][t] = ch < H ? p.w1[(size_t)ch * p.ldw1 + 2 * t + kh] : 0.f;
+        }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // Software pipeline over the groups of this workgroup.  What a group reads from HBM is requested one group ahead and
+    // waits in registers: while group g is multiplied, the gathered rows and coordinates of group g + nwx are in flight
+    // and the neighbour indices of group g + 2 nwx behind them.
+    //   indices  -> source rows of the 16 P pairs (frame base + neighbour index; -1 past the last point), one coalesced read
+    //               of the index tensor, parked in LDS (two buffers) for the row gather and the position encoding to share;
+    //   rows     -> gathered point rows as whole rows (consecutive lanes fetch consecutive 16-byte chunks of one row) and
+    //               the coordinates of the pair this lane owns in each of its mlp1 tiles.
+    // ---------------------------------------------------------------------------------------------------------------
+    const int col = tid % CPR, row0 = tid / CPR;
+    const int pp_l = (l31 >> 2) & 1, nb_l = (l31 & 3) + 4 * (l31 >> 3);          // this lane's slot: point of the tile, neighbour
+    int lrow[NCH];                                    // image row (slot order) of gathered chunk i
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int row = row0 + i * RPI, pp = row >> 4, nb = row & 15;
+        lrow[i] = (pp >> 1) * 32 + ((nb & 3) | ((pp & 1) << 2) | ((nb >> 2) << 3));
+    }
+    int idxr[NI], xdr[NI];
+    u32x4 fch[NCH];
+    float4 pq[RT1][2];                                // coordinates of the pair this lane owns in mlp1 tile j: p, q
+
+    auto fetch_idx = [&](int gg) {
+        const int n0 = gg * P;
+        // a group of P consecutive points touches at most two frames once P <= N
+        const int base0 = (n0 / p.N) * p.N, next = base0 + p.N;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int r = tid + k * BLK, n = n0 + (r >> 4);
+            int v = -1;
+            if (gg < g_end && r < ROWS && n < p.npts) {
+                const size_t pair = (size_t)n0 * 16 + r;
+                const int nbi = p.idx64 ? (int)static_cast<const long long*>(p.nei)[pair] : static_cast<const int*>(p.nei)[pair];
+                v = (P <= p.N ? (n < next ? base0 : next) : (n / p.N) * p.N) + nbi;
+            }
+            idxr[k] = v;
+            // shift between a point's row of f (b * N + n) and its row of the coordinate table (b * xfs + n)
+            xdr[k] = (P <= p.N ? (n < next ? n0 / p.N : n0 / p.N + 1) : n / p.N) * (p.xfs - p.N);
+        }
+    };
+    auto park_idx = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int r = tid + k * BLK;
+            if (r < ROWS) {
+                SRC[buf * SRCN + r] = idxr[k];
+                if ((r & 15) == 0) SRC[buf * SRCN + ROWS + (r >> 4)] = xdr[k];
+            }
+        }
+    };
+    auto fetch_rows = [&](int buf, int gg) {
+        const int* src = SRC + buf * SRCN;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int sr = src[row0 + i * RPI];
+            fch[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_f, sr >= 0 ? sr * p.ldf * SZ + col * 16 : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < RT1; ++j) {
+            const int rt = wave + 4 * j;
+            if (rt >= NRT) break;
+            const int pp = 2 * rt + pp_l;
+            const int sr = src[pp * 16 + nb_l];
+            const int xd = src[ROWS + pp];
+            // pairs past the last point compute on row 0 -- finite, never stored
+            pq[j][0] = p.xyz4[sr >= 0 ? gg * P + pp + xd : 0];
+            pq[j][1] = p.xyz4[sr >= 0 ? sr + xd : 0];
+        }
+    };
+
+    fetch_idx(g);
+    park_idx(0);
+    __syncthreads();
+    fetch_rows(0, g);
+    fetch_idx(g + nwx);
+
+    for (int it = 0; g < g_end; g += nwx, ++it) {
+        const int n0 = g * P;
         // -----------------------------------------------------------------------------------------------------------
-        // 2. lfa.mlp2 on the matrix cores: channels = MFMA rows (weights from L2), pair rows = MFMA columns (image, first half)
-        //    -> second half of the image.  A lane ends up with 4 x 4 consecutive channels of ONE pair row.
+        // 1. position encoding -> lfa.mlp1 on the matrix cores (fp32 in both precisions, K = 10 = five 32x32x2 MFMAs): a
+        //    lane computes the encoding of ONE pair (the slot it owns in the tile), channels are the MFMA rows, and it ends
+        //    up with 4 x 4 consecutive channels of that pair's row of the image.
         // -----------------------------------------------------------------------------------------------------------
-        __syncthreads();
-        constexpr int NOT2 = H / 32 > 0 ? H / 32 : 1;                  // output channel tiles (H = 16: half a tile)
-        constexpr int WR2 = 4 / NOT2;                                  // waves along the row tiles
-        constexpr int RT2 = (NRT + WR2 - 1) / WR2;                     // row tiles per wave
-        const int ot = wave % NOT2, wr = wave / NOT2;
-        const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(p.w2, (unsigned)(H * H * SZ));
-        f32x16 acc[1][RT2];
-        zero(acc);
-        const int w_vo = (ot * 32 + l31) * H * SZ + 16 * kh;           // rows past H: out of range -> zeros
-        gemm_steps<T, H / KSTEP, 1, RT2>(
-            acc,
-            [&](int s, int) { return __builtin_amdgcn_raw_buffer_load_b128(rs_w2, w_vo + s * 32, 0, 0); },
-            [&](int s, int j) {
-                const int rt = min(wr + WR2 * j, NRT - 1);
+        Ring<1, RT2> ring2;
+        if constexpr (MODE == 2) gemm_early<T, H / KSTEP, 1, RT2, true>(ring2, w2_frag, w2_frag);
+#pragma unroll
+        for (int j = 0; j < RT1; ++j) {
+            const int rt = wave + 4 * j;
+            if (rt >= NRT) break;
+            const float px = pq[j][0].x, py = pq[j][0].y, pz = pq[j][0].z, qx = pq[j][1].x, qy = pq[j][1].y, qz = pq[j][1].z;
+            const float dx = px - qx, dy = py - qy, dz = pz - qz;
+            const float s2 = ((dx * dx) + (dy * dy)) + (dz * dz);       // -ffp-contract=off: no fusion (RandLANet.py:216-223)
+            const float dis = sqrtf(s2);
+            // encoding [dis, dx, dy, dz, px, py, pz, qx, qy, qz]: half-wave kh supplies k = 2 t + kh
+            const float eb[5] = {kh ? dx : dis, kh ? dz : dy, kh ? py : px, kh ? qx : pz, kh ? qz : qy};
+            // half 1: this IS the second half of the pair row; half 2: parked in the first half until mlp2 has consumed it
+            unsigned char* const srow = S + (rt * 32 + l31) * RS + (MODE == 1 ? H * SZ : 0);
+#pragma unroll
+            for (int c = 0; c < CT1; ++c) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][t], eb[t], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = c * 32 + 8 * q + 4 * kh;
+                    if (ch >= H) continue;
+                    const float4 b4 = *reinterpret_cast<const float4*>(B1 + ch);
+                    El<T>::st4(reinterpret_cast<T*>(srow) + ch,
+                               make_float4(activate(acc[4 * q] + b4.x, p.slope1), activate(acc[4 * q + 1] + b4.y, p.slope1),
+                                           activate(acc[4 * q + 2] + b4.z, p.slope1), activate(acc[4 * q + 3] + b4.w, p.slope1)));
+                }
+            }
+        }
+
+        if constexpr (MODE == 2) {
+            // -------------------------------------------------------------------------------------------------------
+            // 2. lfa.mlp2: channels = MFMA rows (weights from L2), pair rows = MFMA columns (image, first half) -> second
+            //    half of the image
+            // -------------------------------------------------------------------------------------------------------
+            __syncthreads();
+            f32x16 acc[1][RT2];
+            zero(acc);
+            gemm_run<T, H / KSTEP, 1, RT2, true>(acc, ring2, w2_frag, [&](int s, int j) {
+                const int rt = min(wr2 + WR2 * j, NRT - 1);
                 return *reinterpret_cast<const u32x4*>(S + (rt * 32 + l31) * RS + s * 32 + 16 * kh);
             });
 #pragma unroll
-        for (int j = 0; j < RT2; ++j) {
-            const int rt = wr + WR2 * j;
-            if (rt >= NRT) continue;
+            for (int j = 0; j < RT2; ++j) {
+                const int rt = wr2 + WR2 * j;
+                if (rt >= NRT) continue;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ch = ot * 32 + 8 * q + 4 * kh;
-                if (ch >= H) continue;
-                const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + ch);
-                const float4 v = make_float4(activate(acc[0][j][4 * q] + b4.x, p.slope2), activate(acc[0][j][4 * q + 1] + b4.y, p.slope2),
-                                             activate(acc[0][j][4 * q + 2] + b4.z, p.slope2), activate(acc[0][j][4 * q + 3] + b4.w, p.slope2));
-                El<T>::st4(reinterpret_cast<T*>(S + (rt * 32 + l31) * RS) + H + ch, v);
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = ot2 * 32 + 8 * q + 4 * kh;
+                    if (ch >= H) continue;
+                    const float4 b4 = *reinterpret_cast<const float4*>(B2 + ch);
+                    El<T>::st4(reinterpret_cast<T*>(S + (rt * 32 + l31) * RS) + H + ch,
+                               make_float4(activate(acc[0][j][4 * q] + b4.x, p.slope2), activate(acc[0][j][4 * q + 1] + b4.y, p.slope2),
+                                           activate(acc[0][j][4 * q + 2] + b4.z, p.slope2), activate(acc[0][j][4 * q + 3] + b4.w, p.slope2)));
+                }
             }
+            __syncthreads();                          // every wave is done reading the parked mlp1 rows
         }
-        __syncthreads();                              // every wave is done reading the parked mlp1 rows
-    }
-    // gathered point rows -> first half of the image
+        // gathered point rows -> first half of the image; the next group's source rows -> their LDS buffer
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(S + lrow[i] * RS + col * 16) = fch[i];
-    __syncthreads();
+        for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(S + lrow[i] * RS + col * 16) = fch[i];
+        park_idx((it + 1) & 1);
+        Ring<TM, TN> ring3;
+        gemm_early<T, D / KSTEP, TM, TN, false>(ring3, fc_frag, fc_frag);
+        __syncthreads();
+        fetch_rows((it + 1) & 1, g + nwx);            // in flight while this group is multiplied
+        fetch_idx(g + 2 * nwx);
 
-    // ---------------------------------------------------------------------------------------------------------------
-    // 3. scores A = S Wfc^T (pair rows = MFMA rows out of the image, channels = MFMA columns, weights from L2), then in-lane
-    //    softmax over the 16 neighbours and the weighted sum -> pooled rows
-    // ---------------------------------------------------------------------------------------------------------------
-    {
-        constexpr int WC = NCT < 4 ? NCT : 4;                          // waves along the channel tiles
-        constexpr int WR = 4 / WC;
-        constexpr int TN = NCT / WC;
-        constexpr int TM = (NRT + WR - 1) / WR;
-        const int wc = wave % WC, wr = wave / WC;
-        const __amdgpu_buffer_rsrc_t rs_fc = make_rsrc(p.wfc, (unsigned)(D * D * SZ));
-        f32x16 acc[TM][TN];
-        zero(acc);
-        const int w_vo = (wc * TN * 32 + l31) * D * SZ + 16 * kh;
-        gemm_steps<T, D / KSTEP, TM, TN>(
-            acc,
-            [&](int s, int i) {
+        // -----------------------------------------------------------------------------------------------------------
+        // 3. scores A = S Wfc^T (pair rows = MFMA rows out of the image, channels = MFMA columns, weights from L2), then
+        //    in-lane softmax over the 16 neighbours and the weighted sum -> pooled rows
+        // -----------------------------------------------------------------------------------------------------------
+        {
+            f32x16 acc[TM][TN];
+            zero(acc);
+            gemm_run<T, D / KSTEP, TM, TN, false>(acc, ring3, [&](int s, int i) {
                 const int rt = min(wr + WR * i, NRT - 1);
                 return *reinterpret_cast<const u32x4*>(S + (rt * 32 + l31) * RS + s * 32 + 16 * kh);
-            },
-            [&](int s, int j) { return __builtin_amdgcn_raw_buffer_load_b128(rs_fc, w_vo + j * 32 * D * SZ + s * 32, 0, 0); });
+            }, fc_frag);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int rt = wr + WR * i;
-            if (rt >= NRT) continue;
+            for (int i = 0; i < TM; ++i) {
+                const int rt = wr + WR * i;
+                if (rt >= NRT) continue;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int ch = (wc * TN + j) * 32 + l31;
-                const unsigned char* sp = S + (rt * 32 + (kh << 2)) * RS + ch * SZ;      // slot of (point kh, neighbour 0)
-                float fv[16];
+                for (int j = 0; j < TN; ++j) {
+                    const int ch = (wc * TN + j) * 32 + l31;
+                    const unsigned char* sp = S + (rt * 32 + (kh << 2)) * RS + ch * SZ;      // slot of (point kh, neighbour 0)
+                    float fv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) fv[r] = El<T>::ld(reinterpret_cast<const T*>(sp + ((r & 3) | ((r >> 2) << 3)) * RS));
-                float m = acc[i][j][0];
+                    for (int r = 0; r < 16; ++r) fv[r] = El<T>::ld(reinterpret_cast<const T*>(sp + ((r & 3) | ((r >> 2) << 3)) * RS));
+                    float m = acc[i][j][0];
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
-                float num = 0.f, den = 0.f;
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+                    float num = 0.f, den = 0.f;
+                    const float nm = -m * 1.44269504088896341f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f((acc[i][j][r] - m) * 1.44269504088896341f);
-                    den += e;
-                    num = fmaf(fv[r], e, num);
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(acc[i][j][r], 1.44269504088896341f, nm));
+                        den += e;
+                        num = fmaf(fv[r], e, num);
+                    }
+                    El<T>::st(reinterpret_cast<T*>(PL + (2 * rt + kh) * RS) + ch, num * __builtin_amdgcn_rcpf(den));
                 }
-                El<T>::st(reinterpret_cast<T*>(PL + (2 * rt + kh) * RS) + ch, num * __builtin_amdgcn_rcpf(den));
             }
         }
-    }
-    __syncthreads();
-
-    // ---------------------------------------------------------------------------------------------------------------
-    // 4. output MLP on the pooled rows: channels = MFMA rows (weights from L2), points = MFMA columns (pooled image)
-    // ---------------------------------------------------------------------------------------------------------------
-    {
-        constexpr int NOT = COUT / 32 > 0 ? COUT / 32 : 1;
-        constexpr int TMO = (NOT + 3) / 4;
-        if (wave >= NOT) return;
-        const __amdgpu_buffer_rsrc_t rs_wm = make_rsrc(p.wm, (unsigned)(COUT * D * SZ));
-        f32x16 acc[TMO][1];
-        zero(acc);
-        const int w_vo = (wave * 32 + l31) * D * SZ + 16 * kh;         // tiles wave, wave + 4; rows past COUT: out of range -> zeros
-        const unsigned char* xp = PL + min(l31, P - 1) * RS + 16 * kh;
-        gemm_steps<T, D / KSTEP, TMO, 1>(
-            acc,
-            [&](int s, int i) {
-                return __builtin_amdgcn_raw_buffer_load_b128(rs_wm, wave + 4 * i < NOT ? w_vo + i * 128 * D * SZ + s * 32 : OOB, 0, 0);
-            },
-            [&](int s, int) { return *reinterpret_cast<const u32x4*>(xp + s * 32); });
-        const int n = n0 + l31;
-        if (l31 >= P || n >= p.npts) return;
-        T* orow = static_cast<T*>(p.out) + (size_t)n * p.ldo;
+        // -----------------------------------------------------------------------------------------------------------
+        // 4. output MLP on the pooled rows.
+        //    fp32 -- on the vector ALU: the fp32 MFMA runs at the vector FMA rate, so a 32-column tile padded from P <= 32
+        //    points only wastes it, and it would sit on one or two waves while the others wait.  Thread = one output channel
+        //    x PPT points; its weight row arrives as 16-byte chunks of VL consecutive k (LDS image, or the k-chunked table in
+        //    L2: coalesced), the pooled rows are LDS broadcasts.
+        //    bf16 -- on the matrix cores (16x the rate, beside the vector ALU): channels = MFMA rows, points = MFMA columns;
+        //    the wave that takes tile 0 rotates with the group.  fp32 accumulation either way.
+        // -----------------------------------------------------------------------------------------------------------
+        if constexpr (SZ == 4) {
+            __syncthreads();
+            constexpr int TPC = BLK / COUT > 0 ? BLK / COUT : 1;       // threads per channel
+            constexpr int PPT = P / TPC;                               // points per thread
+            static_assert(COUT <= BLK && BLK % COUT == 0 && P % TPC == 0 && PPT >= 1, "output MLP: P * COUT must be whole multiples of the workgroup");
+            const int c = tid % COUT, p0 = (tid / COUT) * PPT;
+            float acc[PPT];
 #pragma unroll
-        for (int i = 0; i < TMO; ++i) {
+            for (int q = 0; q < PPT; ++q) acc[q] = 0.f;
+            const unsigned char* xrow = PL + p0 * RS;
+#pragma unroll 4
+            for (int kc = 0; kc < D / VL; ++kc) {
+                u32x4 wv;
+                if constexpr (WLDS) wv = *reinterpret_cast<const u32x4*>(WM + c * RS + kc * 16);
+                else wv = __builtin_amdgcn_raw_buffer_load_b128(rs_wm, (kc * COUT + c) * 16, 0, 0);
+                float w[VL];
+                unpack_chunk<T>(wv, w);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ch = (wave + 4 * i) * 32 + 8 * q + 4 * kh;
-                if (ch >= COUT) continue;
-                const float4 b4 = *reinterpret_cast<const float4*>(p.bm + ch);
-                El<T>::st4(orow + ch, make_float4(activate(acc[i][0][4 * q] + b4.x, p.slopem), activate(acc[i][0][4 * q + 1] + b4.y, p.slopem),
-                                                  activate(acc[i][0][4 * q + 2] + b4.z, p.slopem), activate(acc[i][0][4 * q + 3] + b4.w, p.slopem)));
+                for (int q = 0; q < PPT; ++q) {
+                    float x[VL];
+                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(xrow + q * RS + kc * 16), x);
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) acc[q] = fmaf(w[e], x[e], acc[q]);
+                }
+            }
+            const float bias = BM[c];
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const int n = n0 + p0 + q;
+                if (n < p.npts) El<T>::st(static_cast<T*>(p.out) + (size_t)n * p.ldo + c, activate(acc[q] + bias, p.slopem));
+            }
+        } else {
+            constexpr int NOT = COUT / 32 > 0 ? COUT / 32 : 1;         // channel tiles wo, wo + 4
+            constexpr int TMO = (NOT + 3) / 4;
+            const int wo = (wave + it) & 3;
+            // a fragment = VL consecutive k of one channel = ONE chunk of the k-chunked table; channels past COUT: out of range -> zeros
+            auto wm_frag = [&](int s, int i) {
+                const int ch = (wo + 4 * i) * 32 + l31;
+                if constexpr (WLDS) return *reinterpret_cast<const u32x4*>(WM + min(ch, COUT - 1) * RS + s * 32 + 16 * kh);
+                else return __builtin_amdgcn_raw_buffer_load_b128(rs_wm, ch < COUT ? ((2 * s + kh) * COUT + ch) * 16 : OOB, 0, 0);
+            };
+            Ring<TMO, 1> ring4;
+            if (wo < NOT) gemm_early<T, D / KSTEP, TMO, 1, true>(ring4, wm_frag, wm_frag);
+            __syncthreads();
+            if (wo < NOT) {
+                f32x16 acc[TMO][1];
+                zero(acc);
+                const unsigned char* xp = PL + min(l31, P - 1) * RS + 16 * kh;
+                gemm_run<T, D / KSTEP, TMO, 1, true>(acc, ring4, wm_frag,
+                                                     [&](int s, int) { return *reinterpret_cast<const u32x4*>(xp + s * 32); });
+                const int n = n0 + l31;
+                if (l31 < P && n < p.npts) {
+                    T* orow = static_cast<T*>(p.out) + (size_t)n * p.ldo;
+#pragma unroll
+                    for (int i = 0; i < TMO; ++i) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ch = (wo + 4 * i) * 32 + 8 * q + 4 * kh;
+                            if (ch >= COUT) continue;
+                            const float4 b4 = *reinterpret_cast<const float4*>(BM + ch);
+                            El<T>::st4(orow + ch, make_float4(activate(acc[i][0][4 * q] + b4.x, p.slopem), activate(acc[i][0][4 * q + 1] + b4.y, p.slopem),
+                                                              activate(acc[i][0][4 * q + 2] + b4.z, p.slopem), activate(acc[i][0][4 * q + 3] + b4.w, p.slopem)));
+                        }
+                    }
+                }
             }
         }
     }
 }
 
-template <typename T, int D, int MODE, int P>
+template <typename T, int D, int MODE, int P, bool WLDS>
 void launch_lfa(LfaParams& p, hipStream_t st)
 {
-    using G = LfaGeom<T, D, P>;
+    using G = LfaGeom<T, D, MODE, P, WLDS>;
     p.n_grp = (int)ceil_div(p.npts, P);
-    const void* fn = reinterpret_cast<const void*>(&lfa_pm_kernel<T, D, MODE, P>);
-    static const hipError_t attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    (void)attr;
-    const unsigned grid = (unsigned)(ceil_div(p.n_grp, 8) * 8);
-    hipLaunchKernelGGL((lfa_pm_kernel<T, D, MODE, P>), dim3(grid), dim3(BLK), G::LDS, st, p);
+    const void* fn = reinterpret_cast<const void*>(&lfa_pm_kernel<T, D, MODE, P, WLDS>);
+    // persistent workgroups: as many as are resident at once (registers + LDS), each walks its share of the point groups
+    static const int per_cu = [&] {
+        int n = 0;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, BLK, G::LDS) != hipSuccess || n < 1)
+            n = 1;
+        return n;
+    }();
+    const int64_t per_xcd = ceil_div(p.n_grp, 8);                          // groups of one XCD
+    // FFB6D_LFA_WG_PER_XCD: cap on the workgroups per XCD (tuning; the tests use 1 to make every workgroup loop)
+    const char* e = getenv("FFB6D_LFA_WG_PER_XCD");
+    const int64_t cap = e && atoi(e) > 0 ? (int64_t)atoi(e) : (int64_t)1 << 30;
+    const unsigned grid = 8u * (unsigned)std::min<int64_t>(std::min<int64_t>(per_xcd, (int64_t)32 * per_cu), cap);
+    hipLaunchKernelGGL((lfa_pm_kernel<T, D, MODE, P, WLDS>), dim3(grid), dim3(BLK), G::LDS, st, p);
 }
 
 // points per workgroup: 16 P d elements of pair image = 64 KB (fp32) whatever the level; `small` halves it (more, smaller
-// workgroups: the deep levels have few points)
+// workgroups).  wlds: fc / mlp / mlp2 weights resident in LDS (d <= 64 only: they must fit beside the pair image).
 template <typename T, int D, int MODE>
-void launch_lfa_p(LfaParams& p, bool small, hipStream_t st)
+void launch_lfa_p(LfaParams& p, bool small, bool wlds, hipStream_t st)
 {
     constexpr int P = 1024 / D;
-    if (small) launch_lfa<T, D, MODE, P / 2>(p, st);
-    else launch_lfa<T, D, MODE, P>(p, st);
+    if constexpr (D <= 64) {
+        if (wlds) {
+            if (small) launch_lfa<T, D, MODE, P / 2, true>(p, st);
+            else launch_lfa<T, D, MODE, P, true>(p, st);
+            return;
+        }
+    }
+    if (small) launch_lfa<T, D, MODE, P / 2, false>(p, st);
+    else launch_lfa<T, D, MODE, P, false>(p, st);
 }
 
 template <typename T>
-int lfa_pm_impl(int mode, const float* xyz, const void* nei, int idx_bits, const void* f, int64_t ldf, const float* w1, int64_t ldw1,
+int lfa_pm_impl(int mode, const float* xyz4, int64_t xfs, const void* nei, int idx_bits, const void* f, int64_t ldf, const float* w1, int64_t ldw1,
                 const float* b1, int act1, const void* w2, const float* b2, int act2, const void* wfc, const void* wm, const float* bm,
                 int actm, void* out, int64_t ldo, int64_t B, int64_t N, int K, int64_t d, int p_hint, ffb6d_stream_t stream)
 {
@@ -375,27 +570,32 @@ int lfa_pm_impl(int mode, const float* xyz, const void* nei, int idx_bits, const
     FFB6D_REQUIRE(B >= 0 && N >= 0, "lfa_pm: bad shape");
     if (B == 0 || N == 0) return FFB6D_OK;
     const int64_t h = d / 2, cout = mode == 1 ? h : d;
-    FFB6D_REQUIRE(xyz && nei && f && w1 && b1 && wfc && wm && bm && out && (mode == 1 || (w2 && b2)), "lfa_pm: null pointer");
+    FFB6D_REQUIRE(xyz4 && nei && f && w1 && b1 && wfc && wm && bm && out && (mode == 1 || (w2 && b2)), "lfa_pm: null pointer");
     FFB6D_REQUIRE(act1 >= 0 && act1 <= 2 && act2 >= 0 && act2 <= 2 && actm >= 0 && actm <= 2,
                   "lfa_pm: activations must be 0 (none), 1 (relu) or 2 (leaky 0.2)");
     FFB6D_REQUIRE(ldf >= h && ldo >= cout && ldw1 >= 10 && (ldf * SZ) % 16 == 0 && (ldo * SZ) % 16 == 0 &&
                   ((reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(w2) |
                     reinterpret_cast<uintptr_t>(wfc) | reinterpret_cast<uintptr_t>(wm) | reinterpret_cast<uintptr_t>(bm) |
-                    reinterpret_cast<uintptr_t>(b2)) & 15) == 0,
+                    reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(b1)) & 15) == 0,
                   "lfa_pm: rows must be 16-byte aligned and at least as long as their channel count");
     const int64_t npts = B * N;
-    FFB6D_REQUIRE((npts + 64) * ldf * SZ < (1LL << 31) && npts * 16 < (1LL << 31), "lfa_pm: operand larger than the 2 GiB buffer addressing of one launch");
+    FFB6D_REQUIRE((npts + 64) * ldf * SZ < (1LL << 31) && npts * 16 < (1LL << 31) && B * xfs < (1LL << 31),
+                  "lfa_pm: operand larger than the 2 GiB buffer addressing of one launch");
+    FFB6D_REQUIRE(xfs >= N && (reinterpret_cast<uintptr_t>(xyz4) & 15) == 0, "lfa_pm: coordinate table: 16-byte rows, frame stride >= N");
     LfaParams p;
-    p.xyz = xyz; p.nei = nei; p.f = f; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.wfc = wfc; p.wm = wm; p.bm = bm; p.out = out;
+    p.xyz4 = reinterpret_cast<const float4*>(xyz4); p.xfs = (int)xfs; p.nei = nei; p.f = f; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.wfc = wfc; p.wm = wm; p.bm = bm; p.out = out;
     p.npts = (int)npts; p.N = (int)N; p.ldf = (int)ldf; p.ldo = (int)ldo; p.ldw1 = (int)ldw1; p.idx64 = idx_bits == 64;
     auto slope = [](int a) { return a == 0 ? 1.f : (a == 1 ? 0.f : 0.2f); };
     p.slope1 = slope(act1); p.slope2 = slope(act2); p.slopem = slope(actm);
     hipStream_t st = as_stream(stream);
-    const bool small = p_hint == 2 || (p_hint <= 0 && ffb6d_lfa_pm_small_groups(npts, d));
+    const int size_hint = p_hint & 3, w_hint = (p_hint >> 2) & 3;
+    const int choice = ffb6d_lfa_pm_choice(npts, d, SZ == 2);
+    const bool small = size_hint == 2 || (size_hint == 0 && (choice & 3) == 2);
+    const bool wlds = d <= 64 && (w_hint == 1 || (w_hint == 0 && (choice >> 2) == 1));
 #define FFB6D_LFA_D(D_)                                                              \
     do {                                                                             \
-        if (mode == 1) launch_lfa_p<T, D_, 1>(p, small, st);                         \
-        else launch_lfa_p<T, D_, 2>(p, small, st);                                   \
+        if (mode == 1) launch_lfa_p<T, D_, 1>(p, small, wlds, st);                   \
+        else launch_lfa_p<T, D_, 2>(p, small, wlds, st);                             \
     } while (0)
     switch (d) {
         case 32: FFB6D_LFA_D(32); break;
@@ -413,22 +613,27 @@ int lfa_pm_impl(int mode, const float* xyz, const void* nei, int idx_bits, const
 
 using namespace ffb6d;
 
-// 1 = half-size point groups (512 / d points per workgroup instead of 1024 / d): when the full-size groups would leave CUs idle
-extern "C" int ffb6d_lfa_pm_small_groups(int64_t npts, int64_t d)
+// The p_hint an automatic launch resolves to (pure host logic; measured on the four level shapes of BASELINE configuration 2,
+// profiles/r03_lfa_levels.txt): point groups of 512 / d points (size 2) wherever the full-size groups would leave CUs without a
+// resident workgroup or cost occupancy -- fp32: every level but d = 128; bf16: d <= 64 -- and the fc / mlp weights resident in
+// LDS only for d = 32 (at d = 64 their 40 KB cost a resident workgroup).
+extern "C" int ffb6d_lfa_pm_choice(int64_t npts, int64_t d, int bf16)
 {
-    const int64_t P = 1024 / d;
-    return P >= 4 && ceil_div(npts, P) < 2 * 256 * 2;
+    (void)npts;
+    const int size = bf16 ? (d <= 64 ? 2 : 1) : (d == 128 ? 1 : 2);
+    const int w = d == 32 ? 1 : 2;
+    return size + 4 * w;
 }
 
-extern "C" int ffb6d_lfa_pm(int dtype, int mode, const float* xyz, const void* nei, int idx_bits, const void* f, int64_t ldf,
+extern "C" int ffb6d_lfa_pm(int dtype, int mode, const float* xyz4, int64_t xyz_frame_stride, const void* nei, int idx_bits, const void* f, int64_t ldf,
                             const float* w1, int64_t ldw1, const float* b1, int act1, const void* w2, const float* b2, int act2,
                             const void* wfc, const void* wm, const float* bm, int actm, void* out, int64_t ldo, int64_t B, int64_t N,
                             int K, int64_t d, int p_hint, ffb6d_stream_t stream)
 {
     FFB6D_REQUIRE(dtype == 0 || dtype == 1, "lfa_pm: dtype must be 0 (float32) or 1 (bfloat16)");
     if (dtype == 1)
-        return lfa_pm_impl<__bf16>(mode, xyz, nei, idx_bits, f, ldf, w1, ldw1, b1, act1, w2, b2, act2, wfc, wm, bm, actm, out, ldo, B, N, K,
+        return lfa_pm_impl<__bf16>(mode, xyz4, xyz_frame_stride, nei, idx_bits, f, ldf, w1, ldw1, b1, act1, w2, b2, act2, wfc, wm, bm, actm, out, ldo, B, N, K,
                                    d, p_hint, stream);
-    return lfa_pm_impl<float>(mode, xyz, nei, idx_bits, f, ldf, w1, ldw1, b1, act1, w2, b2, act2, wfc, wm, bm, actm, out, ldo, B, N, K, d,
+    return lfa_pm_impl<float>(mode, xyz4, xyz_frame_stride, nei, idx_bits, f, ldf, w1, ldw1, b1, act1, w2, b2, act2, wfc, wm, bm, actm, out, ldo, B, N, K, d,
                               p_hint, stream);
 }

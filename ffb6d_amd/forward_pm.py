@@ -113,18 +113,28 @@ LFA_FUSED = __import__("os").environ.get("FFB6D_LFA_FUSED", "1").strip() not in 
 LFA_WIDTHS = (32, 64, 128, 256)
 
 
+def folded_kc(m, dt):
+    """folded(m) with the weight in the k-chunked layout of the fused LFA kernel's output MLP (ops_pm.k_chunked)"""
+    def build():
+        w, b = folded(m, dt=dt)
+        return ops_pm.k_chunked(w), b
+    return cached(m, "kc%s" % dt, mlp_sources(m), build)
+
+
 def building_block(bb, xyz, f_pc, nei):
     """RandLANet.py:196-214 (Building_block.forward): f_pc [B,N,d/2] -> [B,N,d]."""
     dt = f_pc.dtype
     if LFA_FUSED and 2 * f_pc.shape[-1] in LFA_WIDTHS and nei.shape[-1] == 16:
         w1, b1 = folded(bb.mlp1)                                                   # fp32 [d/2, 10] in both precisions
         a1, a2 = bb.att_pooling_1, bb.att_pooling_2
-        wm1, bm1 = folded(a1.mlp, dt=dt)
+        wm1, bm1 = folded_kc(a1.mlp, dt)
         f_agg = ops_pm.lfa_half(1, xyz, nei, f_pc, w1, b1, bb.mlp1.act_code, fc_weight(a1, dt), wm1, bm1, a1.mlp.act_code)
         w2, b2 = folded(bb.mlp2, dt=dt)
-        wm2, bm2 = folded(a2.mlp, dt=dt)
+        wm2, bm2 = folded_kc(a2.mlp, dt)
         return ops_pm.lfa_half(2, xyz, nei, f_agg, w1, b1, bb.mlp1.act_code, fc_weight(a2, dt), wm2, bm2, a2.mlp.act_code,
                                w2=w2, b2=b2, act2=bb.mlp2.act_code)
+    if xyz.shape[-1] == 4:
+        xyz = xyz[..., :3].contiguous()
     if POSENC_FUSED:                                                               # encoding generated in registers
         w, b = folded(bb.mlp1)                                                     # fp32 [d/2, 10] in both precisions
         f_xyz = ops_pm.posenc_mlp(xyz, nei, w, b, bb.mlp1.act_code, dtype=dt)      # [B,N,16,d/2]
@@ -328,6 +338,11 @@ class StreamedPyramid(dict):
         idx.wait_stream(main)
         with torch.cuda.stream(idx):
             cld = inputs['cld_rgb_nrm'][:, :3, :].transpose(1, 2).contiguous()      # linemod_dataset.py:285,318
+            # coordinate table of the fused local feature aggregation (16-byte rows): every coarser level is a prefix of the
+            # cloud (linemod_dataset.py:322-323), so ONE table serves all four levels through its frame stride
+            self.table0 = ops_pm.xyz_table(cld)
+            if idx is not main:
+                self.table0.record_stream(side)
             b = pyramid.PyramidBuilder(cld, inputs['dpt_xyz'], getattr(net, 'index_dtype', torch.int64))
             for i in range(7):
                 d = b.encoder_level(i) if i < 4 else b.decoder_level(i - 4)
@@ -349,6 +364,10 @@ class StreamedPyramid(dict):
 
     def up_level(self, i, stream):
         self.level(4 + i, stream)
+
+    def xyz_table(self, i):
+        """coordinate table of encoder level i: the first N_i rows of every frame of the level-0 table (valid after level(i))"""
+        return self.table0[:, :self['cld_xyz%d' % i].shape[1]]
 
 
 def forward(net, inputs, end_points, two_streams=True, taps=None):
@@ -436,7 +455,10 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
         rgb0 = cnn_stage(net.cnn_ds_stages[i], rgb_emb)
         need(i)
         with on_side():
-            f_enc = dilated_res_block(net.rndla_ds_stages[i], p_emb, inputs['cld_xyz%d' % i], inputs['cld_nei_idx%d' % i])
+            xyz = inputs['cld_xyz%d' % i]
+            if LFA_FUSED:
+                xyz = inputs.xyz_table(i) if lazy else ops_pm.xyz_table(xyz)
+            f_enc = dilated_res_block(net.rndla_ds_stages[i], p_emb, xyz, inputs['cld_nei_idx%d' % i])
             p0 = ops_pm.random_sample(f_enc, inputs['cld_sub_idx%d' % i])
         if i == 0:
             ds_emb.append(f_enc)

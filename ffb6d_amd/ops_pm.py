@@ -208,24 +208,46 @@ def posenc_mlp(xyz, neigh_idx, w, bias, act, dtype=torch.float32):
     return out
 
 
+def xyz_table(xyz):
+    """[B,N,3] float32 coordinates -> [B,N,4] table of 16-byte rows {x, y, z, 0}: what csrc/lfa_pm.hip gathers neighbour
+    coordinates from (one aligned 16-byte load per point instead of three 4-byte ones)."""
+    return torch.nn.functional.pad(xyz.detach().float(), (0, 1)).contiguous()
+
+
+def k_chunked(w):
+    """[cout, d] weight -> [d / VL, cout, VL] (VL = 16 bytes of consecutive k): the layout csrc/lfa_pm.hip reads the output
+    MLP's weight in (one coalesced 16-byte load per channel and k-chunk)."""
+    vl = 16 // w.element_size()
+    cout, d = w.shape
+    return w.detach().reshape(cout, d // vl, vl).permute(1, 0, 2).contiguous()
+
+
 def lfa_half(mode, xyz, neigh_idx, f, w1, b1, act1, wfc, wm, bm, actm, w2=None, b2=None, act2=ACT_NONE, out=None, p_hint=0):
     """One half of Building_block.forward (RandLANet.py:196-214) in one launch (csrc/lfa_pm.hip): neighbour gather +
     relative_pos_encoding + mlp1 (+ mlp2 for mode 2) + Att_pooling (fc, softmax over the 16 neighbours, weighted sum, mlp).
-    xyz [B,N,3] float32, neigh_idx [B,N,16], f [B,N,d/2] rows (float32 / bfloat16); w1 [d/2, >=10] / b1 float32 (BatchNorm folded),
-    w2 [d/2,d/2], wfc [d,d], wm [cout,d] of f's dtype, b2 / bm float32 -> [B,N,cout], cout = d/2 (mode 1) or d (mode 2).
-    The per-pair tensors of the reference ([B,N,16,10], [B,N,16,d/2], [B,N,16,d]) exist only in LDS."""
+    xyz [B,N,3] float32 or a coordinate table [B,N,4] (xyz_table; may be the first N rows of every frame of a finer level's
+    table: stride(0) is honoured), neigh_idx [B,N,16], f [B,N,d/2] rows (float32 / bfloat16); w1 [d/2, >=10] / b1 float32
+    (BatchNorm folded), w2 [d/2,d/2], wfc [d,d], wm [cout,d] of f's dtype, b2 / bm float32 -> [B,N,cout], cout = d/2 (mode 1)
+    or d (mode 2).  The per-pair tensors of the reference ([B,N,16,10], [B,N,16,d/2], [B,N,16,d]) exist only in LDS."""
     _need_gpu(xyz, neigh_idx, f, wfc, wm)
     lib = _lib.load()
-    x = xyz.detach().contiguous()
     idx, bits = _idx(neigh_idx)
     B, N, K = idx.shape
+    x = xyz if xyz.shape[-1] == 4 else xyz_table(xyz)
+    if x.dtype != torch.float32 or x.shape[:2] != (B, N) or x.stride(2) != 1 or x.stride(1) != 4 or x.data_ptr() % 16 or \
+            (B > 1 and x.stride(0) < 4 * N) or x.stride(0) % 4:
+        x = x.contiguous()
+    xfs = x.stride(0) // 4 if B > 1 else N
     h = f.shape[-1]
     d = 2 * h
     cout = h if mode == 1 else d
     dt = _dt(f, wfc, wm, w2, out)
     if w1.dtype != torch.float32 or w1.dim() != 2 or w1.shape[0] != h or w1.shape[1] < 10 or w1.stride(1) != 1:
         raise ValueError("lfa_half: w1 must be float32 [d/2, >=10] with contiguous rows")
-    for name, t, shape in (("wfc", wfc, (d, d)), ("wm", wm, (cout, d)), ("w2", w2, (h, h))):
+    if wm.dim() == 2:
+        wm = k_chunked(wm)
+    vl = 16 // f.element_size()
+    for name, t, shape in (("wfc", wfc, (d, d)), ("wm", wm, (d // vl, cout, vl)), ("w2", w2, (h, h))):
         if t is not None and (tuple(t.shape) != shape or not t.is_contiguous()):
             raise ValueError(f"lfa_half: {name} must be contiguous {shape}, got {tuple(t.shape)}")
     if (mode == 2) != (w2 is not None) or any(b is not None and b.dtype != torch.float32 for b in (b1, b2, bm)):
@@ -234,10 +256,10 @@ def lfa_half(mode, xyz, neigh_idx, f, w1, b1, act1, wfc, wm, bm, actm, w2=None, 
     if out is None:
         out = torch.empty((B, N, cout), dtype=f.dtype, device=f.device)
     esz = f.element_size()
-    nbytes = 12 * B * N + (bits // 8) * B * N * K + esz * B * N * (h + cout) + esz * (d * d + cout * d + (h * h if mode == 2 else 0)) + 40 * h
+    nbytes = 16 * B * N + (bits // 8) * B * N * K + esz * B * N * (h + cout) + esz * (d * d + cout * d + (h * h if mode == 2 else 0)) + 40 * h
     flops = 2 * K * B * N * (d * d + 10 * h + (h * h if mode == 2 else 0)) + 2 * B * N * d * cout
     with torch.cuda.device(f.device), _lib.traced("lfa_pm", nbytes, (mode, d, N, dt, flops)):
-        rc = lib.ffb6d_lfa_pm(dt, int(mode), x.data_ptr(), idx.data_ptr(), bits, f2.data_ptr(), ldf, w1.data_ptr(), w1.stride(0),
+        rc = lib.ffb6d_lfa_pm(dt, int(mode), x.data_ptr(), xfs, idx.data_ptr(), bits, f2.data_ptr(), ldf, w1.data_ptr(), w1.stride(0),
                               b1.data_ptr(), int(act1), w2.data_ptr() if w2 is not None else None,
                               b2.data_ptr() if b2 is not None else None, int(act2), wfc.data_ptr(), wm.data_ptr(), bm.data_ptr(),
                               int(actm), out.data_ptr(), out.stride(-2), B, N, K, d, int(p_hint), _stream(f))

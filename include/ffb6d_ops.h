@@ -222,16 +222,21 @@ int ffb6d_posenc_mlp_pm(int dtype, const float* xyz, const void* idx, int idx_bi
  *   S[(n,k),:] = [ f[nei[n,k],:] | g_mode ],   out[n,:] = actm( wm . sum_k S[(n,k),:] * softmax_k((S wfc^T)[(n,k),:]) + bm )
  * mode 1 = gather + mlp1 + att_pooling_1 (fc, softmax, pool, mlp): f [B*N, ldf] with d/2 channels -> out [B*N, ldo], d/2 channels;
  * mode 2 = gather + mlp1 + mlp2 + att_pooling_2: f = the output of mode 1 -> out with d channels.
- * xyz [B,N,3] float32, nei [B,N,16] indices inside the frame, w1 [d/2, ldw1 >= 10] / b1 float32 (BatchNorm folded), w2 [d/2, d/2],
- * wfc [d, d], wm [cout, d] of dtype (0 = float32, 1 = bfloat16 rows), b2 / bm float32; act* 0/1/2 = none / ReLU / LeakyReLU(0.2);
+ * xyz4 = coordinate table of 16-byte rows {x, y, z, -} float32, point n of frame b at row b * xyz_frame_stride + n (a level that
+ * is the prefix of a finer one shares its table: stride = the finer level's N); nei [B,N,16] indices inside the frame,
+ * w1 [d/2, ldw1 >= 10] / b1 float32 (BatchNorm folded), w2 [d/2, d/2],
+ * wfc [d, d] of dtype (0 = float32, 1 = bfloat16 rows), wm_kc = the [cout, d] weight of the output MLP re-laid as
+ * [d / VL, cout, VL] (VL = 4 float32 / 8 bfloat16: 16 bytes of consecutive k per channel, so that the per-channel dot products of
+ * the output MLP read it coalesced), b2 / bm float32; act* 0/1/2 = none / ReLU / LeakyReLU(0.2);
  * d in {32, 64, 128, 256}, K = 16.  Neither the encoding, nor the per-pair rows, nor the scores, nor the pooled rows touch HBM
- * (pair rows are staged in LDS, csrc/lfa_pm.hip).  p_hint: 0 = automatic, 1 = 1024/d points per workgroup, 2 = 512/d. */
-int ffb6d_lfa_pm(int dtype, int mode, const float* xyz, const void* nei, int idx_bits, const void* f, int64_t ldf,
+ * (pair rows are staged in LDS, csrc/lfa_pm.hip).  p_hint = size + 4 * w: size 0 = automatic, 1 = 1024/d points per group, 2 = 512/d;
+ * w 0 = automatic, 1 = fc / mlp weights resident in LDS (d <= 64), 2 = streamed from L2. */
+int ffb6d_lfa_pm(int dtype, int mode, const float* xyz4, int64_t xyz_frame_stride, const void* nei, int idx_bits, const void* f, int64_t ldf,
                  const float* w1, int64_t ldw1, const float* b1, int act1, const void* w2, const float* b2, int act2,
-                 const void* wfc, const void* wm, const float* bm, int actm, void* out, int64_t ldo, int64_t B, int64_t N,
+                 const void* wfc, const void* wm_kc, const float* bm, int actm, void* out, int64_t ldo, int64_t B, int64_t N,
                  int K, int64_t d, int p_hint, ffb6d_stream_t stream);
-/* the automatic choice of p_hint 0 (pure host logic): 1 = the half-size point groups */
-int ffb6d_lfa_pm_small_groups(int64_t npts, int64_t d);
+/* the p_hint an automatic launch (p_hint 0) resolves to (pure host logic) */
+int ffb6d_lfa_pm_choice(int64_t npts, int64_t d, int bf16);
 /* Second half of the folded up-convolution (PSPUpsample, pspnet.py:34-45: bilinear x2 with align_corners -> Conv2d 3x3,
  * padding 1 -> BatchNorm -> PReLU).  z [B,IH,IW,9,C] holds, per low-resolution pixel and filter tap (ky*3+kx), the channel
  * mixing (BatchNorm scale * W[:, :, ky, kx]) x -- one ffb6d_mlp_pm GEMM with 9*C output channels -- and

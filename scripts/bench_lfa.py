@@ -35,7 +35,7 @@ for dt in (torch.float32, torch.bfloat16):
     for lvl, d in enumerate((32, 64, 128, 256)):
         N, h = N0 >> (2 * lvl), d // 2
         g = torch.Generator().manual_seed(d)
-        xyz = torch.rand(B, N, 3, generator=g).to(dev)
+        xyz = ops_pm.xyz_table(torch.rand(B, N, 3, generator=g).to(dev))
         # neighbours as the real pyramid has them: nearby in space, scattered in memory
         nei = torch.randint(0, N, (B, N, 16), generator=g).to(IDT).to(dev)
         f = torch.randn(B, N, h, generator=g).to(dt).to(dev)
@@ -54,7 +54,7 @@ for dt in (torch.float32, torch.bfloat16):
             return ops_pm.lfa_half(2, xyz, nei, agg, w1, b1, 2, wfc[1], wm[1], bm[1], 2, w2=w2, b2=b2, act2=2, p_hint=p_hint)
 
         def chain1():
-            g1 = ops_pm.posenc_mlp(xyz, nei, w1, b1, 2, dtype=dt)
+            g1 = ops_pm.posenc_mlp(xyz[..., :3].contiguous(), nei, w1, b1, 2, dtype=dt)
             return ops_pm.mlp(ops_pm.att_pool(f, nei, g1, wfc[0]), wm[0], bm[0], 2), g1
 
         def chain2(g1):
@@ -72,7 +72,7 @@ for dt in (torch.float32, torch.bfloat16):
             nbytes = B * N * (12 + 16 * ib + esz * (h + cout))
             t_ref = timeit(ref)
             line = "%s L%d d=%3d N=%5d half %d: chain %7.1f us |" % ("f32 " if esz == 4 else "bf16", lvl, d, N, mode, t_ref)
-            for ph in (1, 2):
+            for ph in ((1, 2, 9, 10) if d <= 64 else (1, 2)):          # + 8: weights streamed from L2 instead of LDS-resident
                 t = timeit(lambda: fn(ph))
-                line += " P=%2d %7.1f us %6.1f TF %6.0f GB/s |" % (1024 // d // ph, t, flops / t * 1e-6, nbytes / t * 1e-3)
+                line += " P=%2d%s %6.1f us %5.1f TF %4.0f GB/s |" % (1024 // d // (ph & 3), "L2" if ph & 8 else "  ", t, flops / t * 1e-6, nbytes / t * 1e-3)
             print(line + " maxdiff vs chain %.1e" % (e1 if mode == 1 else e2), flush=True)

@@ -16,7 +16,7 @@ B, d = 8, 32 << lvl
 N, h = 12288 >> (2 * lvl), d // 2
 cout = h if mode == 1 else d
 g = torch.Generator().manual_seed(d)
-xyz = torch.rand(B, N, 3, generator=g).to(dev)
+xyz = ops_pm.xyz_table(torch.rand(B, N, 3, generator=g).to(dev))
 nei = torch.randint(0, N, (B, N, 16), generator=g).to(dev)
 f = torch.randn(B, N, h, generator=g).to(dt).to(dev)
 w1, b1 = (torch.randn(h, 10, generator=g) / 2).to(dev), (torch.randn(h, generator=g) / 2).to(dev)

@@ -167,7 +167,7 @@ def _lfa_case(B, N, d, mode, dt, idt, seed):
 # one launch per half of the local feature aggregation (csrc/lfa_pm.hip): both halves, both group sizes of every width, both
 # index types, ragged tails (N not a multiple of the points per workgroup, groups that straddle two frames)
 @pytest.mark.parametrize("B,N,d,p_hint", [(2, 70, 32, 1), (1, 37, 32, 2), (2, 41, 64, 1), (1, 19, 64, 2), (2, 13, 128, 1), (1, 9, 128, 2),
-                                          (1, 7, 256, 1), (2, 3, 256, 2)])
+                                          (1, 7, 256, 1), (2, 3, 256, 2), (2, 70, 32, 9), (2, 41, 64, 10)])     # + 8: weights from L2
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_fused_lfa_half_on_the_emulator(emu, B, N, d, p_hint, mode, dt):
@@ -183,6 +183,30 @@ def test_fused_lfa_half_on_the_emulator(emu, B, N, d, p_hint, mode, dt):
     assert got.shape == want.shape and got.dtype == dt
     tol = 1e-5 if dt == torch.float32 else 2e-2
     assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max())
+
+
+@pytest.mark.parametrize("B,N,d,p_hint,mode", [(2, 300, 32, 2, 1), (2, 300, 32, 2, 2), (1, 45, 256, 2, 2), (3, 50, 64, 1, 1)])
+def test_fused_lfa_persistent_loop_on_the_emulator(emu, monkeypatch, B, N, d, p_hint, mode):
+    """the software pipeline over the point groups of a workgroup (indices two groups ahead, gathered rows one group ahead):
+    one workgroup per XCD, so every workgroup walks several groups, the last ones ragged"""
+    from oracle import ops_ref
+    monkeypatch.setenv("FFB6D_LFA_WG_PER_XCD", "1")
+    a = _lfa_case(B, N, d, mode, torch.float32, torch.int64, seed=N + d)
+    kw = dict(w2=a["w2"], b2=a["b2"], act2=2) if mode == 2 else {}
+    got = ops_pm.lfa_half(mode, a["xyz"], a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2, p_hint=p_hint, **kw)
+    want = ops_ref.lfa_half(mode, a["xyz"], a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2, **kw)
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_fused_lfa_reads_a_level_as_the_prefix_of_a_finer_coordinate_table(emu):
+    """cld_xyz{i+1} is the first quarter of cld_xyz{i} (linemod_dataset.py:322-323): the coarser level gathers its coordinates
+    from the finer level's table through the frame stride, no copy"""
+    a = _lfa_case(3, 40, 32, 1, torch.float32, torch.int64, seed=5)
+    big = torch.rand(3, 160, 3)
+    big[:, :40] = a["xyz"]
+    table = ops_pm.xyz_table(big)
+    args = (a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2)
+    assert torch.equal(ops_pm.lfa_half(1, table[:, :40], *args), ops_pm.lfa_half(1, a["xyz"], *args))
 
 
 def test_emulated_library_reports_argument_errors_like_the_product(emu):
