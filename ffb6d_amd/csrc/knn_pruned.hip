@@ -26,6 +26,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -90,11 +91,9 @@ __device__ __forceinline__ float ord2f(int o) { return __int_as_float(o ^ ((o >>
 
 // per-frame bounding box -> quantisation frame {lo.xyz, 0, scale.xyz, 0}; one 1024-thread
 // block per frame (a frame is at most a few hundred thousand points)
-__global__ void __launch_bounds__(1024)
-frame_kernel(const float* __restrict__ pts, int S, float* __restrict__ frame)
+__device__ __forceinline__ void frame_body(const float* __restrict__ pts, int S, float* __restrict__ frame, int b)
 {
     __shared__ float red[6][16];
-    const int b = blockIdx.x;
     const float* p = pts + (size_t)b * S * 3;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = threadIdx.x; i < S; i += 1024) {
@@ -130,6 +129,12 @@ frame_kernel(const float* __restrict__ pts, int S, float* __restrict__ frame)
     if (threadIdx.x == 3) { frame[b * 8 + 3] = 0.f; frame[b * 8 + 7] = 0.f; }
 }
 
+__global__ void __launch_bounds__(1024)
+frame_kernel(const float* __restrict__ pts, int S, float* __restrict__ frame)
+{
+    frame_body(pts, S, frame, blockIdx.x);
+}
+
 __device__ __forceinline__ uint32_t spread10(uint32_t v)
 {
     v &= 0x3ffu;
@@ -149,26 +154,31 @@ __device__ __forceinline__ uint32_t morton_key(float x, float y, float z, const 
     return spread10((uint32_t)cx) | (spread10((uint32_t)cy) << 1) | (spread10((uint32_t)cz) << 2);
 }
 
-__global__ void __launch_bounds__(BLK)
-morton_kernel(const float* __restrict__ pts, int S, const float* __restrict__ frame,
-              unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+// `seg` = the sort segment of frame b: keys of one segment stay together and in segment order
+__device__ __forceinline__ void morton_body(const float* __restrict__ pts, int S, const float* __restrict__ frame,
+                                            unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, int b, unsigned seg)
 {
-    const int b = blockIdx.y;
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= S) return;
     const float* p = pts + ((size_t)b * S + i) * 3;
     const uint32_t k = morton_key(p[0], p[1], p[2], frame + b * 8);
-    keys[(size_t)b * S + i] = ((unsigned long long)b << 32) | k;
+    keys[(size_t)b * S + i] = ((unsigned long long)seg << 32) | k;
     vals[(size_t)b * S + i] = (uint32_t)i;
 }
 
-// one wave per tile: gather the sorted points, build the tile box
 __global__ void __launch_bounds__(BLK)
-gather_box_kernel(const float* __restrict__ pts, int S, int S_pad, int nt,
-                  const unsigned long long* __restrict__ skeys, const uint32_t* __restrict__ perm,
-                  float4* __restrict__ out_pts, float4* __restrict__ boxes, uint32_t* __restrict__ out_keys)
+morton_kernel(const float* __restrict__ pts, int S, const float* __restrict__ frame,
+              unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
 {
-    const int b = blockIdx.y;
+    morton_body(pts, S, frame, keys, vals, blockIdx.y, blockIdx.y);
+}
+
+// one wave per tile: gather the sorted points, build the tile box
+__device__ __forceinline__ void gather_box_body(const float* __restrict__ pts, int S, int S_pad, int nt,
+                                                const unsigned long long* __restrict__ skeys, const uint32_t* __restrict__ perm,
+                                                float4* __restrict__ out_pts, float4* __restrict__ boxes,
+                                                uint32_t* __restrict__ out_keys, int b)
+{
     const int t = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     if (t >= nt) return;
     const int lane = threadIdx.x & 63;
@@ -199,11 +209,17 @@ gather_box_kernel(const float* __restrict__ pts, int S, int S_pad, int nt,
     }
 }
 
-// level-2 boxes: the hull of FAN consecutive tile boxes
 __global__ void __launch_bounds__(BLK)
-box2_kernel(const float4* __restrict__ boxes, int nt, int nt2, float4* __restrict__ boxes2)
+gather_box_kernel(const float* __restrict__ pts, int S, int S_pad, int nt,
+                  const unsigned long long* __restrict__ skeys, const uint32_t* __restrict__ perm,
+                  float4* __restrict__ out_pts, float4* __restrict__ boxes, uint32_t* __restrict__ out_keys)
 {
-    const int b = blockIdx.y;
+    gather_box_body(pts, S, S_pad, nt, skeys, perm, out_pts, boxes, out_keys, blockIdx.y);
+}
+
+// level-2 boxes: the hull of FAN consecutive tile boxes
+__device__ __forceinline__ void box2_body(const float4* __restrict__ boxes, int nt, int nt2, float4* __restrict__ boxes2, int b)
+{
     const int g = blockIdx.x * BLK + threadIdx.x;
     if (g >= nt2) return;
     float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
@@ -216,11 +232,16 @@ box2_kernel(const float4* __restrict__ boxes, int nt, int nt2, float4* __restric
     boxes2[((size_t)b * nt2 + g) * 2 + 1] = hi;
 }
 
-// cell -> index of the tile that holds the first point whose key is >= (cell << CELL_SHIFT)
 __global__ void __launch_bounds__(BLK)
-cell_table_kernel(const uint32_t* __restrict__ keys, int S, int S_pad, int nt, uint32_t* __restrict__ table)
+box2_kernel(const float4* __restrict__ boxes, int nt, int nt2, float4* __restrict__ boxes2)
 {
-    const int b = blockIdx.y;
+    box2_body(boxes, nt, nt2, boxes2, blockIdx.y);
+}
+
+// cell -> index of the tile that holds the first point whose key is >= (cell << CELL_SHIFT)
+__device__ __forceinline__ void cell_table_body(const uint32_t* __restrict__ keys, int S, int S_pad, int nt,
+                                                uint32_t* __restrict__ table, int b)
+{
     const int c = blockIdx.x * BLK + threadIdx.x;
     if (c >= NCELL) return;
     const uint32_t* k = keys + (size_t)b * S_pad;
@@ -231,6 +252,65 @@ cell_table_kernel(const uint32_t* __restrict__ keys, int S, int S_pad, int nt, u
         if (k[mid] < want) lo = mid + 1; else hi = mid;
     }
     table[(size_t)b * NCELL + c] = (uint32_t)min(lo / PT, nt - 1);
+}
+
+__global__ void __launch_bounds__(BLK)
+cell_table_kernel(const uint32_t* __restrict__ keys, int S, int S_pad, int nt, uint32_t* __restrict__ table)
+{
+    cell_table_body(keys, S, S_pad, nt, table, blockIdx.y);
+}
+
+// ---- several point sets in one go (the 22 searches of an index pyramid touch a handful of sets, all known up front:
+// linemod_dataset.py:299-353): blockIdx.z = set, the kernels above with one more grid dimension, and ONE radix sort over the
+// concatenation of all sets with the sort segment (set, frame) in the key's high bits -- a handful of launches instead of
+// a dozen per set, and the sort's fixed costs are paid once.
+constexpr int MAX_SETS = 8;
+struct SetDesc {
+    const float* pts;
+    float4 *out_pts, *boxes, *boxes2;
+    uint32_t *out_keys, *cell;
+    float* frame;
+    int S, S_pad, nt, nt2;
+    long long pos0;       // first element of the set in the concatenated key / value arrays
+};
+struct MultiDesc {
+    SetDesc s[MAX_SETS];
+    int B;
+};
+
+__global__ void __launch_bounds__(1024)
+frame_multi_kernel(const MultiDesc m)
+{
+    const SetDesc& d = m.s[blockIdx.y];
+    frame_body(d.pts, d.S, d.frame, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(BLK)
+morton_multi_kernel(const MultiDesc m, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const SetDesc& d = m.s[blockIdx.z];
+    morton_body(d.pts, d.S, d.frame, keys + d.pos0, vals + d.pos0, blockIdx.y, blockIdx.z * m.B + blockIdx.y);
+}
+
+__global__ void __launch_bounds__(BLK)
+gather_box_multi_kernel(const MultiDesc m, const unsigned long long* __restrict__ skeys, const uint32_t* __restrict__ perm)
+{
+    const SetDesc& d = m.s[blockIdx.z];
+    gather_box_body(d.pts, d.S, d.S_pad, d.nt, skeys + d.pos0, perm + d.pos0, d.out_pts, d.boxes, d.out_keys, blockIdx.y);
+}
+
+__global__ void __launch_bounds__(BLK)
+box2_multi_kernel(const MultiDesc m)
+{
+    const SetDesc& d = m.s[blockIdx.z];
+    box2_body(d.boxes, d.nt, d.nt2, d.boxes2, blockIdx.y);
+}
+
+__global__ void __launch_bounds__(BLK)
+cell_table_multi_kernel(const MultiDesc m)
+{
+    const SetDesc& d = m.s[blockIdx.z];
+    cell_table_body(d.out_keys, d.S, d.S_pad, d.nt, d.cell, blockIdx.y);
 }
 
 // ---------------------------------------------------------------- search --------------
@@ -652,17 +732,19 @@ struct PrepWs {
     size_t keys_in, keys_out, vals_in, vals_out, bbox, temp, temp_bytes, total;
 };
 
-PrepWs prep_ws(int64_t B, int64_t S)
+PrepWs prep_ws_n(size_t n);
+PrepWs prep_ws(int64_t B, int64_t S) { return prep_ws_n((size_t)B * S); }
+
+PrepWs prep_ws_n(size_t n)
 {
     PrepWs w;
-    const size_t n = (size_t)B * S;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) / 256 * 256; return r; };
     w.keys_in = take(n * 8);
     w.keys_out = take(n * 8);
     w.vals_in = take(n * 4);
     w.vals_out = take(n * 4);
-    w.bbox = take((size_t)B * 6 * 4);
+    w.bbox = take(4096);                       /* unused (frames live in the prepared blob) */
     w.temp_bytes = sort_temp_bound(n);
     w.temp = take(w.temp_bytes);
     w.total = o;
@@ -734,6 +816,71 @@ int ffb6d_knn_prepare(const float* pts, int64_t B, int64_t S, void* prepared, si
     hipLaunchKernelGGL(cell_table_kernel, dim3(NCELL / BLK, (unsigned)B), dim3(BLK), 0, st,
                        reinterpret_cast<const uint32_t*>(pp + L.key_off), (int)S, (int)L.S_pad, (int)L.nt,
                        reinterpret_cast<uint32_t*>(pp + L.cell_off));
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+size_t ffb6d_knn_prepare_multi_workspace_bytes(int nsets, const int64_t* npts, int64_t B)
+{
+    if (nsets <= 0 || !npts || B <= 0) return 0;
+    size_t n = 0;
+    for (int i = 0; i < nsets; ++i) n += (size_t)B * (size_t)(npts[i] > 0 ? npts[i] : 0);
+    return prep_ws_n(n).total;
+}
+
+int ffb6d_knn_prepare_multi(int nsets, const float* const* pts, const int64_t* npts, int64_t B, void* const* prepared,
+                            const size_t* prepared_bytes, void* workspace, size_t workspace_bytes, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(nsets >= 1 && nsets <= MAX_SETS, "knn_prepare_multi: 1..%d sets per call (got %d)", MAX_SETS, nsets);
+    FFB6D_REQUIRE(pts && npts && prepared && prepared_bytes && workspace, "knn_prepare_multi: null pointer");
+    FFB6D_REQUIRE(B >= 1 && B * (int64_t)nsets < 65536, "knn_prepare_multi: bad batch size");
+    MultiDesc m;
+    m.B = (int)B;
+    size_t n = 0;
+    int64_t S_max = 0, nt_max = 0, nt2_max = 0;
+    for (int i = 0; i < nsets; ++i) {
+        FFB6D_REQUIRE(npts[i] >= 1 && npts[i] < (1LL << 31) && pts[i] && prepared[i], "knn_prepare_multi: set %d is empty or null", i);
+        const Layout L = layout(B, npts[i]);
+        if (prepared_bytes[i] < L.total)
+            return set_error(FFB6D_ERR_WORKSPACE, "knn_prepare_multi: set %d needs %zu prepared bytes, got %zu", i, L.total, prepared_bytes[i]);
+        char* pp = static_cast<char*>(prepared[i]);
+        SetDesc& d = m.s[i];
+        d.pts = pts[i];
+        d.out_pts = reinterpret_cast<float4*>(pp + L.pts_off);
+        d.boxes = reinterpret_cast<float4*>(pp + L.box_off);
+        d.boxes2 = reinterpret_cast<float4*>(pp + L.box2_off);
+        d.out_keys = reinterpret_cast<uint32_t*>(pp + L.key_off);
+        d.cell = reinterpret_cast<uint32_t*>(pp + L.cell_off);
+        d.frame = reinterpret_cast<float*>(pp + L.frame_off);
+        d.S = (int)npts[i]; d.S_pad = (int)L.S_pad; d.nt = (int)L.nt; d.nt2 = (int)L.nt2;
+        d.pos0 = (long long)n;
+        n += (size_t)B * (size_t)npts[i];
+        S_max = std::max<int64_t>(S_max, npts[i]); nt_max = std::max<int64_t>(nt_max, L.nt); nt2_max = std::max<int64_t>(nt2_max, L.nt2);
+    }
+    const PrepWs W = prep_ws_n(n);
+    if (workspace_bytes < W.total)
+        return set_error(FFB6D_ERR_WORKSPACE, "knn_prepare_multi: need %zu workspace bytes, got %zu", W.total, workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto* keys_in = reinterpret_cast<unsigned long long*>(ws + W.keys_in);
+    auto* keys_out = reinterpret_cast<unsigned long long*>(ws + W.keys_out);
+    auto* vals_in = reinterpret_cast<uint32_t*>(ws + W.vals_in);
+    auto* vals_out = reinterpret_cast<uint32_t*>(ws + W.vals_out);
+    const unsigned ns = (unsigned)nsets, nb = (unsigned)B;
+    hipLaunchKernelGGL(frame_multi_kernel, dim3(nb, ns), dim3(1024), 0, st, m);
+    hipLaunchKernelGGL(morton_multi_kernel, dim3((unsigned)ceil_div(S_max, BLK), nb, ns), dim3(BLK), 0, st, m, keys_in, vals_in);
+    FFB6D_LAUNCH_CHECK();
+    unsigned end_bit = 32;
+    while ((1LL << (end_bit - 32)) < B * nsets) ++end_bit;
+    size_t need = 0;
+    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
+    if (need > W.temp_bytes)
+        return set_error(FFB6D_ERR_WORKSPACE, "knn_prepare_multi: radix sort wants %zu temp bytes, reserved %zu", need, W.temp_bytes);
+    size_t have = W.temp_bytes;
+    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(ws + W.temp, have, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
+    hipLaunchKernelGGL(gather_box_multi_kernel, dim3((unsigned)ceil_div(nt_max, BLK / 64), nb, ns), dim3(BLK), 0, st, m, keys_out, vals_out);
+    hipLaunchKernelGGL(box2_multi_kernel, dim3((unsigned)ceil_div(nt2_max, BLK), nb, ns), dim3(BLK), 0, st, m);
+    hipLaunchKernelGGL(cell_table_multi_kernel, dim3(NCELL / BLK, nb, ns), dim3(BLK), 0, st, m);
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }

@@ -102,6 +102,44 @@ class PreparedPoints:
         _lib.check(rc, "ffb6d_knn_prepare")
 
 
+def prepare_many(point_sets):
+    """Several point sets [B,S_i,3] (same B, same device) -> list of PreparedPoints, prepared TOGETHER by
+    ffb6d_knn_prepare_multi: one Morton sort over the concatenation of all sets and one launch per remaining pass, instead
+    of a dozen launches per set.  Byte-identical to PreparedPoints(p) for every p."""
+    import ctypes
+
+    import torch
+
+    lib = _lib.load()
+    sets = [p.contiguous() for p in point_sets]
+    if not sets:
+        return []
+    B, dev = int(sets[0].shape[0]), sets[0].device
+    for p in sets:
+        if not p.is_cuda or p.dtype != torch.float32 or p.dim() != 3 or p.shape[2] != 3 or p.shape[0] != B or p.device != dev or p.shape[1] < 1:
+            raise TypeError("prepare_many: float32 [B,S,3] GPU tensors of one batch size on one device")
+    out = []
+    for lo in range(0, len(sets), 8):                       # at most 8 sets per call
+        chunk = sets[lo:lo + 8]
+        n = len(chunk)
+        S = (ctypes.c_int64 * n)(*[int(p.shape[1]) for p in chunk])
+        nbytes = [lib.ffb6d_knn_prepared_bytes(B, int(p.shape[1])) for p in chunk]
+        blobs = [torch.empty((nb,), dtype=torch.uint8, device=dev) for nb in nbytes]
+        wbytes = lib.ffb6d_knn_prepare_multi_workspace_bytes(n, S, B)
+        ws = torch.empty((wbytes,), dtype=torch.uint8, device=dev)
+        pts = (ctypes.c_void_p * n)(*[p.data_ptr() for p in chunk])
+        prep = (ctypes.c_void_p * n)(*[b.data_ptr() for b in blobs])
+        pbytes = (ctypes.c_size_t * n)(*nbytes)
+        with torch.cuda.device(dev), _lib.traced("knn_prepare", 12 * B * sum(int(p.shape[1]) for p in chunk), tuple(int(p.shape[1]) for p in chunk)):
+            rc = lib.ffb6d_knn_prepare_multi(n, pts, S, B, prep, pbytes, ws.data_ptr(), wbytes, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "ffb6d_knn_prepare_multi")
+        for p, blob in zip(chunk, blobs):
+            pp = PreparedPoints.__new__(PreparedPoints)
+            pp.points, pp.B, pp.S, pp.blob = p, B, int(p.shape[1]), blob
+            out.append(pp)
+    return out
+
+
 def knn_prepared(support, query, K, dtype=None, return_dist=False):
     """Exact KNN of `query` in a PreparedPoints `support` (same results as knn_batch_device).
     `query` is a PreparedPoints or -- for 2 <= K <= 16 -- a raw float32 [B,Q,3] GPU tensor."""

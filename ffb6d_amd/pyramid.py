@@ -16,7 +16,7 @@ grid[s] = xyz image at stride s, pixel (y*s, x*s), flattened row-major (:299-311
 """
 import torch
 
-from .nearest_neighbors import PreparedPoints, knn_batch_device, knn_prepared, uses_pruning
+from .nearest_neighbors import knn_batch_device, knn_prepared, prepare_many, uses_pruning
 
 RGB_DS_SR = (4, 8, 8, 8)
 RGB_UP_SR = (4, 2, 2)
@@ -35,58 +35,68 @@ def strided_grid(dpt_xyz, s):
 class PyramidBuilder:
     """The pyramid level by level, so that a consumer can start on level 0 while the later levels are still being
     searched (forward_pm.forward enqueues the levels on their own HIP stream): `encoder_level(i)` for i = 0..3 in
-    order, then `decoder_level(i)` for i = 0..2.  Each returns the keys of that level."""
+    order, then `decoder_level(i)` for i = 0..2.  Each returns the keys of that level.
+
+    All 22 searches read only the cloud and the xyz image, so every point set is known up front: the four cloud levels
+    (prefixes of the cloud, linemod_dataset.py:322-323), the prefix below the last one, and the image grids at strides 2, 4
+    and 8.  The sets that go through the Morton-ordered search are prepared TOGETHER when the builder is created
+    (nearest_neighbors.prepare_many: one sort, a handful of launches), before the first level is searched."""
 
     def __init__(self, cld, dpt_xyz, index_dtype=torch.int64):
         if cld.dim() != 3 or cld.shape[2] != 3 or dpt_xyz.dim() != 4 or dpt_xyz.shape[1] != 3:
             raise ValueError(f"bad shapes {tuple(cld.shape)} / {tuple(dpt_xyz.shape)}")
         self.B = cld.shape[0]
         self.index_dtype = index_dtype
-        self.dpt_xyz = dpt_xyz
-        self.grids = {}
-        self.prepared = {}
-        self.cur = cld.contiguous()
-        self.xyz = []
+        cur = cld.contiguous()
+        self.sets = {('c', 0): cur}                         # ('c', i) = cloud level i (i = 4: the prefix below level 3)
+        for i in range(4):
+            cur = cur[:, :cur.shape[1] // SUB_RATIO[i], :].contiguous()
+            self.sets[('c', i + 1)] = cur
+        for s in sorted(set(RGB_DS_SR) | set(RGB_UP_SR)):
+            self.sets[('g', s)] = strided_grid(dpt_xyz, s)  # ('g', s) = image grid at stride s
+        # the searches, level by level: (output key, support set, query set, K)
+        self.plan = []
+        for i in range(4):
+            c, sub, g = ('c', i), ('c', i + 1), ('g', RGB_DS_SR[i])
+            self.plan.append([('cld_nei_idx%d' % i, c, c, K_NEI), ('cld_interp_idx%d' % i, sub, c, 1),
+                              ('r2p_ds_nei_idx%d' % i, g, sub, K_NEI), ('p2r_ds_nei_idx%d' % i, sub, g, 1)])
+        for i in range(3):
+            g, pts = ('g', RGB_UP_SR[i]), ('c', 3 - i)
+            self.plan.append([('r2p_up_nei_idx%d' % i, g, pts, K_NEI), ('p2r_up_nei_idx%d' % i, pts, g, 1)])
+        # sets the pruned search wants in Morton order: every support of such a search, and its queries when K = 1 (the
+        # 16-lane rows of the K >= 2 kernel take unsorted queries)
+        need = []
+        for level in self.plan:
+            for _, sup, qry, k in level:
+                if uses_pruning(self.B, self.sets[sup].shape[1], self.sets[qry].shape[1], k):
+                    for key in (sup,) + ((qry,) if k < 2 else ()):
+                        if key not in need:
+                            need.append(key)
+        self.prepared = dict(zip(need, prepare_many([self.sets[k] for k in need])))
+        self.n_levels = 0
 
-    def grid(self, s):
-        if s not in self.grids:
-            self.grids[s] = strided_grid(self.dpt_xyz, s)
-        return self.grids[s]
-
-    def search(self, support, query, k):
-        """Route big supports through Morton-prepared sets (each set is sorted once and reused by
-        every search that touches it), small ones through the brute-force scan."""
-        prepared = self.prepared
+    def search(self, sup, qry, k):
+        support, query = self.sets[sup], self.sets[qry]
         if not uses_pruning(self.B, support.shape[1], query.shape[1], k):
             return knn_batch_device(support, query, k, dtype=self.index_dtype)
-        if id(support) not in prepared:
-            prepared[id(support)] = PreparedPoints(support)
-        if k >= 2 and id(query) not in prepared:
-            # 16-lane rows work on one query each: unsorted queries are fine, skip their sort
-            return knn_prepared(prepared[id(support)], query, k, dtype=self.index_dtype)
-        if id(query) not in prepared:
-            prepared[id(query)] = PreparedPoints(query)
-        return knn_prepared(prepared[id(support)], prepared[id(query)], k, dtype=self.index_dtype)
+        return knn_prepared(self.prepared[sup], self.prepared.get(qry, query), k, dtype=self.index_dtype)
+
+    def _level(self, j):
+        assert j == self.n_levels, "levels are built in order"
+        self.n_levels += 1
+        return {name: self.search(sup, qry, k) for name, sup, qry, k in self.plan[j]}
 
     def encoder_level(self, i):
-        assert i == len(self.xyz), "levels are built in order"
-        cur = self.cur
-        n_sub = cur.shape[1] // SUB_RATIO[i]
-        nei = self.search(cur, cur, K_NEI)
-        sub = cur[:, :n_sub, :].contiguous()
-        g = self.grid(RGB_DS_SR[i])
-        out = {'cld_xyz%d' % i: cur, 'cld_nei_idx%d' % i: nei, 'cld_sub_idx%d' % i: nei[:, :n_sub, :].contiguous(),
-               'cld_interp_idx%d' % i: self.search(sub, cur, 1),
-               'r2p_ds_nei_idx%d' % i: self.search(g, sub, K_NEI), 'p2r_ds_nei_idx%d' % i: self.search(sub, g, 1)}
-        self.xyz.append(cur)
-        self.cur = sub
+        out = self._level(i)
+        nei = out['cld_nei_idx%d' % i]
+        n_sub = self.sets[('c', i + 1)].shape[1]
+        out['cld_xyz%d' % i] = self.sets[('c', i)]
+        out['cld_sub_idx%d' % i] = nei[:, :n_sub, :].contiguous()
         return out
 
     def decoder_level(self, i):
-        assert len(self.xyz) == 4, "decoder levels come after the four encoder levels"
-        g = self.grid(RGB_UP_SR[i])
-        pts = self.xyz[3 - i]
-        return {'r2p_up_nei_idx%d' % i: self.search(g, pts, K_NEI), 'p2r_up_nei_idx%d' % i: self.search(pts, g, 1)}
+        assert self.n_levels >= 4, "decoder levels come after the four encoder levels"
+        return self._level(4 + i)
 
 
 def build_index_pyramid(cld, dpt_xyz, index_dtype=torch.int64):

@@ -115,6 +115,13 @@ size_t ffb6d_knn_prepare_workspace_bytes(int64_t batch_size, int64_t npts);
 int ffb6d_knn_prepare(const float* points /* [B,npts,3] device */, int64_t batch_size, int64_t npts,
                       void* prepared, size_t prepared_bytes, void* workspace, size_t workspace_bytes,
                       ffb6d_stream_t stream);
+
+/* Several point sets prepared together (one Morton sort over their concatenation, every other pass with the set as one more
+ * grid dimension): pts[i] [B,npts[i],3], prepared[i] of ffb6d_knn_prepared_bytes(B, npts[i]) bytes, i < nsets <= 8; the results
+ * are byte-identical to nsets calls of ffb6d_knn_prepare. */
+size_t ffb6d_knn_prepare_multi_workspace_bytes(int nsets, const int64_t* npts, int64_t batch_size);
+int ffb6d_knn_prepare_multi(int nsets, const float* const* pts, const int64_t* npts, int64_t batch_size, void* const* prepared,
+                            const size_t* prepared_bytes, void* workspace, size_t workspace_bytes, ffb6d_stream_t stream);
 /* Queries: either a prepared set (prepared_query) or, for 2 <= K <= 16, the raw [B,nqueries,3]
  * device array (raw_query, prepared_query = NULL) -- small query sets need no preparation. */
 int ffb6d_knn_search_prepared(const void* prepared_support, const void* prepared_query,

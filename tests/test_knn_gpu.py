@@ -173,6 +173,19 @@ def test_prepared_sets_and_raw_queries_agree_with_the_oracle(device):
         nn.knn_prepared(ps, q_dev, 1)                                                     # raw needs 2 <= K <= 16
 
 
+def test_sets_prepared_together_equal_sets_prepared_one_by_one(device):
+    """ffb6d_knn_prepare_multi (one Morton sort over the concatenation of all sets, the set as one more grid dimension of
+    every other pass) writes byte-identical prepared sets to ffb6d_knn_prepare -- what the index-pyramid builder relies on"""
+    rng = np.random.RandomState(5)
+    sets = [torch.from_numpy(rng.rand(3, n, 3).astype(np.float32) * s).to(device) for n, s in ((5000, 1.0), (64, 3.0), (2049, 0.5), (777, 1.0))]
+    sets.append(sets[0][:, :1250].contiguous())                     # a prefix level, as in the pyramid
+    many = nn.prepare_many(sets)
+    for p, m in zip(sets, many):
+        one = nn.PreparedPoints(p)
+        assert m.S == one.S and torch.equal(m.blob[:-256], one.blob[:-256])     # (the last < 256 bytes are alignment padding)
+    assert len(nn.prepare_many(sets * 2)) == 10                     # more than 8 sets: chunked
+
+
 def test_distance_pick_matches_reference_goldens_and_oracle(device, monkeypatch):
     """cpp_knn_batch_distance_pick[_omp] (knn_.h:21-27) through the C ABI: bit-exact against the reference's own
     output (knn_pick_small.npz, clock pinned) and against the oracle on a bigger frame."""

@@ -444,6 +444,26 @@ def test_index_pyramid_of_a_frame_on_the_emulator_equals_the_oracle(emu):
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
 
 
+def test_pyramid_builder_with_sets_prepared_together_on_the_emulator(emu):
+    """pyramid.PyramidBuilder: the searches planned up front, their Morton-ordered sets prepared together
+    (ffb6d_knn_prepare_multi), then level by level -- every tensor equals the CPU oracle's pyramid; the prepared sets are
+    byte-identical to sets prepared one by one"""
+    import numpy as np
+    from ffb6d_amd import nearest_neighbors as nn
+    from ffb6d_amd import pyramid, synth
+    from oracle import knn as oknn
+    from oracle import pyramid as opyr
+    frames = synth.make_batch(4, 2, n_points=8192, height=120, width=160)      # 8192 / 2048 points: pruned searches; the rest scans
+    want = opyr.build_batch(frames, oknn.knn_search)
+    got = pyramid.build_index_pyramid(torch.from_numpy(frames['cld']), torch.from_numpy(frames['dpt_xyz']), index_dtype=torch.int32)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        np.testing.assert_array_equal(got[k].numpy().astype(want[k].dtype), want[k], err_msg=k)
+    sets = [torch.from_numpy(frames['cld']), torch.from_numpy(frames['cld'][:, :2048].copy())]
+    for p, m in zip(sets, nn.prepare_many(sets)):
+        assert torch.equal(m.blob[:-256], nn.PreparedPoints(p).blob[:-256])      # (the last < 256 bytes are alignment padding)
+
+
 @pytest.mark.parametrize("B,H,W,C,dt", [(2, 12, 16, 64, torch.float32), (1, 7, 9, 8, torch.float32), (1, 1, 1, 16, torch.float32),
                                         (2, 10, 6, 16, torch.bfloat16)])
 def test_fused_stem_pass_on_the_emulator(emu, B, H, W, C, dt):
