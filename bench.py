@@ -483,7 +483,10 @@ def main():
             # exact KNN is VALU/latency bound, not HBM bound: brute-force-equivalent pairs/s, and the pairs
             # the pruned search really evaluated (device counter, one extra untimed pyramid) against the fp32 VALU roof
             recs = full.records["knn"]
-            pairs = sum(tag[0] * tag[1] for _, _, _, tag in recs) * args.batch
+
+            def triples(tag):       # one (S, Q, K) per search; a batched call (search_many) carries a tuple of them
+                return list(tag) if tag and isinstance(tag[0], tuple) else [tag]
+            pairs = sum(t[0] * t[1] for _, _, _, tag in recs for t in triples(tag)) * args.batch
             sec = summary["knn"]["total_ms"] * 1e-3
             ops_table["knn"]["bruteforce_equivalent_Gpairs_per_s"] = pairs / sec / 1e9
             lib = _lib.load()
@@ -493,8 +496,8 @@ def main():
             pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
             torch.cuda.synchronize()
             _lib.check(lib.ffb6d_knn_set_pair_counter(None), "ffb6d_knn_set_pair_counter")
-            scanned = sum(tag[0] * tag[1] for _, _, _, tag in recs[:len(recs) // N_FULL]
-                          if not lib.ffb6d_knn_uses_pruning(args.batch, tag[0], tag[1], tag[2])) * args.batch
+            scanned = sum(t[0] * t[1] for _, _, _, tag in recs[:len(recs) // N_FULL] for t in triples(tag)
+                          if not lib.ffb6d_knn_uses_pruning(args.batch, t[0], t[1], t[2])) * args.batch
             evaluated = int(ctr.item()) + scanned
             per_step_s = sec / N_FULL
             ops_table["knn"].update({

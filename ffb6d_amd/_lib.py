@@ -26,6 +26,7 @@ SIGNATURES = {
     "ffb6d_knn_prepare": (_i32, [_vp, _i64, _i64, _vp, _sz, _vp, _sz, _vp]),
     "ffb6d_knn_prepare_multi_workspace_bytes": (_sz, [_i32, _vp, _i64]),
     "ffb6d_knn_prepare_multi": (_i32, [_i32, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "ffb6d_knn_search_multi": (_i32, [_i32, _vp, _i64, _vp]),
     "ffb6d_knn_search_prepared": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "ffb6d_knn_set_pair_counter": (_i32, [_vp]),
     "ffb6d_knn_uses_pruning": (_i32, [_i64, _i64, _i64, _i32]),

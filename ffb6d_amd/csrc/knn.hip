@@ -102,21 +102,19 @@ __device__ __forceinline__ void store_result(const TopK<K>& top, size_t row, int
 
 // grid = (ceil(Q / (256*QPT)), nsplit, B)
 template <int K, int QPT>
-__global__ void __launch_bounds__(KNN_BLOCK)
-knn_scan_kernel(const float* __restrict__ support, const float* __restrict__ query,
-                int S, int Q, int nsplit, int chunk,
-                float* __restrict__ part_d, uint32_t* __restrict__ part_i,
-                int64_t* __restrict__ idx64, int32_t* __restrict__ idx32,
-                float* __restrict__ dist, int Kout)
+__device__ __forceinline__ void
+knn_scan_body(const float* __restrict__ support, const float* __restrict__ query,
+              int S, int Q, int nsplit, int chunk,
+              float* __restrict__ part_d, uint32_t* __restrict__ part_i,
+              int64_t* __restrict__ idx64, int32_t* __restrict__ idx32,
+              float* __restrict__ dist, int Kout, const int bx, const int split, const int b)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* tile = reinterpret_cast<float4*>(smem);
     uint2* queue = reinterpret_cast<uint2*>(smem + KNN_TILE * sizeof(float4));
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int split = blockIdx.y;
-    const int q0 = blockIdx.x * (KNN_BLOCK * QPT);
+    const int q0 = bx * (KNN_BLOCK * QPT);
     const float* sup = support + (size_t)b * S * 3;
     const float* qry = query + (size_t)b * Q * 3;
     const int s_begin = split * chunk;
@@ -223,6 +221,45 @@ knn_scan_kernel(const float* __restrict__ support, const float* __restrict__ que
             }
         }
     }
+}
+
+template <int K, int QPT>
+__global__ void __launch_bounds__(KNN_BLOCK)
+knn_scan_kernel(const float* __restrict__ support, const float* __restrict__ query,
+                int S, int Q, int nsplit, int chunk,
+                float* __restrict__ part_d, uint32_t* __restrict__ part_i,
+                int64_t* __restrict__ idx64, int32_t* __restrict__ idx32,
+                float* __restrict__ dist, int Kout)
+{
+    knn_scan_body<K, QPT>(support, query, S, Q, nsplit, chunk, part_d, part_i, idx64, idx32, dist, Kout, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// several scans in ONE launch (ffb6d_knn_search_multi): blockIdx.x walks the (search, frame, query block) triples of a table
+// in the kernel arguments; every block scans its whole support (supports routed here are short: no split, no merge pass)
+struct ScanArgs {
+    const float *support, *query;
+    int64_t* idx64;
+    int32_t* idx32;
+    float* dist;
+    int S, Q, Kout, gx, blk0;
+};
+constexpr int MAX_SCANS = 16;
+struct MultiScan {
+    ScanArgs a[MAX_SCANS];
+    int n;
+};
+
+template <int K, int QPT>
+__global__ void __launch_bounds__(KNN_BLOCK)
+knn_scan_multi_kernel(const MultiScan m)
+{
+    int sidx = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_SCANS; ++i) sidx += (i < m.n && m.a[i].blk0 <= (int)blockIdx.x) ? 1 : 0;
+    const ScanArgs& a = m.a[sidx];
+    const int local = blockIdx.x - a.blk0;
+    knn_scan_body<K, QPT>(a.support, a.query, a.S, a.Q, 1, a.S, nullptr, nullptr, a.idx64, a.idx32, a.dist, a.Kout, local % a.gx, 0,
+                          local / a.gx);
 }
 
 // merges the nsplit sorted partial lists of a query, in split (= index) order
@@ -363,10 +400,77 @@ void knn_host(const char* who, const float* pts, size_t B, size_t npts, size_t d
         fprintf(stderr, "[ffb6d_amd] %s failed: %s\n", who, ffb6d_last_error());
 }
 
+template <int K>
+int launch_scan_multi(const MultiScan& m, int blocks, hipStream_t st)
+{
+    constexpr int QPT = qpt_for(K);
+    const size_t lds = KNN_TILE * sizeof(float4) + (K > 1 ? (size_t)QPT * KNN_QCAP * KNN_BLOCK * sizeof(uint2) : 0);
+    hipLaunchKernelGGL((knn_scan_multi_kernel<K, QPT>), dim3((unsigned)blocks), dim3(KNN_BLOCK), lds, st, m);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
 }  // namespace
+
+int knn_search_multi_prepared(const ffb6d_knn_search_t* s, const int* which, int n, int64_t B, hipStream_t st);   // knn_pruned.hip
 }  // namespace ffb6d
 
 using namespace ffb6d;
+
+extern "C" int ffb6d_knn_search_multi(int n, const ffb6d_knn_search_t* s, int64_t B, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(n >= 0 && (n == 0 || s) && B >= 1, "knn_search_multi: bad arguments");
+    if (n == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(n <= 64, "knn_search_multi: at most 64 searches per call (got %d)", n);
+    hipStream_t st = as_stream(stream);
+    int pruned[64], np = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = check_shape(B, s[i].S, s[i].Q, 3, s[i].K);
+        if (rc != FFB6D_OK) return rc;
+        FFB6D_REQUIRE(s[i].Q >= 1 && (s[i].idx64 || s[i].idx32 || s[i].dist), "knn_search_multi: search %d has no queries or no output", i);
+        if (ffb6d_knn_uses_pruning(B, s[i].S, s[i].Q, s[i].K)) {
+            FFB6D_REQUIRE(s[i].K <= 16, "knn_search_multi: K > 16 on a long support is not batched (search %d): call ffb6d_knn_search_prepared", i);
+            pruned[np++] = i;
+        } else {
+            FFB6D_REQUIRE(s[i].support && s[i].query, "knn_search_multi: search %d runs the scan kernel and needs the raw arrays", i);
+        }
+    }
+    int rc = knn_search_multi_prepared(s, pruned, np, B, st);
+    if (rc != FFB6D_OK) return rc;
+    const int kps[6] = {1, 2, 4, 8, 16, 32};
+    for (int kp : kps) {
+        MultiScan m;
+        m.n = 0;
+        int blocks = 0;
+        auto flush = [&]() -> int {
+            if (m.n == 0) return FFB6D_OK;
+            int r = FFB6D_OK;
+            switch (kp) {
+                case 1: r = launch_scan_multi<1>(m, blocks, st); break;
+                case 2: r = launch_scan_multi<2>(m, blocks, st); break;
+                case 4: r = launch_scan_multi<4>(m, blocks, st); break;
+                case 8: r = launch_scan_multi<8>(m, blocks, st); break;
+                case 16: r = launch_scan_multi<16>(m, blocks, st); break;
+                default: r = launch_scan_multi<32>(m, blocks, st); break;
+            }
+            m.n = 0;
+            blocks = 0;
+            return r;
+        };
+        for (int i = 0; i < n; ++i) {
+            if (ffb6d_knn_uses_pruning(B, s[i].S, s[i].Q, s[i].K) || pad_k(s[i].K) != kp) continue;
+            ScanArgs& a = m.a[m.n];
+            a.support = s[i].support; a.query = s[i].query; a.idx64 = s[i].idx64; a.idx32 = s[i].idx32; a.dist = s[i].dist;
+            a.S = (int)s[i].S; a.Q = (int)s[i].Q; a.Kout = s[i].K;
+            a.gx = (int)ceil_div(s[i].Q, (int64_t)KNN_BLOCK * qpt_for(kp));
+            a.blk0 = blocks;
+            blocks += a.gx * (int)B;
+            if (++m.n == MAX_SCANS && (rc = flush()) != FFB6D_OK) return rc;
+        }
+        if ((rc = flush()) != FFB6D_OK) return rc;
+    }
+    return FFB6D_OK;
+}
 
 extern "C" {
 

@@ -394,13 +394,13 @@ __device__ __forceinline__ float wave_min(float v)
 // per lane against the wave's query box), surviving tiles fetched with one coalesced load and
 // broadcast through a wave-private LDS slice.
 template <int K>
-__global__ void __launch_bounds__(BLK)
-knn_pruned_kernel(const float4* __restrict__ spts, const float4* __restrict__ boxes,
-                  const uint32_t* __restrict__ skeys, const float* __restrict__ sframe,
-                  const uint32_t* __restrict__ scell, int S, int S_pad, int nt,
-                  const float4* __restrict__ qpts, int Q, int Q_pad,
-                  int64_t* __restrict__ idx64, int32_t* __restrict__ idx32, float* __restrict__ dist,
-                  int Kout)
+__device__ __forceinline__ void
+knn_pruned_body(const float4* __restrict__ spts, const float4* __restrict__ boxes,
+                const uint32_t* __restrict__ skeys, const float* __restrict__ sframe,
+                const uint32_t* __restrict__ scell, int S, int S_pad, int nt,
+                const float4* __restrict__ qpts, int Q, int Q_pad,
+                int64_t* __restrict__ idx64, int32_t* __restrict__ idx32, float* __restrict__ dist,
+                int Kout, const int blk_x, const int b)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* tile_all = reinterpret_cast<float4*>(smem);                               // [4 waves][PT]
@@ -408,8 +408,7 @@ knn_pruned_kernel(const float4* __restrict__ spts, const float4* __restrict__ bo
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     float4* tile = tile_all + (tid >> 6) * PT;
-    const int b = blockIdx.y;
-    const int slot = blockIdx.x * BLK + tid;
+    const int slot = blk_x * BLK + tid;
     const float4 q = qpts[(size_t)b * Q_pad + min(slot, Q_pad - 1)];
     const uint32_t q_orig = __float_as_uint(q.w);
     const bool live = slot < Q_pad && q_orig != 0xffffffffu;
@@ -586,20 +585,19 @@ __device__ __forceinline__ u64 row_shr1(u64 v)         // lane r gets lane r-1 (
 }
 
 template <int K>
-__global__ void __launch_bounds__(BLK)
-knn_row16_kernel(const float4* __restrict__ spts, const float4* __restrict__ boxes,
-                 const float4* __restrict__ boxes2, const float* __restrict__ sframe,
-                 const uint32_t* __restrict__ skeys, int S, int S_pad, int nt, int nt2,
-                 const float4* __restrict__ qpts, const float* __restrict__ qraw, int Q, int Q_pad,
-                 int64_t* __restrict__ idx64, int32_t* __restrict__ idx32, float* __restrict__ dist,
-                 int Kout)
+__device__ __forceinline__ void
+knn_row16_body(const float4* __restrict__ spts, const float4* __restrict__ boxes,
+               const float4* __restrict__ boxes2, const float* __restrict__ sframe,
+               const uint32_t* __restrict__ skeys, int S, int S_pad, int nt, int nt2,
+               const float4* __restrict__ qpts, const float* __restrict__ qraw, int Q, int Q_pad,
+               int64_t* __restrict__ idx64, int32_t* __restrict__ idx32, float* __restrict__ dist,
+               int Kout, const int blk_x, const int b)
 {
     static_assert(K >= 2 && K <= 16, "row kernel holds one rank per lane");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int r = tid & 15;
-    const int b = blockIdx.y;
-    const int qslot = blockIdx.x * (BLK / 16) + (tid >> 4);
+    const int qslot = blk_x * (BLK / 16) + (tid >> 4);
     // queries either Morton-prepared (float4 with the original index in .w) or the caller's raw
     // [B,Q,3] array in its own order: a row works alone, so query order only affects cache locality
     float4 q;
@@ -713,6 +711,81 @@ knn_row16_kernel(const float4* __restrict__ spts, const float4* __restrict__ box
         if (idx32) idx32[o] = (int32_t)id;
         if (dist) dist[o] = __uint_as_float((uint32_t)(L >> 32));
     }
+}
+
+// ---- kernels: one search per launch (grid = (query blocks, B)), or several searches in ONE launch -- the searches of an
+// index pyramid read only the cloud and the xyz image, none depends on another (linemod_dataset.py:299-353), so all searches
+// that run the same kernel go out together: blockIdx.x walks the (search, frame, query block) triples of a table in the
+// kernel arguments.
+struct PrunedArgs {
+    const float4 *spts, *boxes, *boxes2, *qpts;
+    const uint32_t *skeys, *scell;
+    const float *sframe, *qraw;
+    int64_t* idx64;
+    int32_t* idx32;
+    float* dist;
+    int S, S_pad, nt, nt2, Q, Q_pad, Kout;
+    int gx;               // query blocks per frame
+    int blk0;             // first block of this search in the flattened grid
+};
+constexpr int MAX_SEARCHES = 12;
+struct MultiPruned {
+    PrunedArgs a[MAX_SEARCHES];
+    int n;
+};
+
+// search of flattened block `blk`: the last one whose first block is <= blk
+__device__ __forceinline__ int find_search(const MultiPruned& m, int blk)
+{
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_SEARCHES; ++i) s += (i < m.n && m.a[i].blk0 <= blk) ? 1 : 0;
+    return s;
+}
+
+template <int K>
+__global__ void __launch_bounds__(BLK)
+knn_pruned_kernel(const float4* __restrict__ spts, const float4* __restrict__ boxes,
+                  const uint32_t* __restrict__ skeys, const float* __restrict__ sframe,
+                  const uint32_t* __restrict__ scell, int S, int S_pad, int nt,
+                  const float4* __restrict__ qpts, int Q, int Q_pad,
+                  int64_t* __restrict__ idx64, int32_t* __restrict__ idx32, float* __restrict__ dist,
+                  int Kout)
+{
+    knn_pruned_body<K>(spts, boxes, skeys, sframe, scell, S, S_pad, nt, qpts, Q, Q_pad, idx64, idx32, dist, Kout, blockIdx.x, blockIdx.y);
+}
+
+template <int K>
+__global__ void __launch_bounds__(BLK)
+knn_pruned_multi_kernel(const MultiPruned m)
+{
+    const PrunedArgs& a = m.a[find_search(m, blockIdx.x)];
+    const int local = blockIdx.x - a.blk0;
+    knn_pruned_body<K>(a.spts, a.boxes, a.skeys, a.sframe, a.scell, a.S, a.S_pad, a.nt, a.qpts, a.Q, a.Q_pad, a.idx64, a.idx32, a.dist,
+                       a.Kout, local % a.gx, local / a.gx);
+}
+
+template <int K>
+__global__ void __launch_bounds__(BLK)
+knn_row16_kernel(const float4* __restrict__ spts, const float4* __restrict__ boxes,
+                 const float4* __restrict__ boxes2, const float* __restrict__ sframe,
+                 const uint32_t* __restrict__ skeys, int S, int S_pad, int nt, int nt2,
+                 const float4* __restrict__ qpts, const float* __restrict__ qraw, int Q, int Q_pad,
+                 int64_t* __restrict__ idx64, int32_t* __restrict__ idx32, float* __restrict__ dist,
+                 int Kout)
+{
+    knn_row16_body<K>(spts, boxes, boxes2, sframe, skeys, S, S_pad, nt, nt2, qpts, qraw, Q, Q_pad, idx64, idx32, dist, Kout,
+                      blockIdx.x, blockIdx.y);
+}
+
+template <int K>
+__global__ void __launch_bounds__(BLK)
+knn_row16_multi_kernel(const MultiPruned m)
+{
+    const PrunedArgs& a = m.a[find_search(m, blockIdx.x)];
+    const int local = blockIdx.x - a.blk0;
+    knn_row16_body<K>(a.spts, a.boxes, a.boxes2, a.sframe, a.skeys, a.S, a.S_pad, a.nt, a.nt2, a.qpts, a.qraw, a.Q, a.Q_pad, a.idx64,
+                      a.idx32, a.dist, a.Kout, local % a.gx, local / a.gx);
 }
 
 int pad_k(int K)
@@ -945,6 +1018,66 @@ int ffb6d_knn_search_prepared(const void* prep_support, const void* prep_query, 
 }
 
 }  // extern "C"
+
+namespace ffb6d {
+// Searches of `s` (indices `which`, all routed to the Morton-ordered kernels) in as few launches as kernels: one per padded K
+// of the 16-lane row kernel, one for K = 1.  Called by ffb6d_knn_search_multi (csrc/knn.hip).
+int knn_search_multi_prepared(const ffb6d_knn_search_t* s, const int* which, int n, int64_t B, hipStream_t st)
+{
+    const int kps[5] = {1, 2, 4, 8, 16};
+    for (int kp : kps) {
+        MultiPruned m;
+        m.n = 0;
+        int blocks = 0;
+        auto flush = [&]() -> int {
+            if (m.n == 0) return FFB6D_OK;
+            const size_t lds = (size_t)(BLK / 64) * PT * sizeof(float4);
+            switch (kp) {
+                case 1: hipLaunchKernelGGL((knn_pruned_multi_kernel<1>), dim3((unsigned)blocks), dim3(BLK), lds, st, m); break;
+                case 2: hipLaunchKernelGGL((knn_row16_multi_kernel<2>), dim3((unsigned)blocks), dim3(BLK), 0, st, m); break;
+                case 4: hipLaunchKernelGGL((knn_row16_multi_kernel<4>), dim3((unsigned)blocks), dim3(BLK), 0, st, m); break;
+                case 8: hipLaunchKernelGGL((knn_row16_multi_kernel<8>), dim3((unsigned)blocks), dim3(BLK), 0, st, m); break;
+                default: hipLaunchKernelGGL((knn_row16_multi_kernel<16>), dim3((unsigned)blocks), dim3(BLK), 0, st, m); break;
+            }
+            FFB6D_LAUNCH_CHECK();
+            m.n = 0;
+            blocks = 0;
+            return FFB6D_OK;
+        };
+        for (int w = 0; w < n; ++w) {
+            const ffb6d_knn_search_t& q = s[which[w]];
+            if (pad_k(q.K) != kp) continue;
+            FFB6D_REQUIRE(q.prep_support && (q.prep_query || (q.query && q.K >= 2)), "knn_search_multi: search %d needs a prepared support "
+                          "and prepared (K = 1) or raw (K >= 2) queries", which[w]);
+            const Layout LS = layout(B, q.S), LQ = layout(B, q.Q);
+            const char* ps = static_cast<const char*>(q.prep_support);
+            const char* pq = static_cast<const char*>(q.prep_query);
+            PrunedArgs& a = m.a[m.n];
+            a.spts = reinterpret_cast<const float4*>(ps + LS.pts_off);
+            a.boxes = reinterpret_cast<const float4*>(ps + LS.box_off);
+            a.boxes2 = reinterpret_cast<const float4*>(ps + LS.box2_off);
+            a.skeys = reinterpret_cast<const uint32_t*>(ps + LS.key_off);
+            a.sframe = reinterpret_cast<const float*>(ps + LS.frame_off);
+            a.scell = reinterpret_cast<const uint32_t*>(ps + LS.cell_off);
+            a.qpts = pq ? reinterpret_cast<const float4*>(pq + LQ.pts_off) : nullptr;
+            a.qraw = pq ? nullptr : q.query;
+            a.idx64 = q.idx64; a.idx32 = q.idx32; a.dist = q.dist;
+            a.S = (int)q.S; a.S_pad = (int)LS.S_pad; a.nt = (int)LS.nt; a.nt2 = (int)LS.nt2;
+            a.Q = (int)q.Q; a.Q_pad = (int)LQ.S_pad; a.Kout = q.K;
+            a.gx = (int)ceil_div(LQ.S_pad, kp == 1 ? BLK : BLK / 16);
+            a.blk0 = blocks;
+            blocks += a.gx * (int)B;
+            if (++m.n == MAX_SEARCHES) {
+                const int rc = flush();
+                if (rc != FFB6D_OK) return rc;
+            }
+        }
+        const int rc = flush();
+        if (rc != FFB6D_OK) return rc;
+    }
+    return FFB6D_OK;
+}
+}  // namespace ffb6d
 
 extern "C" int ffb6d_knn_set_pair_counter(unsigned long long* device_counter)
 {

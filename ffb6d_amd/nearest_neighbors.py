@@ -181,6 +181,58 @@ def knn_prepared(support, query, K, dtype=None, return_dist=False):
     return (idx, dist) if return_dist else idx
 
 
+def search_many(searches, dtype=None):
+    """Several independent searches over the same B frames in as few launches as kernels involved (ffb6d_knn_search_multi).
+    `searches` = list of (support, query, K) with support / query a PreparedPoints or a raw float32 [B,S,3] GPU tensor; every
+    search is routed exactly like the single calls (uses_pruning: Morton-ordered kernels on prepared sets -- K = 1 needs both
+    sets prepared -- else the scan on the raw arrays).  Returns the index tensors [B,Q,K] in order."""
+    import ctypes
+
+    import torch
+
+    lib = _lib.load()
+    dtype = dtype or torch.int64
+    if dtype not in (torch.int64, torch.int32):
+        raise TypeError("index dtype must be int64 or int32")
+    if not searches:
+        return []
+
+    class Search(ctypes.Structure):
+        _fields_ = [("prep_support", ctypes.c_void_p), ("prep_query", ctypes.c_void_p), ("support", ctypes.c_void_p),
+                    ("query", ctypes.c_void_p), ("S", ctypes.c_int64), ("Q", ctypes.c_int64), ("K", ctypes.c_int),
+                    ("idx64", ctypes.c_void_p), ("idx32", ctypes.c_void_p), ("dist", ctypes.c_void_p)]
+
+    def split(x):
+        if isinstance(x, PreparedPoints):
+            return x.blob.data_ptr(), x.points
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3 or x.shape[2] != 3:
+            raise TypeError("point sets must be PreparedPoints or float32 [B,S,3] GPU tensors")
+        return None, x.contiguous()
+
+    arr = (Search * len(searches))()
+    outs, keep, nbytes = [], [], 0
+    B = None
+    for i, (sup, qry, K) in enumerate(searches):
+        ps, s_raw = split(sup)
+        pq, q_raw = split(qry)
+        K = _check(s_raw, q_raw, K, 3)
+        B = int(s_raw.shape[0]) if B is None else B
+        if s_raw.shape[0] != B:
+            raise ValueError("search_many: every search must cover the same frames")
+        S, Q = int(s_raw.shape[1]), int(q_raw.shape[1])
+        idx = torch.empty((B, Q, K), dtype=dtype, device=s_raw.device)
+        outs.append(idx)
+        keep += [s_raw, q_raw]
+        arr[i] = Search(ps, pq, s_raw.data_ptr(), q_raw.data_ptr(), S, Q, K, idx.data_ptr() if dtype == torch.int64 else None,
+                        idx.data_ptr() if dtype == torch.int32 else None, None)
+        nbytes += 12 * B * S + 12 * B * Q + idx.element_size() * B * Q * K       # SURVEY 8d: 12 S + 12 Q + idx per search
+    dev = outs[0].device
+    with torch.cuda.device(dev), _lib.traced("knn", nbytes, tuple((int(a.S), int(a.Q), int(a.K)) for a in arr)):
+        rc = lib.ffb6d_knn_search_multi(len(searches), arr, B, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "ffb6d_knn_search_multi")
+    return outs
+
+
 def uses_pruning(B, S, Q, K):
     return bool(_lib.load().ffb6d_knn_uses_pruning(B, S, Q, K))
 

@@ -16,7 +16,7 @@ grid[s] = xyz image at stride s, pixel (y*s, x*s), flattened row-major (:299-311
 """
 import torch
 
-from .nearest_neighbors import knn_batch_device, knn_prepared, prepare_many, uses_pruning
+from .nearest_neighbors import prepare_many, search_many, uses_pruning
 
 RGB_DS_SR = (4, 8, 8, 8)
 RGB_UP_SR = (4, 2, 2)
@@ -74,17 +74,26 @@ class PyramidBuilder:
                             need.append(key)
         self.prepared = dict(zip(need, prepare_many([self.sets[k] for k in need])))
         self.n_levels = 0
+        self.found = None
 
-    def search(self, sup, qry, k):
-        support, query = self.sets[sup], self.sets[qry]
-        if not uses_pruning(self.B, support.shape[1], query.shape[1], k):
-            return knn_batch_device(support, query, k, dtype=self.index_dtype)
-        return knn_prepared(self.prepared[sup], self.prepared.get(qry, query), k, dtype=self.index_dtype)
+    def _search_all(self):
+        """all 22 searches, none of which depends on another, in ONE call (nearest_neighbors.search_many: one launch per
+        kernel involved -- the 16-lane row kernel, the K = 1 kernel, the scan at K = 1 and at K = 16)"""
+        flat = [srch for level in self.plan for srch in level]
+        args = []
+        for _, sup, qry, k in flat:
+            pruned = uses_pruning(self.B, self.sets[sup].shape[1], self.sets[qry].shape[1], k)
+            args.append((self.prepared[sup] if pruned else self.sets[sup],
+                         self.prepared.get(qry, self.sets[qry]) if pruned else self.sets[qry], k))
+        out = search_many(args, dtype=self.index_dtype)
+        self.found = {name: idx for (name, _, _, _), idx in zip(flat, out)}
 
     def _level(self, j):
         assert j == self.n_levels, "levels are built in order"
         self.n_levels += 1
-        return {name: self.search(sup, qry, k) for name, sup, qry, k in self.plan[j]}
+        if self.found is None:
+            self._search_all()
+        return {name: self.found[name] for name, _, _, _ in self.plan[j]}
 
     def encoder_level(self, i):
         out = self._level(i)

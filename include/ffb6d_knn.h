@@ -122,6 +122,25 @@ int ffb6d_knn_prepare(const float* points /* [B,npts,3] device */, int64_t batch
 size_t ffb6d_knn_prepare_multi_workspace_bytes(int nsets, const int64_t* npts, int64_t batch_size);
 int ffb6d_knn_prepare_multi(int nsets, const float* const* pts, const int64_t* npts, int64_t batch_size, void* const* prepared,
                             const size_t* prepared_bytes, void* workspace, size_t workspace_bytes, ffb6d_stream_t stream);
+/* One search of a batch handed to ffb6d_knn_search_multi: the arguments of ffb6d_knn_search_prepared / ffb6d_knn_batch_device. */
+typedef struct {
+    const void* prep_support;   /* prepared set, or NULL */
+    const void* prep_query;     /* prepared set, or NULL */
+    const float* support;       /* raw [B,npts,3] (needed when the search is not routed to the Morton-ordered kernels) */
+    const float* query;         /* raw [B,nqueries,3] */
+    int64_t S, Q;               /* npts, nqueries */
+    int K;
+    int64_t* idx64;             /* outputs as ffb6d_knn_batch_device; any may be NULL */
+    int32_t* idx32;
+    float* dist;
+} ffb6d_knn_search_t;
+
+/* Several independent searches over the same B frames in as few launches as there are kernels involved (the 22 searches of
+ * an index pyramid: 4).  Each search is routed like a single call would be -- ffb6d_knn_uses_pruning(B, S, Q, K): the
+ * 16-lane row kernel for 2 <= K <= 16 (prepared support; prepared or raw queries), the K = 1 kernel (both sets prepared),
+ * else the LDS-tiled scan on the raw arrays -- and gives the same results. */
+int ffb6d_knn_search_multi(int nsearches, const ffb6d_knn_search_t* searches, int64_t batch_size, ffb6d_stream_t stream);
+
 /* Queries: either a prepared set (prepared_query) or, for 2 <= K <= 16, the raw [B,nqueries,3]
  * device array (raw_query, prepared_query = NULL) -- small query sets need no preparation. */
 int ffb6d_knn_search_prepared(const void* prepared_support, const void* prepared_query,
