@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 #    convolution algorithms over ~110 layers (the plain-torch GPU run shows the same
 #    deviation, asserted below), so the bar is looser and the measured value is printed.
 HOT_TOL = 1e-5
-E2E_TOL = 1e-3
+E2E_TOL = 3e-4      # measured 1e-5 .. 1e-4 (printed by the tests)
 
 
 def build(n_classes, n_pts, device):
@@ -100,9 +100,11 @@ def test_every_fusion_stage_matches_plain_torch(device, cfg):
 
 
 # bf16 bar (BASELINE.json configuration 5: bfloat16 activations / weights, fp32 accumulation): ~110 layers each rounding
-# its output to 8 significant bits.  Stated tolerance: max error <= 5 % and mean error <= 0.8 % of the tensor's range against
-# the fp32 plain-torch restatement, per output tensor and per fusion stage (measured values are printed).
-BF16_MAX, BF16_MEAN = 5e-2, 8e-3
+# its output to 8 significant bits.  Bars = 2 x the error measured on the MI355X (profiles/r02_bf16_parity_vs_fp32_oracle.txt,
+# relative to the tensor's range, against the fp32 plain-torch restatement): the three outputs max <= 2.4e-2 / mean <= 5.2e-3
+# measured, the 14 fusion-stage embeddings max <= 1.4e-2 / mean <= 1.2e-3 measured; the test prints what it measures.
+BF16_MAX, BF16_MEAN = 4.9e-2, 8e-3
+BF16_STAGE_MAX, BF16_STAGE_MEAN = 2.8e-2, 2.4e-3
 
 
 @pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (5, 2, 12288, 480, 640, 22)])
@@ -123,7 +125,8 @@ def test_bf16_forward_matches_fp32_oracle_at_bf16_tolerance(device, cfg):
         scale = float(want.abs().max())
         err = (got - want).abs()
         print(cfg, k, "bf16 max err / range %.3e  mean err / range %.3e" % (float(err.max()) / scale, float(err.mean()) / scale))
-        assert float(err.max()) <= BF16_MAX * scale and float(err.mean()) <= BF16_MEAN * scale, k
+        bar_max, bar_mean = (BF16_MAX, BF16_MEAN) if k in ref else (BF16_STAGE_MAX, BF16_STAGE_MEAN)
+        assert float(err.max()) <= bar_max * scale and float(err.mean()) <= bar_mean * scale, k
     net.precision = "fp32"                                   # and the same module answers in fp32 again (per-dtype weight caches)
     with torch.no_grad():
         ep32 = net(inputs)
