@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true",
                     help="train mode, >1 rank: torch.nn.SyncBatchNorm like the reference's apex SyncBN (train_lm.py:592); "
                          "default = local BatchNorm statistics, gradients are the only collective (north_star)")
+    ap.add_argument("--channels-last", type=int, default=1, help="train mode: keep the colour branch in channels_last (NHWC) memory format")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, one GPU per rank) for real runs; gloo lets several ranks share one GPU "
                          "to exercise the multi-process path on a single-GPU box")
@@ -243,6 +244,8 @@ def main():
     opt = None
     if train:
         net.train()
+        if args.channels_last:      # NHWC convolutions forward and backward (MIOpen's fastest path on gfx950), no layout transposes
+            net = net.to(memory_format=torch.channels_last)
         ddp = distributed.wrap_ddp(net, dev, sync_bn=args.sync_bn) if world > 1 else net     # RCCL all-reduce of 33.85 M fp32 grads
         opt = torch.optim.Adam(net.parameters(), lr=1e-5)              # train_lm.py:596
     else:
@@ -253,6 +256,8 @@ def main():
     frames = distributed.shard_frames(args.config, args.batch, rank, None, n_points=args.n_points)
     cpu_baseline.frames = frames
     rgb = torch.from_numpy(frames["rgb"]).to(dev).float()
+    if train and args.channels_last:
+        rgb = rgb.contiguous(memory_format=torch.channels_last)
     cld_rgb_nrm = torch.from_numpy(frames["cld_rgb_nrm"]).to(dev)
     choose = torch.from_numpy(frames["choose"]).to(dev).long()
     cld = torch.from_numpy(frames["cld"]).to(dev)
@@ -288,7 +293,9 @@ def main():
             # proxy objective (the reference's focal + L1 offset losses need labels that synthetic
             # frames do not have); it touches all three heads so every parameter gets a gradient
             opt.zero_grad(set_to_none=True)
-            with torch.enable_grad():
+            # --precision bf16: mixed precision as the reference trains (apex amp, train_lm.py:600) -- torch.autocast runs
+            # the convolutions / 1x1 layers in bfloat16 with fp32 master weights; the neighbour operators keep fp32
+            with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.precision == "bf16"):
                 out = ddp(inputs)
                 loss = sum((v.float() ** 2).mean() for v in out.values())
             loss.backward()

@@ -42,6 +42,7 @@ def _idx(t):
 
 class _RandomSample(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)      # under autocast: the fp32 kernels, fp32 operands
     def forward(ctx, feature, pool_idx):
         # feature [B,C,M], pool_idx [B,Np,K] -> [B,C,Np]
         lib = _lib.load()
@@ -63,6 +64,7 @@ class _RandomSample(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
         lib = _lib.load()
         (arg,) = ctx.saved_tensors
@@ -92,6 +94,7 @@ def random_sample(feature, pool_idx):
 
 class _NearestInterp(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)      # under autocast: the fp32 kernels, fp32 operands
     def forward(ctx, feature, interp_idx):
         # feature [B,C,M], interp_idx [B,U] -> [B,C,U]
         lib = _lib.load()
@@ -110,6 +113,7 @@ class _NearestInterp(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
         lib = _lib.load()
         (idx,) = ctx.saved_tensors
@@ -148,6 +152,7 @@ def choose_gather(rgb_emb, choose):
 
 class _GatherNeighbour(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)      # under autocast: the fp32 kernels, fp32 operands
     def forward(ctx, pc, neighbor_idx):
         lib = _lib.load()
         B, M, C = pc.shape
@@ -165,6 +170,7 @@ class _GatherNeighbour(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
         lib = _lib.load()
         (idx,) = ctx.saved_tensors
@@ -246,6 +252,7 @@ def att_pool2(feat1, feat2, att_activation):
 
 class _AttPool(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)      # under autocast: the fp32 kernels, fp32 operands
     def forward(ctx, feature_set, att_activation):
         lib = _lib.load()
         B, C, N, K = feature_set.shape
@@ -260,6 +267,7 @@ class _AttPool(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
         lib = _lib.load()
         feat, act = ctx.saved_tensors
