@@ -320,16 +320,19 @@ mlp_pm_kernel(const PmParams p)
 //     result rows in the same LDS image and they leave as whole rows too.
 // No barrier after the W copy: each wave reads and writes only its own image.
 // ---------------------------------------------------------------------------------------------------------------
+// bias_lds: the bias (zero-filled to 32 * TM channels) beside W in LDS; yreg != nullptr: the Y row of this lane's point, fetched by
+// the caller BEFORE it requested the tiles after this one -- a load issued here would be the youngest vector-memory operation
+// in flight and waiting for it (s_waitcnt vmcnt(0)) would also wait for the prefetched tiles
 template <typename T, int TM, bool LSM>
 __device__ __forceinline__ void stream_epilogue(const PmParams& p, f32x16 (&acc)[TM][1], unsigned char* img, int os, int r0,
-                                                int l31, int kh)
+                                                int l31, int kh, const float* bias_lds, const float4 (*yreg)[4])
 {
     const T* yb = static_cast<const T*>(p.y);
     const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
     const int r = r0 + l31;
     const bool live = r < p.rows;
     const T* yrow = nullptr;
-    if (yb && live) {
+    if (yb && live && !yreg) {
         long long yr = r;
         if (p.gidx) {
             const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[r] : (long long)static_cast<const int*>(p.gidx)[r];
@@ -341,11 +344,12 @@ __device__ __forceinline__ void stream_epilogue(const PmParams& p, f32x16 (&acc)
     auto value = [&](int i, int g, int ch) {
         float4 v = make_float4(acc[i][0][4 * g], acc[i][0][4 * g + 1], acc[i][0][4 * g + 2], acc[i][0][4 * g + 3]);
         if (ch < p.cout && live) {
-            if (p.bias) {
-                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
-                v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-            }
-            if (yrow) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + ch);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            if (yreg) {
+                const float4 y4 = yreg[i][g];
+                v.x += y4.x; v.y += y4.y; v.z += y4.z; v.w += y4.w;
+            } else if (yrow) {
                 const float4 y4 = El<T>::ld4(yrow + ch);
                 v.x += y4.x; v.y += y4.y; v.z += y4.z; v.w += y4.w;
             }
@@ -392,7 +396,7 @@ __device__ __forceinline__ void stream_epilogue(const PmParams& p, f32x16 (&acc)
     }
 }
 
-template <typename T, int TM, int NS, bool LSM, bool TWO>
+template <typename T, int TM, int NS, bool LSM, bool TWO, bool HASY>
 __global__ void __launch_bounds__(BLK)
 mlp_pm_stream_kernel(const PmParams p)
 {
@@ -413,6 +417,8 @@ mlp_pm_stream_kernel(const PmParams p)
     const int c1 = p.k1 * SZ / 16, crx = K * SZ / 16, cro = p.cout * SZ / 16;      // chunks: of x1, of a row [x1|x2], of an output row
     unsigned char* img = lds + wave * IMG;
     unsigned char* w_lds = lds + 4 * IMG;
+    float* bias_lds = reinterpret_cast<float*>(w_lds + 32 * TM * XS);          // [32 * TM], zeros past cout / without a bias
+    for (int c = threadIdx.x; c < 32 * TM; c += BLK) bias_lds[c] = (p.bias && c < p.cout) ? p.bias[c] : 0.f;
 
     {   // W -> LDS, once: rows past cout and columns past K read as zeros
         const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)K * SZ);
@@ -453,6 +459,29 @@ mlp_pm_stream_kernel(const PmParams p)
         for (int j = 0; j < NS; ++j)
             *reinterpret_cast<u32x4*>(img + (lrow + j * RPI) * XS + lchunk * 16) = x[j];
     };
+    // HASY: the epilogue's Y rows (gathered or plain) of tile t, one row per lane, 4 x TM chunks of 4 channels
+    float4 yreg[TM][4];
+    auto yload = [&](int t) {
+        if constexpr (HASY) {
+            const int r = t * 128 + wave * 32 + l31;
+            const T* yrow = nullptr;
+            if (r < p.rows) {
+                long long yr = r;
+                if (p.gidx) {
+                    const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[r] : (long long)static_cast<const int*>(p.gidx)[r];
+                    yr = (long long)(r / p.P) * p.py + gi;
+                }
+                yrow = static_cast<const T*>(p.y) + yr * p.ldy;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = i * 32 + 8 * g + 4 * kh;
+                    yreg[i][g] = (yrow && ch < p.cout) ? El<T>::ld4(yrow + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
+    };
     auto compute = [&](int t) {
         f32x16 acc[TM][1];
 #pragma unroll
@@ -477,7 +506,7 @@ mlp_pm_stream_kernel(const PmParams p)
             __builtin_amdgcn_sched_barrier(0);
         }
         const int r0 = t * 128 + wave * 32;
-        stream_epilogue<T, TM, LSM>(p, acc, img, OS, r0, l31, kh);
+        stream_epilogue<T, TM, LSM>(p, acc, img, OS, r0, l31, kh, bias_lds, HASY ? yreg : nullptr);
         // whole result rows out of the image
         constexpr int OPI = 64 / CRO;                 // rows per instruction (CRO <= 32)
         const int orow = lane / CRO, ochunk = lane % CRO;
@@ -499,11 +528,13 @@ mlp_pm_stream_kernel(const PmParams p)
         gload(t + stride, xb);
         while (true) {
             stage(xa);                    FFB6D_PIN();
+            yload(t);                     FFB6D_PIN();
             gload(t + 2 * stride, xa);    FFB6D_PIN();
             compute(t);                   FFB6D_PIN();
             t += stride;
             if (t >= p.n_pt) break;
             stage(xb);                    FFB6D_PIN();
+            yload(t);                     FFB6D_PIN();
             gload(t + 2 * stride, xb);    FFB6D_PIN();
             compute(t);                   FFB6D_PIN();
             t += stride;
@@ -514,6 +545,7 @@ mlp_pm_stream_kernel(const PmParams p)
         gload(t, xa);
         while (true) {
             stage(xa);                    FFB6D_PIN();
+            yload(t);                     FFB6D_PIN();
             gload(t + stride, xa);        FFB6D_PIN();
             compute(t);                   FFB6D_PIN();
             t += stride;
@@ -853,15 +885,15 @@ void launch_lds(PmParams& p, hipStream_t st)
     hipLaunchKernelGGL((mlp_pm_lds_kernel<T>), dim3(grid), dim3(BLK), lds, st, p);
 }
 
-template <typename T, int TM, int NS, bool LSM, bool TWO>
+template <typename T, int TM, int NS, bool LSM, bool TWO, bool HASY = false>
 void launch_stream(PmParams& p, hipStream_t st)
 {
     constexpr int SZ = El<T>::SZ;
     p.n_ct = 1;
     p.n_pt = (int)ceil_div(p.rows, 128);
     constexpr size_t XS = NS * 32 + 16, OS = 32 * TM * SZ + 16, IMG = 32 * (XS > OS ? XS : OS);       // as in the kernel
-    constexpr size_t lds = 4 * IMG + (size_t)32 * TM * XS;
-    const void* fn = reinterpret_cast<const void*>(&mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>);
+    constexpr size_t lds = 4 * IMG + (size_t)32 * TM * XS + (size_t)32 * TM * 4;                        // + the bias
+    const void* fn = reinterpret_cast<const void*>(&mlp_pm_stream_kernel<T, TM, NS, LSM, TWO, HASY>);
     // resident workgroups per CU: registers (the X sets in flight + accumulators) and LDS (four wave images + the W copy)
     static const int per_cu = [&] {
         int n = 0;
@@ -871,7 +903,7 @@ void launch_stream(PmParams& p, hipStream_t st)
         return n;
     }();
     const unsigned grid = (unsigned)std::min<int64_t>(p.n_pt, (int64_t)256 * per_cu);
-    hipLaunchKernelGGL((mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>), dim3(grid), dim3(BLK), lds, st, p);
+    hipLaunchKernelGGL((mlp_pm_stream_kernel<T, TM, NS, LSM, TWO, HASY>), dim3(grid), dim3(BLK), lds, st, p);
 }
 
 template <typename T, int TM, int TN>
@@ -959,15 +991,24 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
         else if (ns <= 8) launch_stream<T, TM_, 8, LSM_, TWO_>(p, st);            \
         else launch_stream<T, TM_, 16, LSM_, TWO_>(p, st);                        \
     } while (0)
+#define FFB6D_STREAM_Y(TM_)                                                       \
+    do {                                                                          \
+        if (ns <= 4) launch_stream<T, TM_, 4, false, false, true>(p, st);         \
+        else if (ns <= 8) launch_stream<T, TM_, 8, false, false, true>(p, st);    \
+        else launch_stream<T, TM_, 16, false, false, true>(p, st);                \
+    } while (0)
 #define FFB6D_STREAM(TM_)                                                         \
     do {                                                                          \
-        if (two) FFB6D_STREAM_NS(TM_, false, true); else FFB6D_STREAM_NS(TM_, false, false); \
+        if (two) FFB6D_STREAM_NS(TM_, false, true);                               \
+        else if (p.y) FFB6D_STREAM_Y(TM_);          /* Y rows fetched ahead of the tile prefetch */ \
+        else FFB6D_STREAM_NS(TM_, false, false);                                  \
     } while (0)
             if (act == 3) { if (tm == 1) FFB6D_STREAM_NS(1, true, false); else FFB6D_STREAM_NS(2, true, false); }
             else if (tm == 1) FFB6D_STREAM(1);
             else if (tm == 2) FFB6D_STREAM(2);
             else FFB6D_STREAM(4);
 #undef FFB6D_STREAM
+#undef FFB6D_STREAM_Y
 #undef FFB6D_STREAM_NS
             break;
         }

@@ -44,5 +44,14 @@ for dt in (torch.float32, torch.bfloat16):
         t6, y6 = run(lambda: ops_pm.mlp(x1, w, b, act, x2=x2, out=o6, tile_hint=6))
         by = rows * (k1 + k2 + cout) * esz
         diff = float((y0.float() - y6.float()).abs().max())
+        if k2 == 0 and act != 3 and rows % 8 == 0:      # the same layer with a gathered epilogue row (p2r fusion / decoder: W_a x + gather(W_b e))
+            Y = torch.randn(8, 3072, cout, device=dev).to(dt)
+            gi = torch.randint(0, 3072, (8, rows // 8), device=dev)
+            xg = x1.view(8, rows // 8, k1)
+            tg, _ = run(lambda: ops_pm.mlp(xg, w, b, act, gather=(Y, gi), tile_hint=6))
+            byg = by + rows * 8 + rows * cout * esz
+            extra = " | +gather %7.1f us %6.0f GB/s" % (tg, byg / tg * 1e-3)
+        else:
+            extra = ""
         print(f"{'f32' if esz == 4 else 'bf16'} [{k1}+{k2}]->{cout} rows {rows:8d} act {act}: default {t0:7.1f} us {by / t0 * 1e-3:6.0f} GB/s | "
-              f"stream {t6:7.1f} us {by / t6 * 1e-3:6.0f} GB/s | maxdiff {diff:.2e}", flush=True)
+              f"stream {t6:7.1f} us {by / t6 * 1e-3:6.0f} GB/s | maxdiff {diff:.2e}" + extra, flush=True)

@@ -20,7 +20,7 @@ KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip", "lfa_pm.hip", "upconv.hip", "posen
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 # statements after which a wave relies on lock-step execution for LDS traffic between its lanes
-LOCKSTEP_AFTER = {"mlp_pm.hip": ["stream_epilogue<T, TM, LSM>(p, acc, img, OS, r0, l31, kh);"]}
+LOCKSTEP_AFTER = {"mlp_pm.hip": ["stream_epilogue<T, TM, LSM>(p, acc, img, OS, r0, l31, kh, bias_lds, HASY ? yreg : nullptr);"]}
 DYN_SHARED = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(16\)\)\)\s+)?((?:unsigned )?\w+)\s+(\w+)\[\];")
 
 

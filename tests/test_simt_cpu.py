@@ -36,7 +36,8 @@ def _ref(x1, w, bias, act, x2=None, add=None, gather=None, x1_gather=None):
 
 # (B, P, K1, K2, Cout, act, py [>0 gathered epilogue rows, <0 added rows], tile_hint); sizes an emulated run finishes in a moment
 CASES = [(2, 130, 24, 8, 37, 1, 13, h) for h in (1, 2, 3, 4, 5)]                      # every tile kernel, ragged rows / channels
-CASES += [(1, 300, 64, 0, 64, 1, 0, 6), (2, 201, 24, 0, 16, 0, 0, 6), (1, 260, 32, 96, 100, 2, 70, 6), (1, 130, 128, 0, 128, 1, -1, 6)]  # stream form
+CASES += [(1, 300, 64, 0, 64, 1, 0, 6), (2, 201, 24, 0, 16, 0, 0, 6), (1, 260, 32, 96, 100, 2, 70, 6), (1, 130, 128, 0, 128, 1, -1, 6),
+          (2, 300, 64, 0, 64, 1, 37, 6), (3, 50, 32, 0, 24, 2, 9, 6)]  # stream form (the last two: Y rows fetched ahead of the tile prefetch)
 CASES += [(1, 300, 96, 0, 40, 0, 0, 7), (2, 140, 32, 32, 72, 2, 50, 7), (1, 257, 256, 0, 200, 1, -1, 7), (8, 24, 512, 256, 256, 2, 0, 7)]  # LDS-tiled form
 CASES += [(8, 48, 1024, 0, 64, 1, 0, 5), (1, 33, 8, 8, 5, 1, 0, 0), (1, 1, 8, 0, 8, 0, 0, 0), (2, 64, 128, 0, 22, 0, 0, 0)]      # K split, tiny, automatic choice
 
