@@ -65,9 +65,9 @@ def parse():
                     help="infer (default, the BASELINE metric): pyramid + forward, eval, no_grad.  train: BASELINE "
                          "config 3 shape -- pyramid + forward + backward + Adam step in train() mode, wrapped in "
                          "DistributedDataParallel (RCCL gradient all-reduce) when launched with more than one rank")
-    ap.add_argument("--sync-bn", action="store_true",
-                    help="train mode, >1 rank: torch.nn.SyncBatchNorm like the reference's apex SyncBN (train_lm.py:592); "
-                         "default = local BatchNorm statistics, gradients are the only collective (north_star)")
+    ap.add_argument("--local-bn", action="store_true",
+                    help="train mode, >1 rank: per-rank BatchNorm statistics, gradients are the only collective (north_star's "
+                         "wording); default = torch.nn.SyncBatchNorm like the reference's apex SyncBN (train_lm.py:592)")
     ap.add_argument("--channels-last", type=int, default=1, help="train mode: keep the colour branch in channels_last (NHWC) memory format")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, one GPU per rank) for real runs; gloo lets several ranks share one GPU "
@@ -246,7 +246,7 @@ def main():
         net.train()
         if args.channels_last:      # NHWC convolutions forward and backward (MIOpen's fastest path on gfx950), no layout transposes
             net = net.to(memory_format=torch.channels_last)
-        ddp = distributed.wrap_ddp(net, dev, sync_bn=args.sync_bn) if world > 1 else net     # RCCL all-reduce of 33.85 M fp32 grads
+        ddp = distributed.wrap_ddp(net, dev, sync_bn=False if args.local_bn else None) if world > 1 else net     # RCCL all-reduce of 33.85 M fp32 grads
         opt = torch.optim.Adam(net.parameters(), lr=1e-5)              # train_lm.py:596
     else:
         net.eval()
@@ -521,7 +521,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": ("FFB6D forward" if not train else "FFB6D training step (forward + backward + Adam, "
                                     "train-mode BatchNorm with %s statistics, DDP gradient all-reduce when n_gpus > 1)" %
-                                    ("synchronised (SyncBatchNorm)" if args.sync_bn and world > 1 else "per-rank")) +
+                                    ("synchronised (SyncBatchNorm)" if not args.local_bn and world > 1 and args.dist_backend == "nccl" else "per-rank")) +
                                    " incl. on-device 22-call KNN index pyramid; "
                                    f"bs={args.batch}/GPU, N={args.n_points} pts, 480x640 RGB-D, "
                                    f"{args.n_classes} classes, " + ("bf16 activations/weights with fp32 accumulation" if args.precision == "bf16" else "fp32") +

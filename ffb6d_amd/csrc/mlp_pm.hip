@@ -217,14 +217,15 @@ mlp_pm_kernel(const PmParams p)
     for (int j = 0; j < TN; ++j) {
         const int r = r0 + (wn * TN + j) * 32 + l31;
         int xr = r;
+        bool dead = false;      // gathered rows past the end: a constant offset past every buffer (reads zeros), no arithmetic on it
         if (p.xidx) {           // gathered operand rows: the gather IS the operand load
-            xr = 0x1fffffff / p.ld1;                            // out of range -> zeros
-            if (r < p.rows)
+            dead = r >= p.rows;
+            if (!dead)
                 xr = (r / p.P) * p.px + (p.idx64 ? (int)static_cast<const long long*>(p.xidx)[r]
                                                  : static_cast<const int*>(p.xidx)[r]);
         }
-        x1_vo[j] = xr * p.ld1 * SZ + 16 * kh;
-        x2_vo[j] = r * p.ld2 * SZ + 16 * kh;
+        x1_vo[j] = dead ? 0x7f000000 : (int)((unsigned)xr * (unsigned)(p.ld1 * SZ) + 16u * kh);      // unsigned: rows past the end may wrap
+        x2_vo[j] = (int)((unsigned)r * (unsigned)(p.ld2 * SZ) + 16u * kh);
     }
 
     const int n1 = p.k1 / KSTEP, nsteps = K / KSTEP;      // steps of 32 bytes per row (k1, k2 multiples of KSTEP)
@@ -775,15 +776,13 @@ att_pool_pm_kernel(const AttParams p)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int n = pbase + 2 * i + a_pp;
-        int frow = 0x1fffffff / p.ldf, grow = 0x1fffffff / p.ldg;       // out of range -> zeros
+        f_vo[i] = g_vo[i] = 0x7f000000;                                // past every buffer -> zeros (no arithmetic on a sentinel row)
         if (n < p.npts) {
             const size_t pair = (size_t)n * 16 + a_nb;
             const int nb = p.idx64 ? (int)static_cast<const long long*>(p.nei)[pair] : static_cast<const int*>(p.nei)[pair];
-            frow = (n / p.N) * p.N + nb;
-            grow = (int)pair;
+            f_vo[i] = ((n / p.N) * p.N + nb) * p.ldf * SZ + 16 * kh;
+            g_vo[i] = (int)pair * p.ldg * SZ + 16 * kh;
         }
-        f_vo[i] = frow * p.ldf * SZ + 16 * kh;
-        g_vo[i] = grow * p.ldg * SZ + 16 * kh;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) w_vo[j] = (c0 + j * 32 + l31) * d * SZ + 16 * kh;

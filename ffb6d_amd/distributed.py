@@ -92,14 +92,20 @@ def timed_steps(step, warmup, steps, group, sync=lambda: None):
     return group.max_over_ranks(elapsed)
 
 
-def wrap_ddp(model, device, sync_bn=False):
+def wrap_ddp(model, device, sync_bn=None):
     """DistributedDataParallel exactly as the reference sets it up (train_lm.py:625-628), with
     RCCL-friendly defaults: gradients as bucket views, 25 MB buckets overlapped with backward.
 
-    BatchNorm: the reference additionally converts every BatchNorm to apex SyncBatchNorm (train_lm.py:592), i.e. one
-    more all-reduce of the batch statistics per BN layer and direction (~150 small collectives per step).  BASELINE.json's
-    north_star asks for "RCCL all-reduce over xGMI for DDP gradients only", so the DEFAULT here is local statistics per
-    rank (8 frames per GPU); sync_bn=True swaps in torch.nn.SyncBatchNorm for recipe parity with the reference."""
+    BatchNorm: the reference converts every BatchNorm to apex SyncBatchNorm before wrapping (train_lm.py:592), i.e. one
+    more all-reduce of the batch statistics per BN layer and direction (~150 small collectives per step); sync_bn=True (the
+    default: recipe parity, same training numerics at 8 frames per GPU) swaps in torch.nn.SyncBatchNorm.  sync_bn=False keeps
+    per-rank statistics, so that the gradients are the only collective -- BASELINE.json's north_star wording ("RCCL all-reduce
+    over xGMI for DDP gradients only"); `bench.py --mode train --local-bn` times that variant and says so in its metric.
+    sync_bn=None (default) = True on the RCCL (nccl) backend with GPU tensors, False elsewhere (torch's SyncBatchNorm needs
+    GPU tensors and a backend with GPU all_gather: the gloo test path keeps per-rank statistics)."""
+    if sync_bn is None:
+        import torch.distributed as dist
+        sync_bn = device.type == "cuda" and dist.is_initialized() and dist.get_backend() == "nccl"
     from torch.nn.parallel import DistributedDataParallel
     if sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)

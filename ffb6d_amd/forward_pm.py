@@ -311,9 +311,23 @@ def cnn_stage(stage, x):
 
 
 def supported(net):
-    """The row kernels need channel counts that are multiples of 8 (every width of the reference's configuration is)."""
-    widths = [m.conv.weight.shape[0] for m in net.modules() if hasattr(m, "conv") and hasattr(m, "act_code")]
-    return all(w % 8 == 0 or w <= 64 for w in widths)
+    """Can the row kernels run this module tree?  Every shared-MLP width must be a legal row: output channels a multiple of 8
+    (or <= 64: padded), input channels (the K of the GEMM) a multiple of 8 in fp32 / 16 in bf16 -- except the two stems, whose
+    9- and 8-channel rows are stored 16 wide.  Every width of the reference's configuration is; anything else falls back to
+    the channel-major path instead of failing inside a kernel.  Memoised per precision (dropped with the weight caches)."""
+    prec = getattr(net, "precision", "fp32")
+    memo = net.__dict__.setdefault("_pm_supported", {})
+    if prec not in memo:
+        kmul = 16 if prec == "bf16" else 8
+        ok = True
+        for name, m in net.named_modules():
+            if hasattr(m, "conv") and hasattr(m, "act_code"):
+                cout, cin = m.conv.weight.shape[0], m.conv.weight.shape[1]
+                stem = name == "rndla_pre_stages" or name.endswith("rndla_ds_stages.0.mlp1") or name.endswith("rndla_ds_stages.0.shortcut") \
+                    or name.endswith("lfa.mlp1")
+                ok = ok and (cout % 8 == 0 or cout <= 64) and (cin % kmul == 0 or stem)
+        memo[prec] = ok
+    return memo[prec]
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -162,12 +162,20 @@ def sample_choose(depth, n_points, generator=None, min_points=400, seed=None):
     return res["choose"]
 
 
-def assemble_inputs(rgb, depth, normals, K, n_points, cam_scale=1.0, generator=None, index_dtype=torch.int64, seed=None):
+def assemble_inputs(rgb, depth, normals, K, n_points, cam_scale=1.0, generator=None, index_dtype=torch.int64, seed=None,
+                    min_points=0):
     """rgb [B,3,H,W] (uint8 or float), depth [B,H,W] f32, normals [B,3,H,W] f32, K intrinsics ->
-    the complete input dict of FFB6D.forward, everything computed on the device, no host synchronisation
-    (`n_valid` [B] is returned for the caller to drop frames with too few valid pixels)."""
+    the complete input dict of FFB6D.forward, everything computed on the device.
+    Frames with too few valid depth pixels: the reference's dataset returns None for fewer than 400 (linemod_dataset.py:264-268);
+    a frame with none at all would otherwise yield N copies of pixel 0.  min_points=400 reproduces the reference's rule (raises;
+    costs one host synchronisation); with the default 0 nothing synchronises and the CALLER must drop the frames whose
+    `n_valid` [B] (returned in the dict) is below its threshold before trusting their outputs."""
     dpt_xyz = depth_to_cloud(depth, K, cam_scale)
     pts = sample_points(depth / cam_scale, n_points, dpt_xyz, rgb, normals, seed=seed, generator=generator)
+    if min_points:
+        nv = pts["n_valid"].cpu()
+        if int(nv.min()) < min_points:
+            raise ValueError(f"frame {int(nv.argmin())}: only {int(nv.min())} valid depth pixels (< {min_points})")
     inputs = {
         'rgb': rgb.float(),
         'cld_rgb_nrm': pts["cld_rgb_nrm"],     # [B,9,N]

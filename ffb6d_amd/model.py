@@ -422,6 +422,7 @@ class FFB6D(nn.Module):
     def train(self, mode=True):
         # drop every cached inference-time fold (BatchNorm scale/shift, split weights): they are
         # also version-checked, this covers edits made through `.data`
+        self.__dict__.pop("_pm_supported", None)
         for m in self.modules():
             m.__dict__.pop("_pm_cache", None)
             for attr in ("_ffb6d_fold", "_slope", "_shift", "_wt", "_fold"):
