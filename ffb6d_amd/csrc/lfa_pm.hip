@@ -450,10 +450,11 @@ lfa_pm_kernel(const LfaParams p)
         // -----------------------------------------------------------------------------------------------------------
         if constexpr (SZ == 4) {
             __syncthreads();
-            constexpr int TPC = BLK / COUT > 0 ? BLK / COUT : 1;       // threads per channel
-            constexpr int PPT = P / TPC;                               // points per thread
-            static_assert(COUT <= BLK && BLK % COUT == 0 && P % TPC == 0 && PPT >= 1, "output MLP: P * COUT must be whole multiples of the workgroup");
-            const int c = tid % COUT, p0 = (tid / COUT) * PPT;
+            constexpr int TPC = BLK / COUT;                            // threads per channel
+            constexpr int PPT = (P + TPC - 1) / TPC;                   // points per thread (threads past P * COUT outputs idle)
+            static_assert(COUT <= BLK && BLK % COUT == 0 && PPT >= 1, "output MLP: one channel per thread");
+            const int c = tid % COUT, p0 = min((tid / COUT) * PPT, P - 1);
+            const bool mine = (tid / COUT) * PPT < P;
             float acc[PPT];
 #pragma unroll
             for (int q = 0; q < PPT; ++q) acc[q] = 0.f;
@@ -468,7 +469,7 @@ lfa_pm_kernel(const LfaParams p)
 #pragma unroll
                 for (int q = 0; q < PPT; ++q) {
                     float x[VL];
-                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(xrow + q * RS + kc * 16), x);
+                    unpack_chunk<T>(*reinterpret_cast<const u32x4*>(xrow + min(q, P - 1 - p0) * RS + kc * 16), x);
 #pragma unroll
                     for (int e = 0; e < VL; ++e) acc[q] = fmaf(w[e], x[e], acc[q]);
                 }
@@ -477,7 +478,7 @@ lfa_pm_kernel(const LfaParams p)
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
                 const int n = n0 + p0 + q;
-                if (n < p.npts) El<T>::st(static_cast<T*>(p.out) + (size_t)n * p.ldo + c, activate(acc[q] + bias, p.slopem));
+                if (mine && p0 + q < P && n < p.npts) El<T>::st(static_cast<T*>(p.out) + (size_t)n * p.ldo + c, activate(acc[q] + bias, p.slopem));
             }
         } else {
             constexpr int NOT = COUT / 32 > 0 ? COUT / 32 : 1;         // channel tiles wo, wo + 4
@@ -543,17 +544,19 @@ void launch_lfa(LfaParams& p, hipStream_t st)
 // points per workgroup: 16 P d elements of pair image = 64 KB (fp32) whatever the level; `small` halves it (more, smaller
 // workgroups).  wlds: fc / mlp / mlp2 weights resident in LDS (d <= 64 only: they must fit beside the pair image).
 template <typename T, int D, int MODE>
-void launch_lfa_p(LfaParams& p, bool small, bool wlds, hipStream_t st)
+void launch_lfa_p(LfaParams& p, int size, bool wlds, hipStream_t st)
 {
     constexpr int P = 1024 / D;
     if constexpr (D <= 64) {
         if (wlds) {
-            if (small) launch_lfa<T, D, MODE, P / 2, true>(p, st);
+            if (size == 3) launch_lfa<T, D, MODE, P / 4, true>(p, st);
+            else if (size == 2) launch_lfa<T, D, MODE, P / 2, true>(p, st);
             else launch_lfa<T, D, MODE, P, true>(p, st);
             return;
         }
+        if (size == 3) { launch_lfa<T, D, MODE, P / 4, false>(p, st); return; }
     }
-    if (small) launch_lfa<T, D, MODE, P / 2, false>(p, st);
+    if (size >= 2) launch_lfa<T, D, MODE, P / 2, false>(p, st);
     else launch_lfa<T, D, MODE, P, false>(p, st);
 }
 
@@ -590,12 +593,12 @@ int lfa_pm_impl(int mode, const float* xyz4, int64_t xfs, const void* nei, int i
     hipStream_t st = as_stream(stream);
     const int size_hint = p_hint & 3, w_hint = (p_hint >> 2) & 3;
     const int choice = ffb6d_lfa_pm_choice(npts, d, SZ == 2);
-    const bool small = size_hint == 2 || (size_hint == 0 && (choice & 3) == 2);
+    const int size = size_hint ? size_hint : (choice & 3);
     const bool wlds = d <= 64 && (w_hint == 1 || (w_hint == 0 && (choice >> 2) == 1));
 #define FFB6D_LFA_D(D_)                                                              \
     do {                                                                             \
-        if (mode == 1) launch_lfa_p<T, D_, 1>(p, small, wlds, st);                   \
-        else launch_lfa_p<T, D_, 2>(p, small, wlds, st);                             \
+        if (mode == 1) launch_lfa_p<T, D_, 1>(p, size, wlds, st);                    \
+        else launch_lfa_p<T, D_, 2>(p, size, wlds, st);                              \
     } while (0)
     switch (d) {
         case 32: FFB6D_LFA_D(32); break;
@@ -614,15 +617,15 @@ int lfa_pm_impl(int mode, const float* xyz4, int64_t xfs, const void* nei, int i
 using namespace ffb6d;
 
 // The p_hint an automatic launch resolves to (pure host logic; measured on the four level shapes of BASELINE configuration 2,
-// profiles/r03_lfa_levels.txt): point groups of 512 / d points (size 2) wherever the full-size groups would leave CUs without a
-// resident workgroup or cost occupancy -- fp32: every level but d = 128; bf16: d <= 64 -- and the fc / mlp weights resident in
-// LDS only for d = 32 (at d = 64 their 40 KB cost a resident workgroup).
+// profiles/r03_lfa_levels.txt).  Point groups: fp32 -- 256 / d points at d = 32 (92 registers: five waves per SIMD), 512 / d at
+// d = 64 and 256, 1024 / d at d = 128; bf16 -- 512 / d for d <= 64, else 1024 / d.  Weights: streamed from L2 everywhere --
+// keeping fc / mlp resident in LDS (w = 1, d <= 64) measured within +-3 % of it at d = 32 and 5-20 % slower at d = 64, where the
+// 40 KB cost a resident workgroup.
 extern "C" int ffb6d_lfa_pm_choice(int64_t npts, int64_t d, int bf16)
 {
     (void)npts;
-    const int size = bf16 ? (d <= 64 ? 2 : 1) : (d == 128 ? 1 : 2);
-    const int w = d == 32 ? 1 : 2;
-    return size + 4 * w;
+    const int size = bf16 ? (d <= 64 ? 2 : 1) : (d == 32 ? 3 : (d == 128 ? 1 : 2));
+    return size + 4 * 2;
 }
 
 extern "C" int ffb6d_lfa_pm(int dtype, int mode, const float* xyz4, int64_t xyz_frame_stride, const void* nei, int idx_bits, const void* f, int64_t ldf,

@@ -27,6 +27,11 @@ def _need_gpu(*ts):
 
 
 def _f32(t):
+    """float32 and contiguous.  Under torch.autocast (mixed-precision training: the convolutions hand over bfloat16 / float16
+    activations) the neighbour operators keep their fp32 kernels: reduced-precision floats are cast up (differentiably);
+    anything else is a caller error."""
+    if t.dtype in (torch.bfloat16, torch.float16) and torch.is_autocast_enabled():
+        t = t.float()
     if t.dtype != torch.float32:
         raise TypeError(f"float32 expected, got {t.dtype}")
     return t.contiguous()

@@ -7,10 +7,11 @@
  * which the reference binds from Cython (knn.pyx:7-30 `cdef extern from "knn_.h"`).
  * The six host-pointer entry points below keep the reference's names, argument order
  * and meaning (all six symbols knn.pyx declares, knn.pyx:7-30), exported with C linkage.
- * knn.pyx is compiled as C++ against the reference's knn_.h, whose declarations are
- * C++-mangled: to bind this library the maintainer points the `cdef extern from` at this
- * header instead (one-line change); tests/test_capi_cpu.py
- * compiles the reference's knn.pyx that way and links it against libffb6d_amd.so.  The result is the exact K-NN set in ascending distance order;
+ * knn.pyx needs NO edit to bind this library: include/knn_.h is a forwarding header with the
+ * reference header's name, so `cdef extern from "knn_.h"` picks these C-linkage declarations
+ * up once <repo>/include is on the include path; tests/test_capi_cpu.py
+ * compiles the reference's own knn.pyx that way and links it against libffb6d_amd.so.
+ * The result is the exact K-NN set in ascending distance order;
  * squared distances are evaluated in float32 as ((dx*dx + dy*dy) + dz*dz) with no FMA
  * contraction (nanoflann.hpp:323-348); equal distances resolve to the LOWEST support
  * index (the reference's kd-tree keeps the first-visited member of a tie,

@@ -9,7 +9,7 @@ bench.py's hot_path_ops.  Counter unit = 1024 B.  MI355X_MICROARCH.md (HBM): FET
 """
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 KEYS = [("mlp_pm_kernel<2, 2, 1, 4, false>", "mlp_pm<64x256>", 2.0), ("mlp_pm_kernel<2, 2, 2, 2, false>", "mlp_pm<128x128>", 2.0),
         ("mlp_pm_kernel<1, 2, 1, 4, false>", "mlp_pm<32x256>", 2.0), ("mlp_pm_kernel<1, 1, 2, 2, false>", "mlp_pm<64x64>", 2.0),
         ("mlp_pm_kernel<2, 1, 2, 2, true>", "mlp_pm<64x32,ksplit>", 2.0), ("mlp_pm_lds_kernel", "mlp_pm<lds128x128>", 2.0),
@@ -17,8 +17,9 @@ KEYS = [("mlp_pm_kernel<2, 2, 1, 4, false>", "mlp_pm<64x256>", 2.0), ("mlp_pm_ke
         ("affine_act_pm_kernel", "affine_act_pm", 2.0), ("bilinear_pm_kernel", "bilinear_resize_pm", 2.0),
         ("random_sample_pm_kernel", "random_sample_pm", 2.0), ("rel_pos_enc_pm_kernel", "relative_pos_encoding_pm", 1.0),
         ("psp_rowsum_pm_kernel", "psp_pool_pm", 2.0), ("psp_binsum_pm_kernel", "psp_pool_pm", 2.0),
-        ("psp_prior_sum_pm_kernel", "psp_prior_sum_pm", 2.0), ("knn_row16_kernel", "knn", 1.0), ("knn_pruned_kernel", "knn", 1.0),
-        ("knn_scan_kernel", "knn", 1.0)]
+        ("psp_prior_sum_pm_kernel", "psp_prior_sum_pm", 2.0), ("knn_row16", "knn", 1.0), ("knn_pruned", "knn", 1.0),
+        ("knn_scan", "knn", 1.0), ("lfa_pm_kernel", "lfa_pm", 2.0), ("upconv_combine", "upconv_combine_pm", 2.0),
+        ("affine_relu_maxpool_pm_kernel", "affine_relu_maxpool_pm", 2.0), ("posenc_mlp_pm_kernel", "posenc_mlp_pm", 1.0)]
 
 
 def read(path):

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round-end records on the GPU box, all from HEAD's defaults:  bash scripts/round_end.sh r03   (through gpurun; ~12 minutes)
+#   1. scripts/profile_round.sh: kernel stats + PMC FETCH_SIZE / WRITE_SIZE passes of the default bench
+#   2. the default bench line with cpu_baseline                                   -> <tag>_bench_default_run.json
+#   3. configurations 4 and 5: bench line with cpu_baseline + rocprofv3 kernel stats -> <tag>_bench_config{4,5}_run.json, <tag>_kernels_config{4,5}.txt
+#   4. per-op / per-shape table on one stream                                      -> <tag>_hot_path_ops_by_shape_one_stream.txt
+#   5. fused LFA: level table and PMC of the level-0 launch; MFMA-busy PMC of the dominant GEMM
+TAG=${1:-r03}
+cd "$(dirname "$0")/.." || exit 1
+REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
+bash scripts/profile_round.sh "$TAG" > /dev/null
+timeout 300 python bench.py > "$OUT/${TAG}_bench_default_run.json" 2> "$OUT/${TAG}_bench_default.err"
+for C in 4 5; do
+    timeout 300 python bench.py --config $C > "$OUT/${TAG}_bench_config${C}_run.json" 2> "$OUT/${TAG}_bench_config${C}.err"
+    ( cd /tmp && rm -rf /tmp/prof_c$C && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_c$C -o k -- python "$REPO/bench.py" --config $C --steps 5 --warmup 3 \
+          --no-cpu-baseline --mark-region > /dev/null 2> "$OUT/${TAG}_prof_c$C.err"
+      DB=$(find /tmp/prof_c$C -name '*.db' | head -1)
+      { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --config $C --steps 5 --warmup 3 --no-cpu-baseline --mark-region"
+        echo "# timed region only (between the two check_range_kernel markers), per-step = totals / 5"
+        python "$REPO/scripts/rocpd_stats.py" "$DB" --between check_range_kernel --steps 5 --top 40; } > "$OUT/${TAG}_kernels_config$C.txt" 2>&1 )
+done
+{ echo "# python bench.py --steps 10 --warmup 3 --no-cpu-baseline --streams 1 --trace-all   (one stream: clean per-kernel durations; bs=8, N=12288, fp32)"
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --streams 1 --trace-all 2>&1 >/dev/null | grep -v amdgpu.ids; } > "$OUT/${TAG}_hot_path_ops_by_shape_one_stream.txt"
+timeout 200 python scripts/bench_lfa.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_lfa_levels.txt"
+bash scripts/pmc_lfa.sh 0 1 f32 > /dev/null 2>&1; cp "$OUT/lfa_pmc_0_1_f32.txt" "$OUT/${TAG}_lfa_pmc_level0_half1.txt"
+bash scripts/pmc_pm_shape.sh 1024 2304 38400 f32 7 > /dev/null 2>&1; cp "$OUT/pm_shape_pmc_1024_2304_38400_f32_7.txt" "$OUT/${TAG}_mlp_pm_lds_pmc_1024_2304_38400.txt"
+python -c "
+import json
+for n in ('default', 'config4', 'config5'):
+    p = json.load(open('$OUT/${TAG}_bench_%s_run.json' % n))
+    print(n, round(p['value'], 1), 'frames/s', round(p['ms_per_step'], 2), 'ms', p['roofline']['kernel'], round(p['roofline']['frac'], 3), 'traffic', p['roofline']['traffic'], 'cpu', p.get('cpu_baseline', {}).get('value'))
+"

@@ -168,7 +168,7 @@ def _lfa_case(B, N, d, mode, dt, idt, seed):
 # one launch per half of the local feature aggregation (csrc/lfa_pm.hip): both halves, both group sizes of every width, both
 # index types, ragged tails (N not a multiple of the points per workgroup, groups that straddle two frames)
 @pytest.mark.parametrize("B,N,d,p_hint", [(2, 70, 32, 1), (1, 37, 32, 2), (2, 41, 64, 1), (1, 19, 64, 2), (2, 13, 128, 1), (1, 9, 128, 2),
-                                          (1, 7, 256, 1), (2, 3, 256, 2), (2, 70, 32, 9), (2, 41, 64, 10)])     # + 8: weights from L2
+                                          (1, 7, 256, 1), (2, 3, 256, 2), (2, 70, 32, 9), (2, 41, 64, 10), (2, 45, 32, 3), (1, 23, 64, 11)])     # + 8: weights from L2
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_fused_lfa_half_on_the_emulator(emu, B, N, d, p_hint, mode, dt):
