@@ -152,10 +152,14 @@ template <typename T, int D, int MODE, int P, bool WLDS> struct LfaGeom {
     static constexpr int LDS = S_BYTES + PL_BYTES + SRC_BYTES + BIAS_BYTES + WFC_BYTES + WM_BYTES + W2_BYTES;
 };
 
-template <typename T, int D, int MODE, int P, bool WLDS>
-__global__ void __launch_bounds__(BLK, 2)
+// NW = waves per workgroup.  4: the waves share one pair image and split the tiles of every phase (barriers between the phases).
+// 1 (d <= 64): a "workgroup" is ONE wave with its own small pair image -- no barrier anywhere, every phase is wave-local, and the
+// CU interleaves a dozen fully independent waves; the point groups are a quarter as large.
+template <typename T, int D, int MODE, int P, bool WLDS, int NW>
+__global__ void __launch_bounds__(64 * NW)
 lfa_pm_kernel(const LfaParams p)
 {
+    constexpr int NT = 64 * NW;                       // threads of the workgroup
     using G = LfaGeom<T, D, MODE, P, WLDS>;
     constexpr int SZ = El<T>::SZ;
     constexpr int KSTEP = 32 / SZ;                    // k per 32-byte step
@@ -165,14 +169,15 @@ lfa_pm_kernel(const LfaParams p)
     constexpr int RS = G::RS, ROWS = G::ROWS;
     constexpr int NRT = P / 2;                        // row tiles (2 points x 16 neighbours)
     constexpr int NCT = D / 32;                       // channel tiles of the score GEMM
-    constexpr int NCH = ROWS * CPR / BLK;             // chunks per thread of the row gather
-    constexpr int RPI = BLK / CPR;                    // pair rows covered by one chunk per thread
-    constexpr int NI = (ROWS + BLK - 1) / BLK;        // pair indices per thread
+    constexpr int NCH = ROWS * CPR / NT;              // chunks per thread of the row gather
+    constexpr int RPI = NT / CPR;                     // pair rows covered by one chunk per thread
+    constexpr int NI = (ROWS + NT - 1) / NT;          // pair indices per thread
     constexpr int COUT = MODE == 1 ? H : D;
     constexpr int OOB = 0x7ffffff0;
     static_assert(D % 32 == 0 && P % 2 == 0 && P <= 32, "tile geometry");
     static_assert(H % KSTEP == 0, "half a pair row must be whole 32-byte steps");
-    static_assert(BLK % CPR == 0 && (ROWS * CPR) % BLK == 0 && NCH >= 1, "chunks must divide evenly over the threads");
+    static_assert(NT % CPR == 0 && (ROWS * CPR) % NT == 0 && NCH >= 1, "chunks must divide evenly over the threads");
+    static_assert(NW == 4 || (NW == 1 && D <= 64 && !WLDS), "one wave per workgroup: d <= 64, weights from L2");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [pair image | pooled rows | source rows x 2 | biases | weights]
     unsigned char* const S = lds;
     unsigned char* const PL = lds + G::S_BYTES;
@@ -199,12 +204,13 @@ lfa_pm_kernel(const LfaParams p)
 
     // wave -> tiles of the three GEMM phases
     constexpr int CT1 = H / 32 > 0 ? H / 32 : 1;      // mlp1: channel tiles (H = 16: half a tile), row tiles wave, wave + 4, ..
-    constexpr int RT1 = (NRT + 3) / 4;
+    constexpr int RT1 = (NRT + NW - 1) / NW;
     constexpr int NOT2 = CT1;                         // mlp2: output channel tiles, waves first along them
-    constexpr int WR2 = 4 / NOT2;
+    constexpr int WR2 = NW / NOT2;
+    static_assert(NW % NOT2 == 0 && WR2 >= 1, "mlp2: the waves tile the output channels first");
     constexpr int RT2 = (NRT + WR2 - 1) / WR2;
-    constexpr int WC = NCT < 4 ? NCT : 4;             // scores: waves along the channel tiles, then along the row tiles
-    constexpr int WR = 4 / WC;
+    constexpr int WC = NCT < NW ? NCT : NW;           // scores: waves along the channel tiles, then along the row tiles
+    constexpr int WR = NW / WC;
     constexpr int TN = NCT / WC;
     constexpr int TM = (NRT + WR - 1) / WR;
     const int wc = wave % WC, wr = wave / WC;
@@ -226,16 +232,16 @@ lfa_pm_kernel(const LfaParams p)
         else return __builtin_amdgcn_raw_buffer_load_b128(rs_w2, w2_vo + s * 32, 0, 0);
     };
     // biases (and, WLDS, the weight images) -> LDS, once; published by the first barrier below
-    for (int c = threadIdx.x; c < 2 * H + COUT; c += BLK)
+    for (int c = threadIdx.x; c < 2 * H + COUT; c += NT)
         B1[c] = c < H ? p.b1[c] : (c < 2 * H ? (MODE == 2 ? p.b2[c - H] : 0.f) : p.bm[c - 2 * H]);
     if constexpr (WLDS) {
         constexpr int CW = D * SZ / 16, CW2 = H * SZ / 16;              // 16-byte chunks of a weight row
-        for (int c = threadIdx.x; c < D * CW; c += BLK)
+        for (int c = threadIdx.x; c < D * CW; c += NT)
             *reinterpret_cast<u32x4*>(WFC + (c / CW) * RS + (c % CW) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_fc, c * 16, 0, 0);
-        for (int c = threadIdx.x; c < COUT * CW; c += BLK)              // k-chunked table [k / VL][channel][VL] -> rows of the image
+        for (int c = threadIdx.x; c < COUT * CW; c += NT)              // k-chunked table [k / VL][channel][VL] -> rows of the image
             *reinterpret_cast<u32x4*>(WM + (c % COUT) * RS + (c / COUT) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_wm, c * 16, 0, 0);
         if constexpr (MODE == 2)
-            for (int c = threadIdx.x; c < (H < 32 ? 32 : H) * CW2; c += BLK)
+            for (int c = threadIdx.x; c < (H < 32 ? 32 : H) * CW2; c += NT)
                 *reinterpret_cast<u32x4*>(W2 + (c / CW2) * RS2 + (c % CW2) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_w2, c * 16, 0, 0);
     }
 
@@ -276,7 +282,7 @@ lfa_pm_kernel(const LfaParams p)
         const int base0 = (n0 / p.N) * p.N, next = base0 + p.N;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            const int r = tid + k * BLK, n = n0 + (r >> 4);
+            const int r = tid + k * NT, n = n0 + (r >> 4);
             int v = -1;
             if (gg < g_end && r < ROWS && n < p.npts) {
                 const size_t pair = (size_t)n0 * 16 + r;
@@ -291,7 +297,7 @@ lfa_pm_kernel(const LfaParams p)
     auto park_idx = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            const int r = tid + k * BLK;
+            const int r = tid + k * NT;
             if (r < ROWS) {
                 SRC[buf * SRCN + r] = idxr[k];
                 if ((r & 15) == 0) SRC[buf * SRCN + ROWS + (r >> 4)] = xdr[k];
@@ -307,7 +313,7 @@ lfa_pm_kernel(const LfaParams p)
         }
 #pragma unroll
         for (int j = 0; j < RT1; ++j) {
-            const int rt = wave + 4 * j;
+            const int rt = wave + NW * j;
             if (rt >= NRT) break;
             const int pp = 2 * rt + pp_l;
             const int sr = src[pp * 16 + nb_l];
@@ -335,7 +341,7 @@ lfa_pm_kernel(const LfaParams p)
         if constexpr (MODE == 2) gemm_early<T, H / KSTEP, 1, RT2, true>(ring2, w2_frag, w2_frag);
 #pragma unroll
         for (int j = 0; j < RT1; ++j) {
-            const int rt = wave + 4 * j;
+            const int rt = wave + NW * j;
             if (rt >= NRT) break;
             const float px = pq[j][0].x, py = pq[j][0].y, pz = pq[j][0].z, qx = pq[j][1].x, qy = pq[j][1].y, qz = pq[j][1].z;
             const float dx = px - qx, dy = py - qy, dz = pz - qz;
@@ -450,9 +456,9 @@ lfa_pm_kernel(const LfaParams p)
         // -----------------------------------------------------------------------------------------------------------
         if constexpr (SZ == 4) {
             __syncthreads();
-            constexpr int TPC = BLK / COUT;                            // threads per channel
+            constexpr int TPC = NT / COUT;                             // threads per channel
             constexpr int PPT = (P + TPC - 1) / TPC;                   // points per thread (threads past P * COUT outputs idle)
-            static_assert(COUT <= BLK && BLK % COUT == 0 && PPT >= 1, "output MLP: one channel per thread");
+            static_assert(COUT <= NT && NT % COUT == 0 && PPT >= 1, "output MLP: one channel per thread");
             const int c = tid % COUT, p0 = min((tid / COUT) * PPT, P - 1);
             const bool mine = (tid / COUT) * PPT < P;
             float acc[PPT];
@@ -482,11 +488,11 @@ lfa_pm_kernel(const LfaParams p)
             }
         } else {
             constexpr int NOT = COUT / 32 > 0 ? COUT / 32 : 1;         // channel tiles wo, wo + 4
-            constexpr int TMO = (NOT + 3) / 4;
-            const int wo = (wave + it) & 3;
+            constexpr int TMO = (NOT + NW - 1) / NW;
+            const int wo = (wave + it) % NW;
             // a fragment = VL consecutive k of one channel = ONE chunk of the k-chunked table; channels past COUT: out of range -> zeros
             auto wm_frag = [&](int s, int i) {
-                const int ch = (wo + 4 * i) * 32 + l31;
+                const int ch = (wo + NW * i) * 32 + l31;
                 if constexpr (WLDS) return *reinterpret_cast<const u32x4*>(WM + min(ch, COUT - 1) * RS + s * 32 + 16 * kh);
                 else return __builtin_amdgcn_raw_buffer_load_b128(rs_wm, ch < COUT ? ((2 * s + kh) * COUT + ch) * 16 : OOB, 0, 0);
             };
@@ -506,7 +512,7 @@ lfa_pm_kernel(const LfaParams p)
                     for (int i = 0; i < TMO; ++i) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int ch = (wo + 4 * i) * 32 + 8 * q + 4 * kh;
+                            const int ch = (wo + NW * i) * 32 + 8 * q + 4 * kh;
                             if (ch >= COUT) continue;
                             const float4 b4 = *reinterpret_cast<const float4*>(BM + ch);
                             El<T>::st4(orow + ch, make_float4(activate(acc[i][0][4 * q] + b4.x, p.slopem), activate(acc[i][0][4 * q + 1] + b4.y, p.slopem),
@@ -519,17 +525,17 @@ lfa_pm_kernel(const LfaParams p)
     }
 }
 
-template <typename T, int D, int MODE, int P, bool WLDS>
+template <typename T, int D, int MODE, int P, bool WLDS, int NW = 4>
 void launch_lfa(LfaParams& p, hipStream_t st)
 {
     using G = LfaGeom<T, D, MODE, P, WLDS>;
     p.n_grp = (int)ceil_div(p.npts, P);
-    const void* fn = reinterpret_cast<const void*>(&lfa_pm_kernel<T, D, MODE, P, WLDS>);
+    const void* fn = reinterpret_cast<const void*>(&lfa_pm_kernel<T, D, MODE, P, WLDS, NW>);
     // persistent workgroups: as many as are resident at once (registers + LDS), each walks its share of the point groups
     static const int per_cu = [&] {
         int n = 0;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, BLK, G::LDS) != hipSuccess || n < 1)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64 * NW, G::LDS) != hipSuccess || n < 1)
             n = 1;
         return n;
     }();
@@ -538,7 +544,7 @@ void launch_lfa(LfaParams& p, hipStream_t st)
     const char* e = getenv("FFB6D_LFA_WG_PER_XCD");
     const int64_t cap = e && atoi(e) > 0 ? (int64_t)atoi(e) : (int64_t)1 << 30;
     const unsigned grid = 8u * (unsigned)std::min<int64_t>(std::min<int64_t>(per_xcd, (int64_t)32 * per_cu), cap);
-    hipLaunchKernelGGL((lfa_pm_kernel<T, D, MODE, P, WLDS>), dim3(grid), dim3(BLK), G::LDS, st, p);
+    hipLaunchKernelGGL((lfa_pm_kernel<T, D, MODE, P, WLDS, NW>), dim3(grid), dim3(64 * NW), G::LDS, st, p);
 }
 
 // points per workgroup: 16 P d elements of pair image = 64 KB (fp32) whatever the level; `small` halves it (more, smaller
@@ -555,6 +561,7 @@ void launch_lfa_p(LfaParams& p, int size, bool wlds, hipStream_t st)
             return;
         }
         if (size == 3) { launch_lfa<T, D, MODE, P / 4, false>(p, st); return; }
+        if (size == 4) { launch_lfa<T, D, MODE, 128 / D, false, 1>(p, st); return; }      // one wave per workgroup: 4 / 2 points each
     }
     if (size >= 2) launch_lfa<T, D, MODE, P / 2, false>(p, st);
     else launch_lfa<T, D, MODE, P, false>(p, st);
@@ -591,10 +598,10 @@ int lfa_pm_impl(int mode, const float* xyz4, int64_t xfs, const void* nei, int i
     auto slope = [](int a) { return a == 0 ? 1.f : (a == 1 ? 0.f : 0.2f); };
     p.slope1 = slope(act1); p.slope2 = slope(act2); p.slopem = slope(actm);
     hipStream_t st = as_stream(stream);
-    const int size_hint = p_hint & 3, w_hint = (p_hint >> 2) & 3;
+    const int size_hint = p_hint & 7, w_hint = (p_hint >> 3) & 3;
     const int choice = ffb6d_lfa_pm_choice(npts, d, SZ == 2);
-    const int size = size_hint ? size_hint : (choice & 3);
-    const bool wlds = d <= 64 && (w_hint == 1 || (w_hint == 0 && (choice >> 2) == 1));
+    const int size = size_hint ? size_hint : (choice & 7);
+    const bool wlds = d <= 64 && size != 4 && (w_hint == 1 || (w_hint == 0 && (choice >> 3) == 1));
 #define FFB6D_LFA_D(D_)                                                              \
     do {                                                                             \
         if (mode == 1) launch_lfa_p<T, D_, 1>(p, size, wlds, st);                    \
@@ -625,7 +632,7 @@ extern "C" int ffb6d_lfa_pm_choice(int64_t npts, int64_t d, int bf16)
 {
     (void)npts;
     const int size = bf16 ? (d <= 64 ? 2 : 1) : (d == 32 ? 3 : (d == 128 ? 1 : 2));
-    return size + 4 * 2;
+    return size + 8 * 2;
 }
 
 extern "C" int ffb6d_lfa_pm(int dtype, int mode, const float* xyz4, int64_t xyz_frame_stride, const void* nei, int idx_bits, const void* f, int64_t ldf,

@@ -229,8 +229,9 @@ int ffb6d_posenc_mlp_pm(int dtype, const float* xyz, const void* idx, int idx_bi
  * [d / VL, cout, VL] (VL = 4 float32 / 8 bfloat16: 16 bytes of consecutive k per channel, so that the per-channel dot products of
  * the output MLP read it coalesced), b2 / bm float32; act* 0/1/2 = none / ReLU / LeakyReLU(0.2);
  * d in {32, 64, 128, 256}, K = 16.  Neither the encoding, nor the per-pair rows, nor the scores, nor the pooled rows touch HBM
- * (pair rows are staged in LDS, csrc/lfa_pm.hip).  p_hint = size + 4 * w: size 0 = automatic, 1 = 1024/d points per group, 2 = 512/d, 3 = 256/d (d <= 64);
- * w 0 = automatic, 1 = fc / mlp weights resident in LDS (d <= 64), 2 = streamed from L2. */
+ * (pair rows are staged in LDS, csrc/lfa_pm.hip).  p_hint = size + 8 * w: size 0 = automatic, 1 = 1024/d points per group, 2 = 512/d,
+ * 3 = 256/d (d <= 64), 4 = one wave per workgroup with 128/d points (d <= 64); w 0 = automatic, 1 = fc / mlp weights resident in
+ * LDS (d <= 64), 2 = streamed from L2. */
 int ffb6d_lfa_pm(int dtype, int mode, const float* xyz4, int64_t xyz_frame_stride, const void* nei, int idx_bits, const void* f, int64_t ldf,
                  const float* w1, int64_t ldw1, const float* b1, int act1, const void* w2, const float* b2, int act2,
                  const void* wfc, const void* wm_kc, const float* bm, int actm, void* out, int64_t ldo, int64_t B, int64_t N,

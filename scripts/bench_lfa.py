@@ -72,7 +72,7 @@ for dt in (torch.float32, torch.bfloat16):
             nbytes = B * N * (12 + 16 * ib + esz * (h + cout))
             t_ref = timeit(ref)
             line = "%s L%d d=%3d N=%5d half %d: chain %7.1f us |" % ("f32 " if esz == 4 else "bf16", lvl, d, N, mode, t_ref)
-            for ph in ((2, 3, 10, 11) if d <= 64 else (1, 2)):          # + 8: weights streamed from L2 instead of LDS-resident
+            for ph in ((2, 3, 4, 10) if d <= 64 else (1, 2)):          # 4: one wave per workgroup; + 8: weights resident in LDS
                 t = timeit(lambda: fn(ph))
-                line += " P=%2d%s %6.1f us %5.1f TF %4.0f GB/s |" % (1024 // d >> ((ph & 3) - 1), "L2" if ph & 8 else "  ", t, flops / t * 1e-6, nbytes / t * 1e-3)
+                line += " P=%2d%s %6.1f us %5.1f TF %4.0f GB/s |" % (128 // d if ph & 7 == 4 else 1024 // d >> ((ph & 7) - 1), "w1" if ph & 7 == 4 else ("LW" if ph & 8 else "  "), t, flops / t * 1e-6, nbytes / t * 1e-3)
             print(line + " maxdiff vs chain %.1e" % (e1 if mode == 1 else e2), flush=True)

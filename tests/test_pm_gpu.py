@@ -226,9 +226,10 @@ def _lfa_run(a, mode, device, p_hint=0):
                            a["wfc"].to(device), a["wm"].to(device), a["bm"].to(device), 2, p_hint=p_hint, **kw)
 
 
-# (B, N, d, p_hint): the four widths of the network at (scaled-down) level shapes, ragged tails, groups straddling frames, both
-# group sizes; the last two are the real level-0 / level-3 shapes of BASELINE configuration 2
+# (B, N, d, p_hint): the four widths of the network at (scaled-down) level shapes, ragged tails, groups straddling frames, every
+# group size (4 = one wave per workgroup, + 8 = weights resident in LDS); the last two are the real level-0 / level-3 shapes of BASELINE configuration 2
 LFA_CASES = [(2, 1000, 32, 1), (1, 777, 32, 2), (2, 771, 64, 0), (3, 193, 128, 1), (2, 190, 128, 2), (3, 47, 256, 1), (1, 50, 256, 2),
+             (2, 1001, 32, 3), (2, 1001, 32, 4), (2, 771, 64, 4), (2, 771, 64, 10),
              (8, 12288, 32, 0), (8, 192, 256, 0)]
 
 

@@ -168,7 +168,8 @@ def _lfa_case(B, N, d, mode, dt, idt, seed):
 # one launch per half of the local feature aggregation (csrc/lfa_pm.hip): both halves, both group sizes of every width, both
 # index types, ragged tails (N not a multiple of the points per workgroup, groups that straddle two frames)
 @pytest.mark.parametrize("B,N,d,p_hint", [(2, 70, 32, 1), (1, 37, 32, 2), (2, 41, 64, 1), (1, 19, 64, 2), (2, 13, 128, 1), (1, 9, 128, 2),
-                                          (1, 7, 256, 1), (2, 3, 256, 2), (2, 70, 32, 9), (2, 41, 64, 10), (2, 45, 32, 3), (1, 23, 64, 11)])     # + 8: weights from L2
+                                          (1, 7, 256, 1), (2, 3, 256, 2), (2, 70, 32, 9), (2, 41, 64, 10), (2, 45, 32, 3), (1, 23, 64, 11),
+                                          (2, 45, 32, 4), (1, 23, 64, 4)])     # + 8: weights resident in LDS; 4: one wave per workgroup
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_fused_lfa_half_on_the_emulator(emu, B, N, d, p_hint, mode, dt):
@@ -186,7 +187,8 @@ def test_fused_lfa_half_on_the_emulator(emu, B, N, d, p_hint, mode, dt):
     assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max())
 
 
-@pytest.mark.parametrize("B,N,d,p_hint,mode", [(2, 300, 32, 2, 1), (2, 300, 32, 2, 2), (1, 45, 256, 2, 2), (3, 50, 64, 1, 1)])
+@pytest.mark.parametrize("B,N,d,p_hint,mode", [(2, 300, 32, 2, 1), (2, 300, 32, 2, 2), (1, 45, 256, 2, 2), (3, 50, 64, 1, 1), (2, 150, 32, 4, 2),
+                                               (2, 70, 64, 4, 1)])
 def test_fused_lfa_persistent_loop_on_the_emulator(emu, monkeypatch, B, N, d, p_hint, mode):
     """the software pipeline over the point groups of a workgroup (indices two groups ahead, gathered rows one group ahead):
     one workgroup per XCD, so every workgroup walks several groups, the last ones ragged"""
