@@ -462,6 +462,18 @@ def main():
                 roofline["algorithmic_flops_per_step"] = r["flops"] / args.steps
             else:
                 roofline["algorithmic_bytes_per_launch"] = r["bytes"] / r["launches"]
+        if roofline and r["bound"] == "mfma" and roof_op.startswith("mlp_pm"):
+            # the same launches split by role: GEMMs of the north-star path (p2r / r2p fusion, decoder, heads) against those of
+            # the colour decoder (folded PSPUpsample z GEMMs, PSP bottleneck), which SURVEY section 2 lists as CNN
+            recs = tracer.records.get(roof_op, [])
+            parts = {}
+            for st, en, _, tag in recs:
+                role = "north_star_path" if (len(tag) < 6 or tag[5] == "path") else "colour_decoder"
+                a = parts.setdefault(role, [0.0, 0.0, 0])
+                a[0] += gemm_flops(roof_op, tag, args.batch); a[1] += st.elapsed_time(en) * 1e-3; a[2] += 1
+            roofline["by_role"] = {k: {"launches_per_step": v[2] / args.steps, "achieved": v[0] / v[1] / 1e12 if v[1] > 0 else 0.0,
+                                       "frac": (v[0] / v[1] / 1e12 / r["peak"]) if v[1] > 0 else 0.0, "ms_per_step": 1e3 * v[1] / args.steps,
+                                       "flops_per_step": v[0] / args.steps} for k, v in parts.items()}
         if roofline and serial is not None:
             iso = roofline_of(serial, roof_op)
             if iso:

@@ -40,17 +40,14 @@ upconv_combine_block_pm_kernel(const upconv::CombineArgs a)
     upconv::combine_block_body<T, FORM>(a, (int)by, (int)(bx * BLK + threadIdx.x));
 }
 
-// FFB6D_UPCONV_COMBINE = simple | select | static | row (A/B): one pixel per thread; 2 x 4 block with operand selects; the same
-// block with the compile-time operand pattern per tap (default: measured 2.2 - 2.7 TB/s, profiles/r02_upconv_blend_forms_ab.txt);
-// "row" = the pattern per filter row with the three taps' loads in flight together -- bit-identical on the host simulation,
-// but 346 registers (one wave per SIMD) and unmeasured: opt-in until a GPU says otherwise
+// FFB6D_UPCONV_COMBINE = simple | select | static (A/B): one pixel per thread; 2 x 4 block with operand selects; the same
+// block with the compile-time operand pattern per tap (default: measured 2.2 - 2.8 TB/s, profiles/r03_upconv_blend_forms_ab.txt)
 int combine_form()
 {
     static const int form = [] {
         const char* v = getenv("FFB6D_UPCONV_COMBINE");
         if (v && strcmp(v, "simple") == 0) return 0;
         if (v && strcmp(v, "select") == 0) return 1;
-        if (v && strcmp(v, "row") == 0) return 3;
         return 2;
     }();
     return form;
@@ -90,9 +87,7 @@ extern "C" int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* sh
         a.nbx = (unsigned)ceil_div(OW / 4 * (int64_t)a.q, BLK);
         a.nby = (unsigned)(B * OH / 2);
         const dim3 grid((unsigned)(8 * ceil_div((int64_t)a.nbx * a.nby, 8)));
-        if (form == 3)
-            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, 3>), grid, dim3(BLK), 0, as_stream(stream), a);
-        else if (form == 2)
+        if (form == 2)
             hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, 2>), grid, dim3(BLK), 0, as_stream(stream), a);
         else
             hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, 1>), grid, dim3(BLK), 0, as_stream(stream), a);

@@ -257,28 +257,10 @@ __host__ __device__ __forceinline__ void tap_static(const CombineArgs& a, const 
     win_blend<T, KYM, KXM, NR, NC>(ay, ax, win, acc);
 }
 
-// the three taps of one filter row at once: all of their loads (20 or 30 sixteen-byte loads) are issued before the first blend.
-// Per-tap, the kernel makes nine dependent round trips to memory with three waves per SIMD to hide them: it is latency bound
-// (measured 2.2 - 2.7 TB/s with neither the vector ALU, the L1 nor HBM near their limits); per row it makes three.
-// Same blends in the same order (kx = 0, 1, 2) as the per-tap form: bit-identical.
-template <typename T, bool KYM>
-__host__ __device__ __forceinline__ void row_static(const CombineArgs& a, const Axis2& ay, const Axis4& ax0, const Axis4& ax1,
-                                                    const Axis4& ax2, size_t tapoff0, size_t q9, int b,
-                                                    float (&acc)[2][4][Unit<T>::VL])
-{
-    constexpr int NR = KYM ? 3 : 2;
-    Unit<T> w0[NR][3], w1[NR][4], w2[NR][3];
-    win_load<T, NR, 3>(a, ay, ax0, tapoff0, q9, b, w0);
-    win_load<T, NR, 4>(a, ay, ax1, tapoff0 + a.q, q9, b, w1);
-    win_load<T, NR, 3>(a, ay, ax2, tapoff0 + 2 * (size_t)a.q, q9, b, w2);
-    win_blend<T, KYM, false, NR, 3>(ay, ax0, w0, acc);
-    win_blend<T, KYM, true, NR, 4>(ay, ax1, w1, acc);
-    win_blend<T, KYM, false, NR, 3>(ay, ax2, w2, acc);
-}
-
 // rowblk = b * (OH / 2) + pair of output rows, t = (block of 4 output columns) * q + unit
-// FORM: 1 = operand selects for every tap, 2 = compile-time pattern per tap where it holds, 3 = compile-time pattern per filter
-// row (three taps' loads in flight together) where it holds for the whole row, else per tap
+// FORM: 1 = operand selects for every tap, 2 = compile-time pattern per tap where it holds.  (A third form that issued the three
+// taps of a filter row together was measured and removed: 346 registers, one wave per SIMD, 1.5 - 1.8 TB/s against 2.2 - 2.8,
+// profiles/r03_upconv_blend_forms_ab.txt.)
 template <typename T, int FORM>
 __host__ __device__ __forceinline__ void combine_block_body(const CombineArgs& a, int rowblk, int t)
 {
@@ -306,23 +288,6 @@ __host__ __device__ __forceinline__ void combine_block_body(const CombineArgs& a
         bool rows_ok = STATIC;
 #pragma unroll
         for (int i = 0; i < 2; ++i) rows_ok = rows_ok && ay.a[i] == pattern_a(ky == 1, i) && ay.b[i] == ay.a[i] + 1;
-        if constexpr (FORM == 3) {
-            Axis4 ax0, ax1, ax2;
-            tap_axis<4>(ax0, X0, 0, a.OW, a.IW, a.rw);
-            tap_axis<4>(ax1, X0, 1, a.OW, a.IW, a.rw);
-            tap_axis<4>(ax2, X0, 2, a.OW, a.IW, a.rw);
-            bool ok = rows_ok;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                ok = ok && ax0.a[j] == pattern_a(false, j) && ax0.b[j] == ax0.a[j] + 1 && ax1.a[j] == pattern_a(true, j) &&
-                     ax1.b[j] == ax1.a[j] + 1 && ax2.a[j] == pattern_a(false, j) && ax2.b[j] == ax2.a[j] + 1;
-            if (ok) {
-                const size_t tapoff0 = (size_t)(ky * 3) * a.q + c;
-                if (ky == 1) row_static<T, true>(a, ay, ax0, ax1, ax2, tapoff0, q9, b, acc);
-                else row_static<T, false>(a, ay, ax0, ax1, ax2, tapoff0, q9, b, acc);
-                continue;
-            }
-        }
 #pragma unroll 1
         for (int kx = 0; kx < 3; ++kx) {
             Axis4 ax;

@@ -206,11 +206,11 @@ def pyramid_pooling(pp, x):
     pooled = ops_pm.psp_pool(x, sizes)                                                        # [B,50,512] fp32
     zs, off = [], 0
     for s, wl in zip(sizes, prods):                                                           # 50 columns: fp32 in both precisions
-        zs.append(ops_pm.mlp(pooled[:, off:off + s * s].contiguous(), wl))
+        zs.append(ops_pm.mlp(pooled[:, off:off + s * s].contiguous(), wl, role="cnn"))
         off += s * s
     prior = ops_pm.psp_prior_sum(torch.cat(zs, dim=1), sizes, (h, w_), dtype=x.dtype)         # [B,h,w,1024]
     wx = cached(pp, "wx%s" % x.dtype, [bw], lambda: wx.to(x.dtype))
-    return ops_pm.mlp(x, wx, pp.bottleneck.bias.detach().float(), ops.ACT_RELU, add=prior)
+    return ops_pm.mlp(x, wx, pp.bottleneck.bias.detach().float(), ops.ACT_RELU, add=prior, role="cnn")
 
 
 # Which PSPUpsample blocks run in the folded form (csrc/upconv.hip).  FFB6D_UPCONV_FOLD: "auto" (default) = every block in
@@ -268,7 +268,7 @@ def up_block(ub, x):
     if _fold_block(cin, x.dtype) and cv.kernel_size == (3, 3) and cv.padding == (1, 1) \
             and cv.stride == (1, 1) and cv.dilation == (1, 1) and cv.groups == 1:
         w9, shift, slope = upconv_folded(ub, x.dtype)
-        z = ops_pm.mlp(x, w9)                                                                 # [B,h,w,9*cout]
+        z = ops_pm.mlp(x, w9, role="cnn")                                                     # [B,h,w,9*cout]
         return ops_pm.upconv_combine(z, shift, slope, (2 * h, 2 * w_))
     y = ops_pm.bilinear_resize(x, (2 * h, 2 * w_), align_corners=True)
     y = conv(y, cv)
@@ -286,7 +286,7 @@ def final_head(fh, x):
     """pspnet.py:108-112 `final`: Conv2d(64,64,1) + LogSoftmax(dim=1) as one GEMM with a log-softmax epilogue."""
     cv = fh[0]
     w = cached(fh, "w%s" % x.dtype, [cv.weight], lambda: cv.weight.detach().reshape(cv.out_channels, -1).to(x.dtype).contiguous())
-    return ops_pm.mlp(x, w, cv.bias.detach().float(), ops_pm.ACT_LOG_SOFTMAX)
+    return ops_pm.mlp(x, w, cv.bias.detach().float(), ops_pm.ACT_LOG_SOFTMAX, role="cnn")
 
 
 def cnn_stage(stage, x):

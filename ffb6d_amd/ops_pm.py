@@ -30,7 +30,7 @@ def rows_view(x):
 ACT_LOG_SOFTMAX = 3
 
 
-def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gather=None, out=None, tile_hint=0):
+def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gather=None, out=None, tile_hint=0, role="path"):
     """Shared MLP (1x1 conv + folded BatchNorm + activation; pytorch_utils.py:75-129, RandLA/pytorch_utils.py:35-111)
     on row-major activations:  out[r,:] = act(w @ cat(x1[r], x2[r]) + bias + extra[r])
         x1 [..., K1], x2 [..., K2] or None, w [Cout, K1+K2] (conv weight layout, BN folded), bias [Cout] or None
@@ -38,7 +38,8 @@ def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gathe
         gather    = (Y [B, Py, Cout], idx [B, P]): extra[b, p] = Y[b, idx[b, p]]            (conv(cat(a, interp(b))))
         x1_gather = idx [B, P]: x1 is [B, M, K1] and row (b, p) of the GEMM reads x1[b, idx[b, p]]   (`choose`, :309-312)
     act: ACT_NONE / ACT_RELU / ACT_LEAKY / ACT_LOG_SOFTMAX (over the Cout <= 64 channels, pspnet.py:108-112).
-    Returns [..., Cout] (or writes `out`, which may be a channel slice of a wider row buffer)."""
+    Returns [..., Cout] (or writes `out`, which may be a channel slice of a wider row buffer).
+    `role` only labels the launch in traces (bench.py reports the north-star path's GEMMs and the colour decoder's separately)."""
     _need_gpu(x1, w)
     lib = _lib.load()
     dt = _dt(x1, w, x2, add, gather[0] if gather is not None else None, out)
@@ -100,7 +101,7 @@ def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gathe
         tile = int(tile_hint) if tile_hint > 0 else lib.ffb6d_mlp_pm_choice(rows, Cout, K1, K2, int(act), int(dt), int(xi is not None))
     else:
         tile = 0
-    with torch.cuda.device(x1.device), _lib.traced("mlp_pm", nbytes, (K1 + K2, Cout, rows, tile, dt)):
+    with torch.cuda.device(x1.device), _lib.traced("mlp_pm", nbytes, (K1 + K2, Cout, rows, tile, dt, role)):
         rc = (lib.ffb6d_mlp_pm_bf16 if dt else lib.ffb6d_mlp_pm_f32)(w.data_ptr(), bias.data_ptr() if bias is not None else None,
                                   a.data_ptr(), K1, ld1, xi.data_ptr() if xi is not None else None, px,
                                   b.data_ptr() if b is not None else None, K2, ld2,

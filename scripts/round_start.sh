@@ -11,7 +11,7 @@ bash scripts/profile_round.sh "${TAG}_start"
 for C in 4 5; do
     timeout 300 python bench.py --config $C --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_start_bench_config${C}_run.json" 2> "$OUT/${TAG}_start_bench_config${C}.err"
 done
-{ for F in static row; do FFB6D_UPCONV_COMBINE=$F timeout 60 python scripts/blend_forms_ab.py; done
+{ for F in static select; do FFB6D_UPCONV_COMBINE=$F timeout 60 python scripts/blend_forms_ab.py; done
   echo "--- row-major workgroup order (FFB6D_UPCONV_XCD=0)"
   FFB6D_UPCONV_XCD=0 timeout 60 python scripts/blend_forms_ab.py; } > "$OUT/${TAG}_upconv_blend_forms_ab.txt" 2>&1
 FFB6D_STEM_FUSED=0 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_start_bench_stem_unfused.json" 2> /dev/null

@@ -31,12 +31,10 @@ extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shi
         for (int rb = 0; rb < (int)(B * OH / 2); ++rb)
             for (int t = 0; t < threads; ++t) {
                 if (dtype == 1) {
-                    if (blocked == 3) combine_block_body<__bf16, 3>(a, rb, t);
-                    else if (blocked == 2) combine_block_body<__bf16, 2>(a, rb, t);
+                    if (blocked == 2) combine_block_body<__bf16, 2>(a, rb, t);
                     else combine_block_body<__bf16, 1>(a, rb, t);
                 } else {
-                    if (blocked == 3) combine_block_body<float, 3>(a, rb, t);
-                    else if (blocked == 2) combine_block_body<float, 2>(a, rb, t);
+                    if (blocked == 2) combine_block_body<float, 2>(a, rb, t);
                     else combine_block_body<float, 1>(a, rb, t);
                 }
             }

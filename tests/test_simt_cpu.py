@@ -176,6 +176,8 @@ def test_fused_lfa_half_on_the_emulator(emu, B, N, d, p_hint, mode, dt):
     """Building_block.forward, RandLANet.py:196-214: gather + position encoding + mlp1 (+ mlp2) + attentive pooling + mlp in
     one kernel, pair rows in LDS only -- against the float64 restatement (oracle/ops_ref.lfa_half)"""
     from oracle import ops_ref
+    if dt == torch.bfloat16 and (p_hint in (2, 3, 10, 11) or (d == 256 and mode == 1)):
+        pytest.skip("bf16: one group size per width is enough on the emulator (the GPU suite runs them all)")
     idt = torch.int64 if (N + mode) % 2 else torch.int32
     a = _lfa_case(B, N, d, mode, dt, idt, seed=N + d + mode)
     kw = dict(w2=a["w2"], b2=a["b2"], act2=2) if mode == 2 else {}
