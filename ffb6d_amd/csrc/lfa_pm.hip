@@ -625,14 +625,15 @@ using namespace ffb6d;
 
 // The p_hint an automatic launch resolves to (pure host logic; measured on the four level shapes of BASELINE configuration 2,
 // profiles/r03_lfa_levels.txt).  Point groups: fp32 -- 256 / d points at d = 32 (92 registers: five waves per SIMD), 512 / d at
-// d = 64 and 256, 1024 / d at d = 128; bf16 -- 512 / d for d <= 64, else 1024 / d.  Weights: streamed from L2 everywhere --
-// keeping fc / mlp resident in LDS (w = 1, d <= 64) measured within +-3 % of it at d = 32 and 5-20 % slower at d = 64, where the
-// 40 KB cost a resident workgroup.
+// d = 64 and 256, 1024 / d at d = 128; bf16 -- 512 / d for d <= 64, else 1024 / d.  Weights: streamed from L2, except bf16 at
+// d = 64 (LDS-resident fc / mlp: 25 against 36 us on the first half); in fp32 LDS residence measured within +-3 % at d = 32 and
+// 5-20 % slower at d = 64, where the 40 KB cost a resident workgroup.  The one-wave form (size 4) measured within +-5 % of these.
 extern "C" int ffb6d_lfa_pm_choice(int64_t npts, int64_t d, int bf16)
 {
     (void)npts;
     const int size = bf16 ? (d <= 64 ? 2 : 1) : (d == 32 ? 3 : (d == 128 ? 1 : 2));
-    return size + 8 * 2;
+    const int w = (bf16 && d == 64) ? 1 : 2;
+    return size + 8 * w;
 }
 
 extern "C" int ffb6d_lfa_pm(int dtype, int mode, const float* xyz4, int64_t xyz_frame_stride, const void* nei, int idx_bits, const void* f, int64_t ldf,
