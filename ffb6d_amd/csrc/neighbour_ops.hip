@@ -19,6 +19,9 @@
 #include <cfloat>
 
 namespace ffb6d {
+bool nearest_interp_bwd_lds(const float* grad_out, const void* idx, int idx_bits, float* grad_feat, int64_t B, int64_t C, int64_t M,
+                            int64_t U, hipStream_t st);      // csrc/train_ops.hip
+
 namespace {
 
 constexpr int BLK = 256;
@@ -550,6 +553,12 @@ int ffb6d_nearest_interpolation_bwd_f32(const float* grad_out, const void* idx, 
     if (B == 0 || C == 0) return FFB6D_OK;
     FFB6D_REQUIRE(grad_out && idx && grad_feat, "nearest_interpolation_bwd: null pointer");
     hipStream_t st = as_stream(stream);
+    // rows of one frame and a group of channels privatised in LDS (csrc/train_ops.hip) whenever M rows of floats fit: no global
+    // atomics, no memset; else the global scatter-add below
+    if (U > 0 && nearest_interp_bwd_lds(grad_out, idx, idx_bits, grad_feat, B, C, M, U, st)) {
+        FFB6D_LAUNCH_CHECK();
+        return FFB6D_OK;
+    }
     FFB6D_HIP_TRY(hipMemsetAsync(grad_feat, 0, (size_t)B * C * M * sizeof(float), st));
     const size_t total = (size_t)B * C * U;
     if (total == 0) return FFB6D_OK;

@@ -310,7 +310,13 @@ class UpBlock(nn.Module):
 
     def forward(self, x):
         if _autograd_path(x, self):
-            return self.conv(x)
+            if not x.is_cuda:
+                return self.conv(x)
+            # training on the GPU: same modules and arithmetic, but the up-sampling and the PReLU carry hand-written backward
+            # passes (csrc/train_ops.hip: gather instead of ATen's atomic scatter; slope gradient reduced in the kernel)
+            _, conv, bn, prelu = self.conv
+            y = ops.upsample_align(x, (2 * x.shape[2], 2 * x.shape[3]))
+            return ops.prelu(bn(conv(y)), prelu.weight)
         y = ops.bilinear_resize(x, (2 * x.shape[2], 2 * x.shape[3]), align_corners=True)
         conv, bn, prelu = self.conv[1], self.conv[2], self.conv[3]
         if prelu.weight.numel() != 1 or (y.shape[2] * y.shape[3]) % 4:

@@ -299,6 +299,88 @@ def att_pool(feature_set, att_activation):
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# training-side replacements for the two slowest non-convolution backward passes of the colour decoder (PSPUpsample,
+# pspnet.py:34-45; csrc/train_ops.hip).  Forward results are torch's own; what changes is the backward.
+# ----------------------------------------------------------------------------------------------------------------------
+def _rows_dt(t):
+    return {torch.float32: 0, torch.bfloat16: 1}.get(t.dtype)
+
+
+class _UpsampleAlign(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True) whose backward is a gather (ffb6d_bilinear_bwd_pm) instead
+    of ATen's atomic scatter."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, size):
+        ctx.in_shape = tuple(x.shape)
+        return torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=True)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        B, C, IH, IW = ctx.in_shape
+        OH, OW = g.shape[2], g.shape[3]
+        dt = _rows_dt(g)
+        vl = 8 if dt == 1 else 4
+        if g.is_cuda and dt is not None and C % vl == 0 and IH > 1 and IW > 1 and IH <= OH <= 4 * IH - 3 and IW <= OW <= 4 * IW - 3 \
+                and B * IH < 65536:
+            g = g.contiguous(memory_format=torch.channels_last)              # pixel-major rows [B,OH,OW,C]
+            gin = torch.empty((B, C, IH, IW), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+            nbytes = g.element_size() * (g.numel() + gin.numel())
+            with torch.cuda.device(g.device), _lib.traced("bilinear_bwd_pm", nbytes, (C, OH, OW)):
+                rc = _lib.load().ffb6d_bilinear_bwd_pm(dt, g.data_ptr(), gin.data_ptr(), B, IH, IW, OH, OW, C, _stream(g))
+            _lib.check(rc, "ffb6d_bilinear_bwd_pm")
+            return gin, None
+        return torch.ops.aten.upsample_bilinear2d_backward(g, [OH, OW], list(ctx.in_shape), True, None, None), None
+
+
+def upsample_align(x, size):
+    """bilinear, align_corners=True (pspnet.py:37-42) with the gather backward; x [B,C,IH,IW]."""
+    return _UpsampleAlign.apply(x, (int(size[0]), int(size[1])))
+
+
+class _PReLU(torch.autograd.Function):
+    """Single-slope PReLU on a dense tensor of any memory format: the slope's gradient is reduced inside the backward kernel
+    (ATen materialises a gradient tensor as large as the map and reduces it afterwards)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight):
+        y = torch.empty_like(x)                                            # same strides as x
+        with torch.cuda.device(x.device), _lib.traced("prelu_fwd", 2 * x.element_size() * x.numel(), (x.numel(),)):
+            rc = _lib.load().ffb6d_prelu_fwd(_rows_dt(x), x.data_ptr(), weight.data_ptr(), y.data_ptr(), x.numel(), _stream(x))
+        _lib.check(rc, "ffb6d_prelu_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        if g.dtype != x.dtype or g.stride() != x.stride():
+            g = torch.empty_like(x).copy_(g)
+        gx = torch.empty_like(x)
+        ga = torch.empty(1, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), _lib.traced("prelu_bwd", 3 * x.element_size() * x.numel(), (x.numel(),)):
+            rc = _lib.load().ffb6d_prelu_bwd(_rows_dt(x), x.data_ptr(), g.data_ptr(), weight.data_ptr(), gx.data_ptr(), ga.data_ptr(),
+                                             x.numel(), _stream(x))
+        _lib.check(rc, "ffb6d_prelu_bwd")
+        return gx, ga.to(weight.dtype).reshape(weight.shape)
+
+
+def prelu(x, weight):
+    """torch.nn.functional.prelu(x, weight) for a single float32 slope, with the in-kernel slope gradient; anything the
+    kernel does not cover (per-channel slopes, other dtypes, non-dense or unaligned tensors) goes to torch."""
+    dt = _rows_dt(x)
+    dense = x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
+    if not (x.is_cuda and dt is not None and weight.numel() == 1 and weight.dtype == torch.float32 and dense
+            and x.numel() % (8 if dt else 4) == 0 and x.data_ptr() % 16 == 0):
+        return torch.nn.functional.prelu(x, weight.to(x.dtype) if weight.dtype != x.dtype else weight)
+    return _PReLU.apply(x, weight)
+
+
 def _rows(x):
     """[B,K,*spatial] -> (tensor viewed as [B,K,P] with contiguous rows, batch stride in floats)."""
     B, K = x.shape[0], x.shape[1]

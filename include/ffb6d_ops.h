@@ -238,6 +238,17 @@ int ffb6d_lfa_pm(int dtype, int mode, const float* xyz4, int64_t xyz_frame_strid
                  int K, int64_t d, int p_hint, ffb6d_stream_t stream);
 /* the p_hint an automatic launch (p_hint 0) resolves to (pure host logic) */
 int ffb6d_lfa_pm_choice(int64_t npts, int64_t d, int bf16);
+/* Backward bodies of the colour decoder's PSPUpsample for training (csrc/train_ops.hip), on pixel-major rows = torch's
+ * channels_last memory format; dtype 0 = float32, 1 = bfloat16 rows, fp32 arithmetic.
+ * ffb6d_bilinear_bwd_pm: gradient of the align_corners = True bilinear up-sampling (pspnet.py:37-42) as a gather with ATen's
+ * source-index arithmetic: grad_out [B,OH,OW,C] -> grad_in [B,IH,IW,C] (up-sampling by at most 4, maps of at least 2 x 2 pixels).
+ * ffb6d_prelu_fwd / _bwd: single-slope PReLU (pspnet.py:43) on n elements; the backward writes grad_x and the slope's gradient
+ * (*grad_slope is overwritten: reduced inside the kernel, fp32). */
+int ffb6d_bilinear_bwd_pm(int dtype, const void* grad_out, void* grad_in, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
+                          int64_t C, ffb6d_stream_t stream);
+int ffb6d_prelu_fwd(int dtype, const void* x, const float* slope, void* y, int64_t n, ffb6d_stream_t stream);
+int ffb6d_prelu_bwd(int dtype, const void* x, const void* grad_out, const float* slope, void* grad_x, float* grad_slope, int64_t n,
+                    ffb6d_stream_t stream);
 /* Second half of the folded up-convolution (PSPUpsample, pspnet.py:34-45: bilinear x2 with align_corners -> Conv2d 3x3,
  * padding 1 -> BatchNorm -> PReLU).  z [B,IH,IW,9,C] holds, per low-resolution pixel and filter tap (ky*3+kx), the channel
  * mixing (BatchNorm scale * W[:, :, ky, kx]) x -- one ffb6d_mlp_pm GEMM with 9*C output channels -- and

@@ -322,3 +322,63 @@ def test_att_score_pool_equals_unfused_attentive_pooling(device, B, d1, d2, N):
     got = ops.att_score_pool(f1.to(device), f2.to(device), w.t().contiguous().to(device)).cpu()
     assert got.shape == (B, d1 + d2, N, 1)
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def _grad_pair(fn_ours, fn_ref, x, extra=()):
+    """gradients of (y * r).sum() through our Function and through the torch reference"""
+    outs = []
+    for fn in (fn_ours, fn_ref):
+        xs = x.detach().clone().requires_grad_(True)
+        ex = [e.detach().clone().requires_grad_(True) for e in extra]
+        y = fn(xs, *ex)
+        r = torch.linspace(-1.0, 1.0, y.numel(), device=y.device).reshape(y.shape).to(y.dtype)
+        (y.float() * r.float()).sum().backward()
+        outs.append((y.detach(), xs.grad, [e.grad for e in ex]))
+    return outs
+
+
+@pytest.mark.parametrize("B,C,IH,IW,fmt", [(2, 8, 5, 7, "cl"), (1, 16, 2, 2, "cl"), (2, 8, 6, 4, "nchw"), (1, 24, 9, 3, "cl")])
+def test_upsample_align_gather_backward_matches_aten(device, B, C, IH, IW, fmt):
+    """pspnet.py:37-42: bilinear x2 with align_corners; forward = torch's, backward = ffb6d_bilinear_bwd_pm (a gather with ATen's
+    source-index arithmetic) against ATen's own scatter backward"""
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(IH * IW + C)
+    x = torch.randn(B, C, IH, IW, generator=g).to(device)
+    if fmt == "cl":
+        x = x.contiguous(memory_format=torch.channels_last)
+    (y, gx, _), (yr, gr, _) = _grad_pair(lambda t: ops.upsample_align(t, (2 * IH, 2 * IW)),
+                                          lambda t: F.interpolate(t, size=(2 * IH, 2 * IW), mode="bilinear", align_corners=True), x)
+    assert torch.equal(y, yr)
+    torch.testing.assert_close(gx, gr, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,fmt,dt", [((2, 8, 5, 6), "cl", torch.float32), ((3, 16, 4, 4), "nchw", torch.float32), ((2, 8, 6, 6), "cl", torch.bfloat16)])
+@pytest.mark.parametrize("slope", [0.25, 1.5, -0.3])
+def test_prelu_with_in_kernel_slope_gradient_matches_torch(device, shape, fmt, dt, slope):
+    """single-slope PReLU (pspnet.py:43), any learned slope: y, grad_x and the slope's gradient against torch"""
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(int(slope * 100) + shape[1])
+    x = torch.randn(*shape, generator=g).to(dt).to(device)
+    if fmt == "cl":
+        x = x.contiguous(memory_format=torch.channels_last)
+    w = torch.tensor([slope], device=x.device)
+    (y, gx, (gw,)), (yr, gr, (gwr,)) = _grad_pair(ops.prelu, lambda t, a: F.prelu(t.float(), a).to(t.dtype), x, (w,))
+    tol = 1e-6 if dt == torch.float32 else 1e-2
+    torch.testing.assert_close(y.float(), yr.float(), rtol=tol, atol=tol)
+    torch.testing.assert_close(gx.float(), gr.float(), rtol=tol, atol=tol)
+    torch.testing.assert_close(gw, gwr, rtol=1e-3 if dt == torch.float32 else 3e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,C,M,U,idt", [(2, 8, 50, 400, torch.int64), (3, 70, 17, 90, torch.int32), (1, 4, 3072, 5000, torch.int64)])
+def test_nearest_interpolation_backward_privatised_in_lds(device, B, C, M, U, idt):
+    """FFB6D.nearest_interpolation (ffb6d.py:179-194) backward: the scatter-add of the pixel gradients, privatised per (frame,
+    channel group) in LDS, against torch.gather's autograd"""
+    g = torch.Generator().manual_seed(M + U)
+    feat = torch.randn(B, C, M, 1, generator=g).to(device)
+    idx = torch.randint(0, M, (B, U, 1), generator=g).to(idt).to(device)
+
+    def ref(f):
+        return torch.gather(f.squeeze(3), 2, idx.long().reshape(B, 1, U).expand(-1, C, -1)).unsqueeze(3)
+    (y, gf, _), (yr, gr, _) = _grad_pair(lambda f: ops.nearest_interpolation(f, idx), ref, feat)
+    assert torch.equal(y, yr)
+    torch.testing.assert_close(gf, gr, rtol=1e-5, atol=1e-4)
