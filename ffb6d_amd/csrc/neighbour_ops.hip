@@ -424,6 +424,46 @@ att_pool_bwd_kernel(const float* __restrict__ grad_out, const float* __restrict_
     }
 }
 
+// K = 16 (the network's neighbourhood size): a row is one 64-byte line -- four 16-byte loads per operand, every exponential
+// computed once, four 16-byte stores per gradient: the pass moves its 4 x 64 bytes per row at the HBM rate (the generic kernel
+// above reads a row as 16 scalar loads per lane, 64 lines per instruction, and evaluates every exponential three times)
+__global__ void __launch_bounds__(BLK)
+att_pool_bwd16_kernel(const float* __restrict__ grad_out, const float4* __restrict__ feat, const float4* __restrict__ act,
+                      float4* __restrict__ grad_feat, float4* __restrict__ grad_act, size_t rows)
+{
+    const size_t row = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (row >= rows) return;
+    float f[16], e[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 fv = feat[row * 4 + q], av = act[row * 4 + q];
+        f[4 * q] = fv.x; f[4 * q + 1] = fv.y; f[4 * q + 2] = fv.z; f[4 * q + 3] = fv.w;
+        e[4 * q] = av.x; e[4 * q + 1] = av.y; e[4 * q + 2] = av.z; e[4 * q + 3] = av.w;
+    }
+    float m = e[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, e[k]);
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { e[k] = expf(e[k] - m); den += e[k]; }
+    float y = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { e[k] = e[k] / den; y += f[k] * e[k]; }       // the generic kernel's arithmetic: s = exp / den
+    const float g = grad_out[row];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float gf[4], ga[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gs = g * e[4 * q + j];
+            gf[j] = gs;
+            ga[j] = gs * (f[4 * q + j] - y);
+        }
+        grad_feat[row * 4 + q] = make_float4(gf[0], gf[1], gf[2], gf[3]);
+        grad_act[row * 4 + q] = make_float4(ga[0], ga[1], ga[2], ga[3]);
+    }
+}
+
 template <typename IdxT>
 __global__ void __launch_bounds__(BLK)
 check_range_kernel(const IdxT* __restrict__ idx, size_t count, long long M, int32_t* bad)
@@ -723,8 +763,15 @@ int ffb6d_att_pool_bwd_f32(const float* grad_out, const float* feat, const float
     const size_t rows = (size_t)B * C * N;
     if (rows == 0) return FFB6D_OK;
     FFB6D_REQUIRE(grad_out && feat && act && grad_feat && grad_act, "att_pool_bwd: null pointer");
-    hipLaunchKernelGGL(att_pool_bwd_kernel, dim3((unsigned)ceil_div(rows, BLK)), dim3(BLK), 0,
-                       as_stream(stream), grad_out, feat, act, grad_feat, grad_act, rows, K);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(grad_feat) |
+                           reinterpret_cast<uintptr_t>(grad_act)) & 15) == 0;
+    if (K == 16 && aligned)
+        hipLaunchKernelGGL(att_pool_bwd16_kernel, dim3((unsigned)ceil_div(rows, BLK)), dim3(BLK), 0, as_stream(stream), grad_out,
+                           reinterpret_cast<const float4*>(feat), reinterpret_cast<const float4*>(act),
+                           reinterpret_cast<float4*>(grad_feat), reinterpret_cast<float4*>(grad_act), rows);
+    else
+        hipLaunchKernelGGL(att_pool_bwd_kernel, dim3((unsigned)ceil_div(rows, BLK)), dim3(BLK), 0,
+                           as_stream(stream), grad_out, feat, act, grad_feat, grad_act, rows, K);
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
