@@ -164,6 +164,18 @@ class BuildingBlock(nn.Module):
     def forward(self, xyz, feature, neigh_idx):
         if not _autograd_path(feature, self):
             return self.fused(xyz, feature, neigh_idx)
+        if feature.is_cuda:
+            # channel-major throughout, like `fused`: the neighbour gather of a [B,C,N,1] tensor IS a nearest interpolation with
+            # the flattened index (autograd: the LDS-privatised scatter-add), the encoding comes out channel-major -- none of the
+            # reference's transposes / contiguous copies, forward or backward (RandLANet.py:196-214, same arithmetic)
+            B, N, K = neigh_idx.shape
+            flat_idx = neigh_idx.reshape(B, N * K, 1)
+            f_xyz = self.mlp1(ops.relative_pos_encoding_cm(xyz, neigh_idx))
+            f_nei = ops.nearest_interpolation(feature, flat_idx).view(B, -1, N, K)
+            f_agg = self.att_pooling_1(torch.cat([f_nei, f_xyz], dim=1))
+            f_xyz = self.mlp2(f_xyz)
+            f_nei = ops.nearest_interpolation(f_agg, flat_idx).view(B, -1, N, K)
+            return self.att_pooling_2(torch.cat([f_nei, f_xyz], dim=1))
         f_xyz = ops.relative_pos_encoding(xyz, neigh_idx).permute(0, 3, 1, 2).contiguous()
         f_xyz = self.mlp1(f_xyz)
         f_nei = ops.gather_neighbour(feature.squeeze(-1).transpose(1, 2).contiguous(), neigh_idx)
