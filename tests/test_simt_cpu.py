@@ -458,13 +458,13 @@ def test_pyramid_builder_with_sets_prepared_together_on_the_emulator(emu):
     from ffb6d_amd import pyramid, synth
     from oracle import knn as oknn
     from oracle import pyramid as opyr
-    frames = synth.make_batch(4, 2, n_points=8192, height=120, width=160)      # 8192 / 2048 points: pruned searches; the rest scans
+    frames = synth.make_batch(4, 2, n_points=4096, height=120, width=160)      # cloud (4096) and stride-2 grid (4800): pruned searches; the rest scans
     want = opyr.build_batch(frames, oknn.knn_search)
     got = pyramid.build_index_pyramid(torch.from_numpy(frames['cld']), torch.from_numpy(frames['dpt_xyz']), index_dtype=torch.int32)
     assert sorted(got) == sorted(want)
     for k in want:
         np.testing.assert_array_equal(got[k].numpy().astype(want[k].dtype), want[k], err_msg=k)
-    sets = [torch.from_numpy(frames['cld']), torch.from_numpy(frames['cld'][:, :2048].copy())]
+    sets = [torch.from_numpy(frames['cld']), torch.from_numpy(frames['cld'][:, :2100].copy())]
     for p, m in zip(sets, nn.prepare_many(sets)):
         assert torch.equal(m.blob[:-256], nn.PreparedPoints(p).blob[:-256])      # (the last < 256 bytes are alignment padding)
 
