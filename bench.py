@@ -247,7 +247,12 @@ def main():
         if args.channels_last:      # NHWC convolutions forward and backward (MIOpen's fastest path on gfx950), no layout transposes.
             # (Converting the colour branch only was measured slower: 92.9 against 98.0 frames/s in bf16 -- the fusion layers then
             # hand NCHW maps back to it.)
-            net = net.to(memory_format=torch.channels_last)
+            if args.channels_last == 2:     # A/B: pixel-map modules only (colour branch + the p2r fusion convolutions); point-branch
+                for name, mod in net.named_children():     # modules keep NCHW = channel-major [B,C,N,1], what the neighbour ops read
+                    if name.startswith("cnn_") or name.endswith("p2r_fuse_layers"):
+                        mod.to(memory_format=torch.channels_last)
+            else:
+                net = net.to(memory_format=torch.channels_last)
         ddp = distributed.wrap_ddp(net, dev, sync_bn=False if args.local_bn else None) if world > 1 else net     # RCCL all-reduce of 33.85 M fp32 grads
         opt = torch.optim.Adam(net.parameters(), lr=1e-5)              # train_lm.py:596
     else:
