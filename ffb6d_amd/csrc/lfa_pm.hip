@@ -216,7 +216,8 @@ lfa_pm_kernel(const LfaParams p)
     const int wc = wave % WC, wr = wave / WC;
     const int ot2 = wave % NOT2, wr2 = wave / NOT2;
 
-    const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.f, (unsigned)p.npts * (unsigned)p.ldf * SZ);
+    // (the point rows may be a channel slice of a wider row buffer: the descriptor ends with the slice's last element)
+    const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.f, (((unsigned)p.npts - 1u) * (unsigned)p.ldf + (unsigned)H) * SZ);
     const __amdgpu_buffer_rsrc_t rs_fc = make_rsrc(p.wfc, (unsigned)(D * D * SZ));
     const __amdgpu_buffer_rsrc_t rs_wm = make_rsrc(p.wm, (unsigned)(COUT * D * SZ));
     const __amdgpu_buffer_rsrc_t rs_w2 = make_rsrc(MODE == 2 ? p.w2 : p.wfc, (unsigned)(H * H * SZ));

@@ -42,6 +42,13 @@ namespace {
 
 using namespace pm;
 
+// bytes a row buffer [rows][ld] spans when only the first k elements of its last row belong to it (the operand may be a channel
+// slice of a wider row buffer: the descriptor must not reach past the slice's last element)
+__device__ __forceinline__ unsigned span_bytes(unsigned rows, int ld, int k, int sz)
+{
+    return rows ? ((rows - 1u) * (unsigned)ld + (unsigned)k) * (unsigned)sz : 0u;
+}
+
 struct PmParams {
     const void* w;        // [cout, k1 + k2]  (nn.Conv weight layout, BatchNorm folded), element type T
     const float* bias;    // [cout] fp32 or null
@@ -206,8 +213,8 @@ mlp_pm_kernel(const PmParams p)
     const int K = p.k1 + p.k2;
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)K * SZ);
     const unsigned x1_rows = p.xidx ? (unsigned)(p.rows / p.P) * (unsigned)p.px : (unsigned)p.rows;
-    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, x1_rows * (unsigned)p.ld1 * SZ);
-    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? (unsigned)p.rows * (unsigned)p.ld2 * SZ : 0u);
+    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, span_bytes(x1_rows, p.ld1, p.k1, SZ));
+    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? span_bytes((unsigned)p.rows, p.ld2, p.k2, SZ) : 0u);
 
     // per-lane byte offsets of this lane's rows (k = 0); rows past the end are out of range -> zeros
     int w_vo[TM], x1_vo[TN], x2_vo[TN];
@@ -431,8 +438,8 @@ mlp_pm_stream_kernel(const PmParams p)
         __syncthreads();
     }
 
-    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, (unsigned)p.rows * (unsigned)p.ld1 * SZ);
-    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(TWO ? p.x2 : p.x1, TWO ? (unsigned)p.rows * (unsigned)p.ld2 * SZ : 0u);
+    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, span_bytes((unsigned)p.rows, p.ld1, p.k1, SZ));
+    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(TWO ? p.x2 : p.x1, TWO ? span_bytes((unsigned)p.rows, p.ld2, p.k2, SZ) : 0u);
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, (unsigned)p.rows * (unsigned)p.ldo * SZ);
 
     // whole rows: load j of a lane is chunk (64 j + lane) % CRX of image row (64 j + lane) / CRX; chunks past K stay zero
@@ -444,7 +451,8 @@ mlp_pm_stream_kernel(const PmParams p)
 
     auto gload = [&](int t, u32x4 (&x)[NS]) {
         const int rbase = t * 128 + wave * 32 + lrow;
-        const int o1 = rbase * p.ld1 * SZ, o2 = rbase * p.ld2 * SZ;
+        // unsigned: tiles prefetched past the last one may wrap (their loads are deselected below)
+        const int o1 = (int)((unsigned)rbase * (unsigned)(p.ld1 * SZ)), o2 = (int)((unsigned)rbase * (unsigned)(p.ld2 * SZ));
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const bool live = rbase + j * RPI < p.rows;
@@ -595,8 +603,8 @@ mlp_pm_lds_kernel(const PmParams p)
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)kbt);
     const unsigned x1_rows = p.xidx ? (unsigned)(p.rows / p.P) * (unsigned)p.px : (unsigned)p.rows;
-    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, x1_rows * (unsigned)p.ld1 * SZ);
-    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? (unsigned)p.rows * (unsigned)p.ld2 * SZ : 0u);
+    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, span_bytes(x1_rows, p.ld1, p.k1, SZ));
+    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? span_bytes((unsigned)p.rows, p.ld2, p.k2, SZ) : 0u);
 
     // loader: thread -> 16-byte chunk lchunk of the 128-byte segment of rows lrow + 32 i (i < 4), for W and for X.  The
     // launcher guarantees K * SZ % 128 == 0 (no row tail) and, with a second source, k1 * SZ % 128 == 0 (a step comes from
@@ -767,8 +775,8 @@ att_pool_pm_kernel(const AttParams p)
     T* ob = static_cast<T*>(p.out);
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)d * (unsigned)d * SZ);
-    const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.f, (unsigned)p.npts * (unsigned)p.ldf * SZ);
-    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(p.g, (unsigned)p.npts * 16u * (unsigned)p.ldg * SZ);
+    const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.f, span_bytes((unsigned)p.npts, p.ldf, p.c1, SZ));
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(p.g, span_bytes((unsigned)p.npts * 16u, p.ldg, p.c2, SZ));
 
     // A operand: this lane's pair of every row tile
     const int a_pp = (l31 >> 2) & 1, a_nb = (l31 & 3) + 4 * (l31 >> 3);
