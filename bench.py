@@ -493,6 +493,9 @@ def main():
             if is_gemm(k):      # GEMM-shaped ops: MFMA rate next to the byte rate
                 fl = sum(gemm_flops(k, t, args.batch) for _, _, _, t in full.records[k])
                 ops_table[k]["algorithmic_TFLOPs"] = fl / (summary[k]["total_ms"] * 1e-3) / 1e12
+            if k == "lfa_pm":   # fused kernel: also the bytes of the unfused reference ops it replaces over its time
+                rb = sum(t[5] for _, _, _, t in full.records[k] if len(t) > 5)
+                ops_table[k]["reference_equivalent_GBps"] = rb / (summary[k]["total_ms"] * 1e-3) / 1e9
         # the same table from the one-stream pass: durations no kernel of another stream shares the CUs with (the numbers a
         # per-kernel roofline fraction should be read from; hot_path_ops above is the benchmarked, overlapped schedule)
         ops_one_stream = None
@@ -505,6 +508,9 @@ def main():
                 if is_gemm(k):
                     fl = sum(gemm_flops(k, t, args.batch) for _, _, _, t in serial.records[k])
                     ops_one_stream[k]["algorithmic_TFLOPs"] = fl / (one[k]["total_ms"] * 1e-3) / 1e12
+                if k == "lfa_pm":
+                    rb = sum(t[5] for _, _, _, t in serial.records[k] if len(t) > 5)
+                    ops_one_stream[k]["reference_equivalent_GBps"] = rb / (one[k]["total_ms"] * 1e-3) / 1e9
         if "knn" in summary:
             # exact KNN is VALU/latency bound, not HBM bound: brute-force-equivalent pairs/s, and the pairs
             # the pruned search really evaluated (device counter, one extra untimed pyramid) against the fp32 VALU roof

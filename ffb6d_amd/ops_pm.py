@@ -259,7 +259,12 @@ def lfa_half(mode, xyz, neigh_idx, f, w1, b1, act1, wfc, wm, bm, actm, w2=None, 
     esz = f.element_size()
     nbytes = 16 * B * N + (bits // 8) * B * N * K + esz * B * N * (h + cout) + esz * (d * d + cout * d + (h * h if mode == 2 else 0)) + 40 * h
     flops = 2 * K * B * N * (d * d + 10 * h + (h * h if mode == 2 else 0)) + 2 * B * N * d * cout
-    with torch.cuda.device(f.device), _lib.traced("lfa_pm", nbytes, (mode, d, N, dt, flops)):
+    # SURVEY section 8d "reference-equivalent" bytes: what the unfused reference operators this launch replaces move at their own
+    # boundaries -- relative_pos_encoding (half 1), gather_neighbour, the attentive pooling pass (feature set + activation in)
+    ib = bits // 8
+    ref_bytes = (12 * B * N + ib * B * N * K + 40 * B * N * K if mode == 1 else 0) + (esz * B * N * h + ib * B * N * K + esz * B * N * K * h) \
+        + (2 * esz * B * N * K * d + esz * B * N * d)
+    with torch.cuda.device(f.device), _lib.traced("lfa_pm", nbytes, (mode, d, N, dt, flops, ref_bytes)):
         rc = lib.ffb6d_lfa_pm(dt, int(mode), x.data_ptr(), xfs, idx.data_ptr(), bits, f2.data_ptr(), ldf, w1.data_ptr(), w1.stride(0),
                               b1.data_ptr(), int(act1), w2.data_ptr() if w2 is not None else None,
                               b2.data_ptr() if b2 is not None else None, int(act2), wfc.data_ptr(), wm.data_ptr(), bm.data_ptr(),
