@@ -79,9 +79,6 @@ def parse():
                     help="1 (default, inference with --streams 2): the forward builds the index pyramid itself, level by "
                          "level on a third HIP stream (forward_pm.StreamedPyramid), so the point branch starts after the "
                          "level-0 searches and the rest runs under the network; 0: whole pyramid first, then the forward")
-    ap.add_argument("--layout", choices=["pm", "cm"], default="pm",
-                    help="activation layout of the fused forward: pm = point-major / pixel-major rows (default), "
-                         "cm = the reference's channel-major layout on the first-generation kernels (A/B)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="BASELINE.json workload: 2 = bs=8, N=12288, 22 classes, fp32 (the headline metric, default); "
                          "4 = YCB-shaped bs=8, N=24576, 22 classes, fp32; 5 = bs=16, N=12288, bf16 mixed precision "
@@ -100,13 +97,8 @@ def parse():
     return args
 
 
-# hot_path_ops key -> kernel instantiation as rocprofv3 lists it (csrc/shared_mlp.hip: per-frame tiles with
-# Cout > 32 take the buffer-load pipelined loop, small per-frame P the flat split-K kernel; csrc/mlp_pm.hip: tile id
-# from ffb6d_mlp_pm_tile)
-MLP_KERNEL_NAMES = {"shared_mlp<128,frame>": "shared_mlp_pipe_kernel<128>", "shared_mlp<64,frame>": "shared_mlp_pipe_kernel<64>",
-                    "shared_mlp<32,frame>": "shared_mlp_kernel<32, false>", "shared_mlp<128,flat>": "shared_mlp_kernel<128, true>",
-                    "shared_mlp<64,flat>": "shared_mlp_kernel<64, true>", "shared_mlp<32,flat>": "shared_mlp_kernel<32, true>",
-                    "mlp_pm<128x128>": "mlp_pm_kernel<2, 2, 2, 2, false>", "mlp_pm<64x256>": "mlp_pm_kernel<2, 2, 1, 4, false>",
+# hot_path_ops key -> kernel instantiation as rocprofv3 lists it (csrc/mlp_pm.hip: tile id from ffb6d_mlp_pm_tile)
+MLP_KERNEL_NAMES = {"mlp_pm<128x128>": "mlp_pm_kernel<2, 2, 2, 2, false>", "mlp_pm<64x256>": "mlp_pm_kernel<2, 2, 1, 4, false>",
                     "mlp_pm<32x256>": "mlp_pm_kernel<1, 2, 1, 4, false>", "mlp_pm<64x64>": "mlp_pm_kernel<1, 1, 2, 2, false>",
                     "mlp_pm<64x32,ksplit>": "mlp_pm_kernel<2, 1, 2, 2, true>",
                     "mlp_pm<stream>": "mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>", "mlp_pm<lds128x128>": "mlp_pm_lds_kernel<T>",
@@ -116,14 +108,10 @@ PM_TILES = {1: "128x128", 2: "64x256", 3: "32x256", 4: "64x64", 5: "64x32,ksplit
 
 def gemm_flops(name, rec_tag, batch):
     """algorithmic flops of one traced GEMM launch (tags: see ffb6d_amd/ops.py / ops_pm.py)"""
-    if name.startswith("shared_mlp"):
-        return 2.0 * batch * rec_tag[0] * rec_tag[1] * rec_tag[2]          # (K, Cout, P per frame)
     if name.startswith("mlp_pm"):
         return 2.0 * rec_tag[0] * rec_tag[1] * rec_tag[2]                  # (K, Cout, rows of all frames, tile)
     if name.startswith("att_pool_pm"):
         return 2.0 * rec_tag[0] * rec_tag[0] * 16 * rec_tag[1] * batch     # (d, N): score GEMM d x d over 16 N pairs
-    if name.startswith("att_score_pool"):
-        return 2.0 * rec_tag[0] * rec_tag[0] * 16 * rec_tag[1] * batch
     if name.startswith("lfa_pm"):
         return float(rec_tag[4])                                           # (mode, d, N, dtype, flops): ops_pm.lfa_half
     return 0.0
@@ -274,14 +262,13 @@ def main():
     phase = {"pyramid": [], "forward": []}
 
     # streams: the point branch of the forward runs on a second HIP stream under the colour branch's
-    # convolutions (model.FFB6D._forward_two_streams); with --overlap-pyramid the index pyramid is
+    # convolutions (forward_pm.forward); with --overlap-pyramid the index pyramid is
     # enqueued on that stream too (nothing in the colour stem needs an index)
     overlap = bool(args.streams == 2) and not train
     net.two_streams = overlap
-    net.layout = args.layout
     net.precision = args.precision
     net.index_dtype = idt
-    side = True if (overlap and args.overlap_pyramid and args.layout == "pm") else None       # pyramid streamed inside the forward
+    side = True if (overlap and args.overlap_pyramid) else None       # pyramid streamed inside the forward
 
     def step(record=False):
         e0, e1, e2 = (ev(), ev(), ev()) if record else (None, None, None)
@@ -316,15 +303,9 @@ def main():
         return out
 
     # op name of a traced launch as hot_path_ops lists it: the shared-MLP launches are split by the kernel instantiation
-    # rocprofv3 lists them under -- shared_mlp_kernel<BM, FLAT> (BM by Cout, FLAT for small per-frame P, csrc/shared_mlp.hip),
-    # mlp_pm by tile / kernel form -- and mlp_pm also by the side of the ridge the layer is on (157.3 TFLOP/s / 8 TB/s =
+    # rocprofv3 lists them under -- mlp_pm by tile / kernel form -- and also by the side of the ridge the layer is on (157.3 TFLOP/s / 8 TB/s =
     # 19.7 flop per byte in fp32: arithmetic intensity of a row = 2 K Cout flop over esz (K + Cout) bytes)
     def split_name(name, tag):
-        if name == "shared_mlp":
-            k, cout, pcols = tag
-            bm = 128 if cout > 64 else (64 if cout > 32 else 32)
-            flat = pcols < 2048 and pcols % 4 == 0
-            return "shared_mlp<%d,%s>" % (bm, "flat" if flat else "frame")
         if name == "mlp_pm":
             k, cout = tag[0], tag[1]
             esz, peak = (2.0, BF16_PEAK_TFLOPS) if args.precision == "bf16" else (4.0, VALU_PEAK_TFLOPS)
@@ -333,9 +314,8 @@ def main():
         return name
 
     def split_mlp(tr):
-        for base in ("shared_mlp", "mlp_pm"):
-            for rec in tr.records.pop(base, []):
-                tr.records.setdefault(split_name(base, rec[3]), []).append(rec)
+        for rec in tr.records.pop("mlp_pm", []):
+            tr.records.setdefault(split_name("mlp_pm", rec[3]), []).append(rec)
 
     with torch.no_grad():
         marker = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -425,7 +405,7 @@ def main():
         pyr_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["pyramid"]]))
         fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in phase["forward"]]))
         def is_gemm(name):
-            return name.startswith(("shared_mlp", "mlp_pm", "att_pool_pm", "att_score_pool", "lfa_pm"))
+            return name.startswith(("mlp_pm", "att_pool_pm", "lfa_pm"))
 
         def mfma_bound(name):
             return is_gemm(name) and not name.endswith(",hbm>")
@@ -456,7 +436,7 @@ def main():
             traffic = None
             pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             # HBM bytes per launch measured offline with rocprofv3 --pmc on the default workload (config 2, fp32, pm)
-            if os.path.exists(pmc_file) and args.precision == "fp32" and args.layout == "pm" and args.config == 2:
+            if os.path.exists(pmc_file) and args.precision == "fp32" and args.config == 2:
                 with open(pmc_file) as fh:
                     table = json.load(fh)
                     key = roof_op.replace(",mfma>", ">").replace(",hbm>", ">")
@@ -552,7 +532,7 @@ def main():
                                    f"{args.n_classes} classes, " + ("bf16 activations/weights with fp32 accumulation" if args.precision == "bf16" else "fp32") +
                                    f", {'train' if train else 'eval'}",
                        "baseline_config": args.config, "global_batch": args.batch * world, "n_points": args.n_points,
-                       "index_dtype": args.index_dtype, "layout": args.layout,
+                       "index_dtype": args.index_dtype, "layout": "pm",
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "
                                       f"{args.dist_backend if world > 1 else 'no'} process group)"},
             "breakdown_ms": ({"step": fwd_ms, "knn_pyramid_alone": pyr_alone_ms,

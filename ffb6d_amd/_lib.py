@@ -38,11 +38,8 @@ SIGNATURES = {
     "ffb6d_gather_neighbour_bwd_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_relative_pos_encoding_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_att_pool_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
-    "ffb6d_att_pool2_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_relative_pos_encoding_cm_f32": (_i32, [_vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp]),
     "ffb6d_att_pool_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
-    "ffb6d_shared_mlp_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i32, _i64, _i64, _vp, _i64,
-                                    _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "ffb6d_mlp_pm_f32": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _vp,
                                 _i64, _i64, _i64, _i32, _i32, _vp]),
     "ffb6d_mlp_pm_tile": (_i32, [_i64, _i64, _i64, _i32]),
@@ -68,13 +65,6 @@ SIGNATURES = {
     "ffb6d_psp_pool_pm_workspace_bytes": (_sz, [_i64, _i64, _i64, _vp, _i32]),
     "ffb6d_psp_pool_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp]),
     "ffb6d_psp_prior_sum_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp]),
-    "ffb6d_att_score_pool_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
-    "ffb6d_shared_mlp_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
-    "ffb6d_bilinear_resize_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
-    "ffb6d_affine_act_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _c.c_float, _vp]),
-    "ffb6d_channel_log_softmax_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),
-    "ffb6d_psp_pool_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
-    "ffb6d_psp_prior_sum_f32": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "ffb6d_depth_to_cloud_f32": (_i32, [_vp, _vp, _c.c_float, _vp, _i64, _i64, _i64, _vp]),
     "ffb6d_sample_points_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "ffb6d_sample_points_f32": (_i32, [_vp, _c.c_float, _vp, _vp, _i32, _vp, _c.c_uint64, _vp, _vp, _vp, _vp, _i64, _i64, _i64,

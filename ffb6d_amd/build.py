@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libffb6d_amd.so")
 
-SOURCES = ["errors.hip", "knn.hip", "knn_pruned.hip", "neighbour_ops.hip", "resize.hip", "shared_mlp.hip", "pose.hip",
+SOURCES = ["errors.hip", "knn.hip", "knn_pruned.hip", "neighbour_ops.hip", "pose.hip",
            "knn_pick.hip", "mlp_pm.hip", "ops_pm.hip", "inputs.hip", "holefill.hip"]
 
 # -ffp-contract=off: the KNN distance and the position encoding must round every product

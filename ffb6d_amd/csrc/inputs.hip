@@ -229,3 +229,56 @@ extern "C" int ffb6d_depth_normal(const void* depth_mm, int depth_is_u16, double
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Depth image -> xyz image (the dataset's `dpt_2_pcld`,
+// ffb6d/datasets/linemod/linemod_dataset.py:188-199), on the device so the index pyramid can be
+// built without a host round trip.  Arithmetic as numpy does it there: dpt = f32(depth)/cam_scale
+// in float32, then ((col - cx) * dpt) / fx in float64 (int64 index minus float64 intrinsic), masked
+// by dpt > 1e-8, NaN/Inf -> 0 (linemod_dataset.py:258-259), rounded once to float32.
+// Output channel-major [B,3,H,W] (x, y, z planes), the layout build_index_pyramid consumes.
+// ------------------------------------------------------------------------------------------
+namespace ffb6d {
+namespace {
+
+__global__ void __launch_bounds__(256)
+depth_to_cloud_kernel(const float* __restrict__ depth, const double* __restrict__ K, float cam_scale,
+                      float* __restrict__ out, int H, int W, size_t total)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;   // over B*H*W
+    if (t >= total) return;
+    const size_t hw = (size_t)H * W;
+    const size_t b = t / hw;
+    const size_t pix = t - b * hw;
+    const int r = (int)(pix / W), c = (int)(pix - (size_t)r * W);
+    const double* k = K + b * 9;
+    const float dpt = depth[t] / cam_scale;
+    const float msk = dpt > 1e-8f ? 1.f : 0.f;
+    double x = (((double)c - k[2]) * (double)dpt) / k[0];     // K[0][2], K[0][0]
+    double y = (((double)r - k[5]) * (double)dpt) / k[4];     // K[1][2], K[1][1]
+    double z = (double)dpt;
+    x *= (double)msk; y *= (double)msk; z *= (double)msk;
+    if (!(fabs(x) <= 1.79e308)) x = 0.0;                       // NaN / Inf -> 0
+    if (!(fabs(y) <= 1.79e308)) y = 0.0;
+    if (!(fabs(z) <= 1.79e308)) z = 0.0;
+    float* o = out + b * 3 * hw + pix;
+    o[0] = (float)x;
+    o[hw] = (float)y;
+    o[2 * hw] = (float)z;
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+extern "C" int ffb6d_depth_to_cloud_f32(const float* depth, const double* K, float cam_scale, float* out,
+                                        int64_t B, int64_t H, int64_t W, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && cam_scale != 0.f, "depth_to_cloud: bad arguments");
+    const size_t total = (size_t)B * H * W;
+    if (total == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(depth && K && out, "depth_to_cloud: null pointer");
+    hipLaunchKernelGGL(ffb6d::depth_to_cloud_kernel, dim3((unsigned)ffb6d::ceil_div((int64_t)total, 256)), dim3(256), 0,
+                       ffb6d::as_stream(stream), depth, K, cam_scale, out, (int)H, (int)W, total);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}

@@ -1,6 +1,6 @@
 // ffb6d_amd/csrc/mlp_pm.hip -- shared MLP on POINT-MAJOR / PIXEL-MAJOR activations ("channels last") for gfx950.
 //
-// Reference: the same 1x1 Conv + BatchNorm + activation wrappers as csrc/shared_mlp.hip
+// Reference: the 1x1 Conv + BatchNorm + activation wrappers
 //   ffb6d/models/pytorch_utils.py:75-129, ffb6d/models/RandLA/pytorch_utils.py:35-111
 // and the cat / interpolate / residual plumbing around them (ffb6d.py:245-263,273-298,302-312,
 // RandLANet.py:179-184).  Same mathematics, different data layout:

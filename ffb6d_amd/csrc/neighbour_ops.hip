@@ -349,38 +349,6 @@ att_pool_kernel(const float4* __restrict__ feat, const float4* __restrict__ act,
     if (live && (threadIdx.x % LPR) == 0) out[row] = acc;
 }
 
-// two-source variant: the feature set is cat(feat1 [B,C1,N,K], feat2 [B,C2,N,K]) along channels
-// (RandLANet.py:204,212) without materialising the cat; act/out are [B,C1+C2,N(,K)]
-template <int LPR>
-__global__ void __launch_bounds__(BLK)
-att_pool2_kernel(const float4* __restrict__ feat1, const float4* __restrict__ feat2,
-                 const float4* __restrict__ act, float* __restrict__ out, int C1, int C2, int N, size_t rows)
-{
-    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;  // float4 id over act = row*LPR + lane
-    const size_t row = t / LPR;                                // (b*(C1+C2) + c)*N + n
-    const int sub = (int)(t - row * LPR);
-    const bool live = row < rows;
-    float4 f = make_float4(0, 0, 0, 0), a = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-    if (live) {
-        const int C = C1 + C2;
-        const size_t bc = row / N;
-        const int n = (int)(row - bc * N);
-        const size_t b = bc / C;
-        const int c = (int)(bc - b * C);
-        a = act[t];
-        f = (c < C1) ? feat1[(((b * C1 + c) * (size_t)N) + n) * LPR + sub]
-                     : feat2[(((b * C2 + (c - C1)) * (size_t)N) + n) * LPR + sub];
-    }
-    const float m = group_max<LPR>(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
-    const float e0 = expf(a.x - m), e1 = expf(a.y - m), e2 = expf(a.z - m), e3 = expf(a.w - m);
-    const float den = group_sum<LPR>((e0 + e1) + (e2 + e3));
-    float acc = f.x * (e0 / den);
-    acc += f.y * (e1 / den);
-    acc += f.z * (e2 / den);
-    acc += f.w * (e3 / den);
-    acc = group_sum<LPR>(acc);
-    if (live && sub == 0) out[row] = acc;
-}
 
 // generic K: one lane per row
 __global__ void __launch_bounds__(BLK)
@@ -707,32 +675,6 @@ int ffb6d_att_pool_f32(const float* feat, const float* act, float* out, int64_t 
     } else {
         hipLaunchKernelGGL(att_pool_anyk_kernel, dim3((unsigned)ceil_div(rows, BLK)), dim3(BLK), 0, st,
                            feat, act, out, rows, K);
-    }
-    FFB6D_LAUNCH_CHECK();
-    return FFB6D_OK;
-}
-
-int ffb6d_att_pool2_f32(const float* feat1, int64_t C1, const float* feat2, int64_t C2, const float* act,
-                        float* out, int64_t B, int64_t N, int K, ffb6d_stream_t stream)
-{
-    FFB6D_REQUIRE(B >= 0 && C1 >= 1 && C2 >= 1 && N >= 0, "att_pool2: bad shape");
-    FFB6D_REQUIRE(K == 16 || K == 8 || K == 4 || K == 32, "att_pool2: K must be 4, 8, 16 or 32");
-    const size_t rows = (size_t)B * (C1 + C2) * N;
-    if (rows == 0) return FFB6D_OK;
-    FFB6D_REQUIRE(feat1 && feat2 && act && out, "att_pool2: null pointer");
-    FFB6D_REQUIRE(((reinterpret_cast<uintptr_t>(feat1) | reinterpret_cast<uintptr_t>(feat2) |
-                    reinterpret_cast<uintptr_t>(act)) & 15) == 0, "att_pool2: inputs must be 16-byte aligned");
-    hipStream_t st = as_stream(stream);
-    const float4* f1 = reinterpret_cast<const float4*>(feat1);
-    const float4* f2 = reinterpret_cast<const float4*>(feat2);
-    const float4* a4 = reinterpret_cast<const float4*>(act);
-    const int lpr = K / 4;
-    const dim3 grid((unsigned)ceil_div((int64_t)(rows * lpr), BLK));
-    switch (lpr) {
-        case 1: hipLaunchKernelGGL((att_pool2_kernel<1>), grid, dim3(BLK), 0, st, f1, f2, a4, out, (int)C1, (int)C2, (int)N, rows); break;
-        case 2: hipLaunchKernelGGL((att_pool2_kernel<2>), grid, dim3(BLK), 0, st, f1, f2, a4, out, (int)C1, (int)C2, (int)N, rows); break;
-        case 4: hipLaunchKernelGGL((att_pool2_kernel<4>), grid, dim3(BLK), 0, st, f1, f2, a4, out, (int)C1, (int)C2, (int)N, rows); break;
-        default: hipLaunchKernelGGL((att_pool2_kernel<8>), grid, dim3(BLK), 0, st, f1, f2, a4, out, (int)C1, (int)C2, (int)N, rows); break;
     }
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;

@@ -234,7 +234,7 @@ affine_relu_maxpool_pm_kernel(const void* __restrict__ x, const float* __restric
 
 // ------------------------------------------------------------------------------------------------
 // bilinear resize of [B, IH, IW, C] -> [B, OH, OW, C]; lane = one 16-byte unit of one output pixel;
-// ATen's upsample_bilinear2d arithmetic (area_pixel_compute_source_index + the lambda blend), as csrc/resize.hip
+// ATen's upsample_bilinear2d arithmetic (area_pixel_compute_source_index + the lambda blend)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float src_index(float scale, int dst, bool align_corners)
 {

@@ -9,14 +9,15 @@ tree reproduces the reference's `state_dict()` keys and shapes exactly
 (tests/golden/state_dict_keys.json); `FFB6D.forward(inputs)` takes the same input dict and
 returns the same `end_points`.
 
-What is different from the reference (MI355X-first, eval mode):
-  * every gather / pooling / encoding step is one HIP kernel call (ffb6d_amd.ops) instead of
-    index.repeat + torch.gather + permute().contiguous() chains;
-  * every shared MLP (1x1 conv + BatchNorm + activation) is folded into one GEMM with the
-    BatchNorm scale/shift absorbed into the weights (inference only; training mode keeps
-    the unfused conv -> BN -> act so gradients and running statistics behave as upstream);
-  * the dense 3x3/7x7 convolutions of the colour branch stay on MIOpen (out of scope for
-    hand-written kernels).
+Two ways through this module tree:
+  * `eval()` + `torch.no_grad()` on a GPU: the fused point-major inference path (ffb6d_amd/forward_pm.py) -- activations as
+    rows, BatchNorm folded into the GEMMs, one launch per half of the local feature aggregation, three HIP streams;
+  * everything else (training, gradients, train() under no_grad, widths the row kernels do not cover): the stock modules below
+    -- conv -> BatchNorm -> activation exactly as upstream, so gradients and running statistics behave like the reference --
+    with every gather / pooling / encoding step as one HIP kernel call with an autograd body (ffb6d_amd.ops) instead of
+    index.repeat + torch.gather + permute().contiguous() chains.
+The dense 3x3/7x7 convolutions of the colour branch stay on MIOpen (out of scope for hand-written kernels, SURVEY.md section 2
+row 8).  (Rounds 1-2 also carried a channel-major fused inference path, `layout="cm"`; it was removed in round 3.)
 """
 import os
 
@@ -25,7 +26,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import forward_pm, ops, pyramid
-from .forward_pm import cached, mlp_sources
 
 D_OUT = (32, 64, 128, 256)   # ConfigRandLA.d_out (ffb6d/common.py:26)
 IN_C = 9                     # ConfigRandLA.in_c
@@ -72,50 +72,20 @@ class SharedMLP(nn.Module):
             return y
         return F.leaky_relu_(y, 0.2) if self.flavour == "randla" else F.relu_(y)
 
-    def folded(self):
-        """(Wt [Cin,Cout], b [Cout]): transposed weights with eval-mode BatchNorm absorbed -- the operand layout of
-        ops.shared_mlp (channel-major path).  Cached; the key covers version, storage and device of every source
-        tensor (forward_pm.cached), so load_state_dict / in-place edits / .to(device) are picked up."""
-        def build():
-            w = self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1)
-            if self.has_bn:
-                bn = self._bn_module()
-                scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
-                w = w * scale[:, None]
-                b = bn.bias.detach() - bn.running_mean * scale
-            else:
-                b = self.conv.bias.detach()
-            return w.t().contiguous(), b.contiguous()
-        return cached(self, "cm_folded", mlp_sources(self), build)
-
     @property
     def act_code(self):
         return ops.ACT_NONE if not self.act else (ops.ACT_LEAKY if self.flavour == "randla" else ops.ACT_RELU)
 
-    def fused(self, x, x2=None):
-        """Inference: one fused MFMA GEMM = conv(cat(x, x2)) + folded BN + activation."""
-        wt, b = self.folded()
-        return ops.shared_mlp(x, wt, b, self.act_code, x2=x2)
-
-    def split(self, k1):
-        """(Wt_a [k1,Cout], Wt_b [Cin-k1,Cout], b) for conv(cat(a, gather(b))) == W_a a + gather(W_b b)."""
-        def build():
-            wt, b = self.folded()
-            return wt[:k1].contiguous(), wt[k1:].contiguous(), b
-        return cached(self, "cm_split%d" % k1, mlp_sources(self), build)
-
-    def forward(self, x):
-        if _autograd_path(x, self):   # unfused conv -> BN -> act (training, DDP, CPU)
-            y = self.conv(x)
-            if self.has_bn:
-                y = (self.bn if self.flavour == "randla" else self.normlayer)(y)
-            return self.activation(y)
-        return self.fused(x)
+    def forward(self, x):           # conv -> BN -> act as separate modules (the fused inference path folds them: forward_pm.folded)
+        y = self.conv(x)
+        if self.has_bn:
+            y = (self.bn if self.flavour == "randla" else self.normlayer)(y)
+        return self.activation(y)
 
 
 def _autograd_path(x, mod=None):
     """True when the stock-torch layers (conv -> BN -> activation as separate modules) must be used instead of the
-    fused inference kernels: gradients enabled, tensors not on a GPU, or the module in train() mode -- the fused
+    fused inference path: gradients enabled, tensors not on a GPU, or the module in train() mode -- the fused
     kernels fold BatchNorm with its RUNNING statistics and skip dropout, which is eval() semantics only; train() under
     torch.no_grad() (BN re-calibration, a validation loop that forgot eval()) must keep batch statistics, running-stat
     updates and dropout exactly like the reference.
@@ -140,16 +110,6 @@ class AttPooling(nn.Module):
         att = self.fc(feature_set)
         return self.mlp(ops.att_pool(feature_set, att))
 
-    def fused(self, f_nei, f_xyz):
-        """Inference: feature_set = cat(f_nei, f_xyz) is never materialised -- the score GEMM
-        reads both halves as two K-ranges, the pooling kernel reads them as two channel blocks."""
-        w = self.fc.weight
-        fct = cached(self, "cm_fct", [w], lambda: w.detach().reshape(w.shape[0], -1).t().contiguous())
-        if f_nei.shape[3] == 16:    # score GEMM with the softmax pooling in its epilogue
-            return self.mlp.fused(ops.att_score_pool(f_nei, f_xyz, fct))
-        att = ops.shared_mlp(f_nei, fct, None, ops.ACT_NONE, x2=f_xyz)
-        return self.mlp.fused(ops.att_pool2(f_nei, f_xyz, att))
-
 
 class BuildingBlock(nn.Module):
     """RandLANet.py:187-214 (local spatial encoding + two attentive poolings)."""
@@ -162,10 +122,8 @@ class BuildingBlock(nn.Module):
         self.att_pooling_2 = AttPooling(d_out, d_out)
 
     def forward(self, xyz, feature, neigh_idx):
-        if not _autograd_path(feature, self):
-            return self.fused(xyz, feature, neigh_idx)
         if feature.is_cuda:
-            # channel-major throughout, like `fused`: the neighbour gather of a [B,C,N,1] tensor IS a nearest interpolation with
+            # channel-major throughout: the neighbour gather of a [B,C,N,1] tensor IS a nearest interpolation with
             # the flattened index (autograd: the LDS-privatised scatter-add), the encoding comes out channel-major -- none of the
             # reference's transposes / contiguous copies, forward or backward (RandLANet.py:196-214, same arithmetic)
             B, N, K = neigh_idx.shape
@@ -187,18 +145,6 @@ class BuildingBlock(nn.Module):
         return self.att_pooling_2(f_cat)
 
 
-    def fused(self, xyz, feature, neigh_idx):
-        """Inference path, channel-major throughout: no permute/contiguous/cat copies."""
-        B, N, K = neigh_idx.shape
-        flat_idx = neigh_idx.reshape(B, N * K, 1)
-        f_xyz = self.mlp1.fused(ops.relative_pos_encoding_cm(xyz, neigh_idx))            # [B,d/2,N,K]
-        f_nei = ops.nearest_interpolation(feature, flat_idx).view(B, -1, N, K)           # [B,d/2,N,K]
-        f_agg = self.att_pooling_1.fused(f_nei, f_xyz)                                   # [B,d/2,N,1]
-        f_xyz = self.mlp2.fused(f_xyz)
-        f_nei = ops.nearest_interpolation(f_agg, flat_idx).view(B, -1, N, K)
-        return self.att_pooling_2.fused(f_nei, f_xyz)
-
-
 class DilatedResBlock(nn.Module):
     """RandLANet.py:170-184."""
 
@@ -211,15 +157,7 @@ class DilatedResBlock(nn.Module):
 
     def forward(self, feature, xyz, neigh_idx):
         f = self.lfa(xyz, self.mlp1(feature), neigh_idx)
-        if _autograd_path(feature, self):
-            return F.leaky_relu(self.mlp2(f) + self.shortcut(feature), negative_slope=0.2)
-
-        # leaky(mlp2(f) + shortcut(x)) as ONE GEMM over K = [f ; x] with summed biases
-        def build():
-            (w2, b2), (ws, bs) = self.mlp2.folded(), self.shortcut.folded()
-            return torch.cat([w2, ws], dim=0).contiguous(), (b2 + bs).contiguous()
-        w, b = cached(self, "cm_res", mlp_sources(self.mlp2) + mlp_sources(self.shortcut), build)
-        return ops.shared_mlp(f, w, b, ops.ACT_LEAKY, x2=feature)
+        return F.leaky_relu(self.mlp2(f) + self.shortcut(feature), negative_slope=0.2)
 
 
 # --------------------------------------------------------------------------------------
@@ -239,19 +177,11 @@ class ResBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        if _autograd_path(x, self) or (x.shape[2] * x.shape[3]) % 4:
-            y = F.relu_(self.bn1(self.conv1(x)))
-            y = self.bn2(self.conv2(y))
-            if self.downsample is not None:
-                x = self.downsample(x)
-            return F.relu_(y + x)
-        # inference: BN+ReLU and BN+add(+BN of the projection)+ReLU as one pass each
-        y = ops.affine_act_(self.conv1(x), *ops.bn_fold(self.bn1), act=ops.ACT_RELU)
-        y = self.conv2(y)
+        y = F.relu_(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
         if self.downsample is not None:
-            return ops.affine_act_(y, *ops.bn_fold(self.bn2), act=ops.ACT_RELU, residual=self.downsample[0](x),
-                                   res_affine=ops.bn_fold(self.downsample[1]))
-        return ops.affine_act_(y, *ops.bn_fold(self.bn2), act=ops.ACT_RELU, residual=x)
+            x = self.downsample(x)
+        return F.relu_(y + x)
 
 
 def res_layer(cin, cout, blocks, stride):
@@ -273,43 +203,8 @@ class PyramidPooling(nn.Module):
 
     def forward(self, x):
         h, w = x.shape[2:]
-        if _autograd_path(x, self):
-            pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]
-            return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
-        if w % 4 or h * w * 4 > 160 * 1024:
-            pri = [ops.bilinear_resize(st(x), (h, w), align_corners=False) for st in self.stages]
-            return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
-        return self.fused(x)
-
-    def _weights(self):
-        """Per-level products W_b,i @ W_i ([512 -> 1024], the level's 1x1 conv followed by its slice
-        of the bottleneck) and the transposed direct slice W_x^T, cached."""
-        bw = self.bottleneck.weight
-        key = (bw._version,) + tuple(st[1].weight._version for st in self.stages)
-        if getattr(self, "_fold", None) is None or self._fold[0] != key:
-            ch = self.stages[0][1].weight.shape[0]
-            wb = bw.detach().reshape(bw.shape[0], -1)                                 # [1024, 2560]
-            prods = [(wb[:, i * ch:(i + 1) * ch] @ st[1].weight.detach().reshape(ch, ch)).t().contiguous()
-                     for i, st in enumerate(self.stages)]                              # each [512, 1024]
-            wx = wb[:, len(self.stages) * ch:].t().contiguous()                        # [512, 1024]
-            self._fold = (key, prods, wx)
-        return self._fold[1], self._fold[2]
-
-    def fused(self, x):
-        """bottleneck(cat(up_i(conv_i(pool_i(x))), x)) = W_x x + b + sum_i up_i((W_b,i W_i) pool_i(x)):
-        no 2560-channel concatenation, the big GEMM shrinks from K=2560 to K=512."""
-        B, C, h, w = x.shape
-        sizes = [st[0].output_size[0] for st in self.stages]
-        prods, wx = self._weights()
-        pooled = ops.psp_pool(x, sizes)                                                # [B,512,50]
-        zs, off = [], 0
-        for s, wt in zip(sizes, prods):
-            zs.append(ops.shared_mlp(pooled[:, :, off:off + s * s].contiguous(), wt, None, ops.ACT_NONE))
-            off += s * s
-        prior = ops.psp_prior_sum(torch.cat(zs, dim=2), sizes, (h, w))                 # [B,1024,h,w]
-        if getattr(self, "_iota", None) is None or self._iota.shape != (B, h * w) or self._iota.device != x.device:
-            self._iota = torch.arange(h * w, dtype=torch.int32, device=x.device).repeat(B, 1)
-        return ops.shared_mlp(x, wx, self.bottleneck.bias.detach(), ops.ACT_RELU, gather=(prior, self._iota))
+        pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]
+        return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
 
 
 class UpBlock(nn.Module):
@@ -321,47 +216,21 @@ class UpBlock(nn.Module):
                                   nn.Conv2d(cin, cout, 3, padding=1), nn.BatchNorm2d(cout), nn.PReLU())
 
     def forward(self, x):
-        if _autograd_path(x, self):
-            if not x.is_cuda:
-                return self.conv(x)
-            # training on the GPU: same modules and arithmetic, but the up-sampling and the PReLU carry hand-written backward
-            # passes (csrc/train_ops.hip: gather instead of ATen's atomic scatter; slope gradient reduced in the kernel)
-            _, conv, bn, prelu = self.conv
-            y = ops.upsample_align(x, (2 * x.shape[2], 2 * x.shape[3]))
-            return ops.prelu(bn(conv(y)), prelu.weight)
-        y = ops.bilinear_resize(x, (2 * x.shape[2], 2 * x.shape[3]), align_corners=True)
-        conv, bn, prelu = self.conv[1], self.conv[2], self.conv[3]
-        if prelu.weight.numel() != 1 or (y.shape[2] * y.shape[3]) % 4:
-            return prelu(bn(conv(y)))
-        if getattr(self, "_slope", None) is None or self._slope[0] != prelu.weight._version:
-            self._slope = (prelu.weight._version, float(prelu.weight.detach().item()))
-        # conv bias rides in the BatchNorm shift: BN(conv(y)+b) = scale*conv(y) + (shift + scale*b)
-        scale, shift = ops.bn_fold(bn)
-        key = (conv.bias._version, bn.bias._version, bn.weight._version, bn.running_mean._version,
-               bn.running_var._version)
-        if getattr(self, "_shift", None) is None or self._shift[0] != key:
-            self._shift = (key, (shift + scale * conv.bias.detach()).contiguous())
-        y = F.conv2d(y, conv.weight, None, conv.stride, conv.padding)
-        return ops.affine_act_(y, scale, self._shift[1], act=ops.ACT_LEAKY, slope=self._slope[1])
+        if not x.is_cuda:
+            return self.conv(x)
+        # same modules and arithmetic, but the up-sampling and the PReLU carry hand-written backward passes
+        # (csrc/train_ops.hip: gather instead of ATen's atomic scatter; slope gradient reduced in the kernel)
+        _, conv, bn, prelu = self.conv
+        y = ops.upsample_align(x, (2 * x.shape[2], 2 * x.shape[3]))
+        return ops.prelu(bn(conv(y)), prelu.weight)
 
 
 class FinalHead(nn.Sequential):
-    """pspnet.py:108-112 `final`: Conv2d(64,64,1) + LogSoftmax (implicit dim = 1 on a 4-d map).
-    Inference: the 1x1 conv is the fused MFMA shared-MLP kernel (bias in the epilogue), the
-    log-softmax one register-resident pass."""
+    """pspnet.py:108-112 `final`: Conv2d(64,64,1) + LogSoftmax (implicit dim = 1 on a 4-d map); the fused inference path runs it
+    as one GEMM with a log-softmax epilogue (forward_pm.final_head)."""
 
     def __init__(self, ch=64):
         super().__init__(nn.Conv2d(ch, ch, 1), nn.LogSoftmax(dim=1))
-
-    def forward(self, x):
-        conv = self[0]
-        if _autograd_path(x, self) or conv.out_channels not in (16, 32, 64):
-            return super().forward(x)
-        key = (conv.weight._version, conv.bias._version)
-        if getattr(self, "_wt", None) is None or self._wt[0] != key:
-            self._wt = (key, conv.weight.detach().reshape(conv.out_channels, -1).t().contiguous())
-        y = ops.shared_mlp(x, self._wt[1], conv.bias.detach(), ops.ACT_NONE)
-        return ops.channel_log_softmax_(y)
 
 
 def _head(cin, cout):
@@ -443,9 +312,6 @@ class FFB6D(nn.Module):
         self.__dict__.pop("_pm_supported", None)
         for m in self.modules():
             m.__dict__.pop("_pm_cache", None)
-            for attr in ("_ffb6d_fold", "_slope", "_shift", "_wt", "_fold"):
-                if hasattr(m, attr):
-                    setattr(m, attr, None)
         return super().train(mode)
 
     # the reference exposes these two as static methods of the model (ffb6d.py:159-194)
@@ -456,45 +322,19 @@ class FFB6D(nn.Module):
         """One bidirectional fusion step (ffb6d.py:245-263 / 281-298); both directions read
         the pre-fusion tensors, so they are independent."""
         bs, c, hr, wr = rgb_emb0.shape
-        if _autograd_path(rgb_emb0, self):
-            p2r = ops.nearest_interpolation(pre_p2r[i](p_emb0), p2r_idx).view(bs, -1, hr, wr)
-            rgb_emb = fuse_p2r[i](torch.cat((rgb_emb0, p2r), dim=1))
-            r2p = ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx)
-            p_emb = fuse_r2p[i](torch.cat((p_emb0, pre_r2p[i](r2p)), dim=1))
-            return rgb_emb, p_emb
-        # p2r: conv(cat(rgb0, interp(e))) = W_a rgb0 + gather(W_b e): the point half is multiplied at
-        # N' points instead of h*w pixels and enters the pixel GEMM's epilogue as a column gather
-        e = pre_p2r[i].fused(p_emb0)
-        wa, wb, bias = fuse_p2r[i].split(c)
-        y = ops.shared_mlp(e, wb, None, ops.ACT_NONE)
-        rgb_emb = ops.shared_mlp(rgb_emb0, wa, bias, fuse_p2r[i].act_code, gather=(y, p2r_idx))
-        # r2p: max-pool the 16 nearest pixels, then conv(cat(p0, pre(.))) as a two-source GEMM
-        r2p = pre_r2p[i].fused(ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx))
-        p_emb = fuse_r2p[i].fused(p_emb0, x2=r2p)
+        p2r = ops.nearest_interpolation(pre_p2r[i](p_emb0), p2r_idx).view(bs, -1, hr, wr)
+        rgb_emb = fuse_p2r[i](torch.cat((rgb_emb0, p2r), dim=1))
+        r2p = ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx)
+        p_emb = fuse_r2p[i](torch.cat((p_emb0, pre_r2p[i](r2p)), dim=1))
         return rgb_emb, p_emb
 
     def _decode(self, stage, skip, p_emb, interp_idx):
         """RandLA decoder step conv(cat(skip, interp(p))) (ffb6d.py:273-279,302-307)."""
-        if _autograd_path(skip, self):
-            return stage(torch.cat([skip, ops.nearest_interpolation(p_emb, interp_idx)], dim=1))
-        wa, wb, bias = stage.split(skip.shape[1])
-        y = ops.shared_mlp(p_emb, wb, None, ops.ACT_NONE)
-        return ops.shared_mlp(skip, wa, bias, stage.act_code, gather=(y, interp_idx))
+        return stage(torch.cat([skip, ops.nearest_interpolation(p_emb, interp_idx)], dim=1))
 
-    # ------------------------------------------------------------------------------------------
-    # Two-stream inference.  Within a stage the colour branch (MIOpen convolutions: few, large,
-    # MFMA-bound launches) and the point branch (many small gather / pooling / GEMM launches) are
-    # independent until the fusion step, and the two fusion directions read the pre-fusion tensors
-    # (ffb6d.py:245-262), so they are independent too.  Running the point side on a second HIP stream
-    # hides most of it under the convolutions:
-    #     main:  CNN_i ---------------> [join] p2r (pixel GEMM) ----------> CNN_i+1 ...
-    #     side:  LFA_i + pooling -----> [join] r2p (gather-max + GEMMs) --> LFA_i+1 ...
-    # Tensors crossing streams are handed over with events and record_stream().
-    # ------------------------------------------------------------------------------------------
+    # Fused inference (forward_pm.forward): the point branch on a second HIP stream under the colour branch's convolutions,
+    # the index pyramid on a third; two_streams = False keeps everything on the caller's stream (bit-identical results).
     two_streams = True
-    # activation layout of the fused inference path: "pm" = point-major / pixel-major rows (forward_pm.py, default),
-    # "cm" = the reference's channel-major layout on the first-generation kernels (kept for A/B measurements)
-    layout = "pm"
     # arithmetic of the fused point-major path: "fp32" (default, BASELINE configurations 2-4) or "bf16" (configuration 5:
     # bfloat16 activations and weights, fp32 accumulation / BatchNorm / softmax arithmetic, fp32 end_points)
     precision = "fp32"
@@ -516,87 +356,6 @@ class FFB6D(nn.Module):
             st = torch.cuda.Stream(device=device)
             self._side = st
         return st
-
-    def _forward_two_streams(self, inputs, end_points):
-        dev = inputs['rgb'].device
-        main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev)
-        side.wait_stream(main)                      # inputs (and the index pyramid) come from `main`
-
-        def handover(t, producer, consumer):
-            """tensor produced on `producer`, about to be read on `consumer`"""
-            ev = torch.cuda.Event()
-            ev.record(producer)
-            consumer.wait_event(ev)
-            t.record_stream(consumer)
-            return t
-
-        def fuse(i, pre_p2r, fuse_p2r, pre_r2p, fuse_r2p, rgb_emb0, p_emb0, p2r_idx, r2p_idx):
-            bs, c, hr, wr = rgb_emb0.shape
-            handover(p_emb0, side, main)
-            handover(rgb_emb0, main, side)
-            p2r_idx.record_stream(main)
-            # p2r on main (see _fuse for the algebra)
-            e = pre_p2r[i].fused(p_emb0)
-            wa, wb, bias = fuse_p2r[i].split(c)
-            y = ops.shared_mlp(e, wb, None, ops.ACT_NONE)
-            rgb_emb = ops.shared_mlp(rgb_emb0, wa, bias, fuse_p2r[i].act_code, gather=(y, p2r_idx))
-            with torch.cuda.stream(side):
-                r2p = pre_r2p[i].fused(ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx))
-                p_emb = fuse_r2p[i].fused(p_emb0, x2=r2p)
-            return rgb_emb, p_emb
-
-        # stem
-        y = ops.affine_act_(self.cnn_pre_stages[0](inputs['rgb']), *ops.bn_fold(self.cnn_pre_stages[1]),
-                            act=ops.ACT_RELU)
-        rgb_emb = self.cnn_pre_stages[3](y)
-        with torch.cuda.stream(side):
-            p_emb = self.rndla_pre_stages(inputs['cld_rgb_nrm']).unsqueeze(3)
-
-        ds_emb = []
-        for i in range(4):
-            rgb_emb0 = self.cnn_ds_stages[i](rgb_emb)
-            with torch.cuda.stream(side):
-                f_enc = self.rndla_ds_stages[i](p_emb, inputs['cld_xyz%d' % i], inputs['cld_nei_idx%d' % i])
-                p_emb0 = ops.random_sample(f_enc, inputs['cld_sub_idx%d' % i])
-            if i == 0:
-                ds_emb.append(f_enc)
-            rgb_emb, p_emb = fuse(i, self.ds_fuse_p2r_pre_layers, self.ds_fuse_p2r_fuse_layers,
-                                  self.ds_fuse_r2p_pre_layers, self.ds_fuse_r2p_fuse_layers, rgb_emb0, p_emb0,
-                                  inputs['p2r_ds_nei_idx%d' % i], inputs['r2p_ds_nei_idx%d' % i])
-            ds_emb.append(p_emb)
-
-        n_up = len(self.rndla_up_stages)
-        for i in range(n_up - 1):
-            rgb_emb0 = self.cnn_up_stages[i](rgb_emb)
-            with torch.cuda.stream(side):
-                p_emb0 = self._decode(self.rndla_up_stages[i], ds_emb[-i - 2], p_emb,
-                                      inputs['cld_interp_idx%d' % (n_up - i - 1)])
-            rgb_emb, p_emb = fuse(i, self.up_fuse_p2r_pre_layers, self.up_fuse_p2r_fuse_layers,
-                                  self.up_fuse_r2p_pre_layers, self.up_fuse_r2p_fuse_layers, rgb_emb0, p_emb0,
-                                  inputs['p2r_up_nei_idx%d' % i], inputs['r2p_up_nei_idx%d' % i])
-
-        rgb_emb = self.cnn_up_stages[n_up - 1](rgb_emb)
-        with torch.cuda.stream(side):
-            p_emb = self._decode(self.rndla_up_stages[n_up - 1], ds_emb[0], p_emb,
-                                 inputs['cld_interp_idx0']).squeeze(-1)
-        handover(p_emb, side, main)                 # also the final join: main is behind all side work
-
-        bs = rgb_emb.shape[0]
-        rgb_emb_c = ops.choose_gather(rgb_emb, inputs['choose'])
-
-        def head(seq):
-            y = seq[0].fused(rgb_emb_c, x2=p_emb)
-            for layer in list(seq)[1:]:
-                y = layer.fused(y)
-            return y
-
-        end_points['pred_rgbd_segs'] = head(self.rgbd_seg_layer)
-        end_points['pred_kp_ofs'] = head(self.kp_ofst_layer).view(
-            bs, self.n_kps, 3, -1).permute(0, 1, 3, 2).contiguous()
-        end_points['pred_ctr_ofs'] = head(self.ctr_ofst_layer).view(
-            bs, 1, 3, -1).permute(0, 1, 3, 2).contiguous()
-        return end_points
 
     def check_indices(self, inputs):
         """Debug aid (FFB6D_CHECK_INDICES=1 runs it on every forward): every index tensor of the input dict must address
@@ -636,20 +395,14 @@ class FFB6D(nn.Module):
             # every other path builds it up front.
             if 'dpt_xyz' not in inputs:
                 raise KeyError("inputs carry neither the index pyramid ('cld_nei_idx0', ...) nor 'dpt_xyz' to build it from")
-            if not (fused and self.layout == "pm" and forward_pm.supported(self)) or taps is not None:
+            if not (fused and forward_pm.supported(self)) or taps is not None:
                 inputs = dict(inputs)
                 inputs.update(pyramid.build_index_pyramid(inputs['cld_rgb_nrm'][:, :3, :].transpose(1, 2).contiguous(),
                                                           inputs['dpt_xyz'], index_dtype=self.index_dtype))
-        if fused and self.layout == "pm" and forward_pm.supported(self):
+        if fused and forward_pm.supported(self):
             return forward_pm.forward(self, inputs, end_points, two_streams=self.two_streams, taps=taps)
-        if self.two_streams and fused and (rgb.shape[2] * rgb.shape[3]) % 16 == 0:
-            return self._forward_two_streams(inputs, end_points)
-        if not fused or (inputs['rgb'].shape[2] * inputs['rgb'].shape[3]) % 16:
-            rgb_emb = self.cnn_pre_stages(inputs['rgb'])
-        else:   # stem: conv7x7 -> [BN+ReLU in one pass] -> maxpool
-            y = ops.affine_act_(self.cnn_pre_stages[0](inputs['rgb']), *ops.bn_fold(self.cnn_pre_stages[1]),
-                                act=ops.ACT_RELU)
-            rgb_emb = self.cnn_pre_stages[3](y)
+        # stock modules + the neighbour operators (training; or widths the row kernels do not cover)
+        rgb_emb = self.cnn_pre_stages(inputs['rgb'])
         p_emb = self.rndla_pre_stages(inputs['cld_rgb_nrm']).unsqueeze(3)
 
         ds_emb = []
@@ -683,12 +436,7 @@ class FFB6D(nn.Module):
         rgb_emb_c = ops.choose_gather(rgb_emb, inputs['choose'])
 
         def head(seq):
-            if not fused:
-                return seq(torch.cat([rgb_emb_c, p_emb], dim=1))
-            y = seq[0].fused(rgb_emb_c, x2=p_emb)          # cat(rgb_c, p_emb) as two K-ranges
-            for layer in list(seq)[1:]:
-                y = layer.fused(y)
-            return y
+            return seq(torch.cat([rgb_emb_c, p_emb], dim=1))
 
         end_points['pred_rgbd_segs'] = head(self.rgbd_seg_layer)
         end_points['pred_kp_ofs'] = head(self.kp_ofst_layer).view(

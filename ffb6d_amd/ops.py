@@ -7,6 +7,8 @@ autograd-capable wrapper around one C-ABI entry point of libffb6d_amd.so.
     relative_pos_encoding(xyz, neigh_idx)       == Building_block.relative_pos_encoding RandLANet.py:216-223
     att_pool(feature_set, att_activation)       == the softmax/mul/sum of Att_pooling.forward RandLANet.py:245-248
     choose_gather(rgb_emb, choose)              == the final per-point pixel pick ffb6d.py:309-312
+    upsample_align / prelu                      == PSPUpsample's up-sampling and PReLU with hand-written backward (pspnet.py:34-45)
+    bn_fold(bn)                                 == eval-mode BatchNorm as (scale, shift), for the fused inference path
 
 Tensors: float32, contiguous (made so), on a ROCm device; indices int64 or int32.
 There is no CPU path: a CPU tensor raises FFB6DNativeError."""
@@ -236,25 +238,6 @@ def relative_pos_encoding_cm(xyz, neigh_idx):
     return out
 
 
-def att_pool2(feat1, feat2, att_activation):
-    """att_pool(cat(feat1, feat2, dim=1), att_activation) without the cat (inference only).
-    feat1 [B,C1,N,K], feat2 [B,C2,N,K], att_activation [B,C1+C2,N,K] -> [B,C1+C2,N,1]."""
-    _need_gpu(feat1, feat2, att_activation)
-    lib = _lib.load()
-    f1, f2, a = _f32(feat1.detach()), _f32(feat2.detach()), _f32(att_activation.detach())
-    B, C1, N, K = f1.shape
-    C2 = f2.shape[1]
-    if f2.shape != (B, C2, N, K) or a.shape != (B, C1 + C2, N, K):
-        raise ValueError(f"bad shapes {tuple(f1.shape)} / {tuple(f2.shape)} / {tuple(a.shape)}")
-    out = torch.empty((B, C1 + C2, N), dtype=torch.float32, device=f1.device)
-    nbytes = 2 * 4 * B * (C1 + C2) * N * K + 4 * B * (C1 + C2) * N
-    with torch.cuda.device(f1.device), _lib.traced("att_pool", nbytes, (C1 + C2, N)):
-        rc = lib.ffb6d_att_pool2_f32(f1.data_ptr(), C1, f2.data_ptr(), C2, a.data_ptr(), out.data_ptr(),
-                                     B, N, K, _stream(f1))
-    _lib.check(rc, "ffb6d_att_pool2_f32")
-    return out.unsqueeze(3)
-
-
 class _AttPool(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)      # under autocast: the fp32 kernels, fp32 operands
@@ -381,114 +364,6 @@ def prelu(x, weight):
     return _PReLU.apply(x, weight)
 
 
-def _rows(x):
-    """[B,K,*spatial] -> (tensor viewed as [B,K,P] with contiguous rows, batch stride in floats)."""
-    B, K = x.shape[0], x.shape[1]
-    x3 = x.reshape(B, K, -1)
-    if x3.stride(2) != 1 or (K > 1 and x3.stride(1) != x3.shape[2]) or x3.data_ptr() % 16 or x3.stride(0) % 4:
-        x3 = x3.contiguous()
-    return x3, x3.stride(0)
-
-
-def shared_mlp(x1, wt, bias=None, act=ACT_NONE, x2=None, gather=None):
-    """Fused shared MLP on channel-major activations (inference only, no autograd):
-
-        out[b,:,p] = act( wt.T @ cat(x1, x2)[b,:,p] + bias + Y[b,:,idx[b,p]] )
-
-    x1 [B,K1,*S], x2 [B,K2,*S] or None, wt [K1+K2, Cout] (transposed, BatchNorm folded),
-    bias [Cout] or None, gather = (Y [B,Cout,Py], idx [B,P] int32/int64) or None.
-    Returns [B,Cout,*S]."""
-    _need_gpu(x1, wt)
-    lib = _lib.load()
-    if x1.dtype != torch.float32 or (x2 is not None and x2.dtype != torch.float32):
-        raise TypeError("float32 expected")
-    cols = x1[0, 0].numel() if x1.numel() else 0
-    if gather is None and 0 < cols < 2048 and cols % 4:
-        # a handful of columns per frame (e.g. the 1x1 and 3x3 levels of the pyramid pooling): pad to a
-        # multiple of 4 so the launch takes the flat split-K kernel (all frames in one column range, K
-        # spread over workgroups) instead of one under-filled tile per frame walking the whole K
-        pad = (-cols) % 4
-        p1 = torch.nn.functional.pad(x1.detach().reshape(x1.shape[0], x1.shape[1], cols), (0, pad))
-        p2 = None if x2 is None else torch.nn.functional.pad(x2.detach().reshape(x2.shape[0], x2.shape[1], cols), (0, pad))
-        out = shared_mlp(p1, wt, bias, act, x2=p2)[:, :, :cols]
-        return out.reshape(out.shape[0], out.shape[1], *x1.shape[2:])
-    a, a_bs = _rows(x1.detach())
-    B, K1, P = a.shape
-    K2 = 0
-    b3, b_bs = None, 0
-    if x2 is not None:
-        b3, b_bs = _rows(x2.detach())
-        if b3.shape[0] != B or b3.shape[2] != P:
-            raise ValueError(f"x2 {tuple(x2.shape)} does not match x1 {tuple(x1.shape)}")
-        K2 = b3.shape[1]
-    if wt.dim() != 2 or wt.shape[0] != K1 + K2 or not wt.is_contiguous() or wt.dtype != torch.float32:
-        raise ValueError(f"wt must be contiguous float32 [{K1 + K2}, Cout], got {tuple(wt.shape)}")
-    Cout = wt.shape[1]
-    y = gi = None
-    py = ybs = bits = 0
-    if gather is not None:
-        y, gi = gather
-        y = _f32(y.detach()).reshape(B, Cout, -1)
-        gi, bits = _idx(gi.reshape(B, -1))
-        if gi.shape[1] != P:
-            raise ValueError("gather index must have one entry per output column")
-        py, ybs = y.shape[2], y.stride(0)
-    out = torch.empty((B, Cout, P), dtype=torch.float32, device=x1.device)
-    wbytes = lib.ffb6d_shared_mlp_workspace_bytes(B, Cout, K1 + K2, P)
-    ws = torch.empty((wbytes,), dtype=torch.uint8, device=x1.device) if wbytes else None
-    nbytes = 4 * ((K1 + K2) * Cout + B * (K1 + K2) * P + B * Cout * P) + (B * P * bits // 8 + 4 * B * Cout * py if y is not None else 0)
-    with torch.cuda.device(x1.device), _lib.traced("shared_mlp", nbytes, (K1 + K2, Cout, P)):
-        rc = lib.ffb6d_shared_mlp_f32(
-            wt.data_ptr(), bias.data_ptr() if bias is not None else None,
-            a.data_ptr(), K1, a_bs, b3.data_ptr() if b3 is not None else None, K2, b_bs,
-            y.data_ptr() if y is not None else None, gi.data_ptr() if gi is not None else None, bits, py, ybs,
-            out.data_ptr(), out.stride(0), B, Cout, P, int(act),
-            ws.data_ptr() if ws is not None else None, wbytes, _stream(x1))
-    _lib.check(rc, "ffb6d_shared_mlp_f32")
-    return out.view(B, Cout, *x1.shape[2:])
-
-
-def att_score_pool(f_nei, f_xyz, fc_wt):
-    """Att_pooling up to the pooled tensor with the score GEMM fused in (inference only):
-    scores = fc(cat(f_nei, f_xyz)); returns sum_k cat(f_nei, f_xyz) * softmax_k(scores) as [B,d,N,1].
-    f_nei [B,d1,N,16], f_xyz [B,d2,N,16], fc_wt = fc.weight^T [d1+d2, d1+d2]."""
-    _need_gpu(f_nei, f_xyz, fc_wt)
-    lib = _lib.load()
-    a, b = _f32(f_nei.detach()), _f32(f_xyz.detach())
-    B, d1, N, K = a.shape
-    d2 = b.shape[1]
-    if b.shape != (B, d2, N, K) or fc_wt.shape != (d1 + d2, d1 + d2) or not fc_wt.is_contiguous():
-        raise ValueError(f"bad shapes {tuple(a.shape)} / {tuple(b.shape)} / {tuple(fc_wt.shape)}")
-    out = torch.empty((B, d1 + d2, N), dtype=torch.float32, device=a.device)
-    d = d1 + d2
-    nbytes = 4 * (d * d + B * d * N * K + B * d * N)
-    with torch.cuda.device(a.device), _lib.traced("att_score_pool", nbytes, (d, N)):
-        rc = lib.ffb6d_att_score_pool_f32(fc_wt.data_ptr(), a.data_ptr(), d1, b.data_ptr(), d2, out.data_ptr(),
-                                          B, N, K, _stream(a))
-    _lib.check(rc, "ffb6d_att_score_pool_f32")
-    return out.unsqueeze(3)
-
-
-def bilinear_resize(x, size, align_corners):
-    """x [B,C,IH,IW] float32 -> [B,C,OH,OW], bilinear, the two conventions of the colour branch
-    (pspnet.py:24-28 align_corners=False; pspnet.py:37-42 align_corners=True).  Inference only
-    (no autograd): callers fall back to torch's differentiable op when gradients are needed."""
-    _need_gpu(x)
-    if x.dim() != 4:
-        raise ValueError(f"expected [B,C,H,W], got {tuple(x.shape)}")
-    lib = _lib.load()
-    xc = _f32(x.detach())
-    B, C, IH, IW = xc.shape
-    OH, OW = int(size[0]), int(size[1])
-    out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
-    nbytes = 4 * B * C * (IH * IW + OH * OW)
-    with torch.cuda.device(x.device), _lib.traced("bilinear_resize", nbytes, (C, OH, OW)):
-        rc = lib.ffb6d_bilinear_resize_f32(xc.data_ptr(), out.data_ptr(), B * C, IH, IW, OH, OW,
-                                           1 if align_corners else 0, _stream(xc))
-    _lib.check(rc, "ffb6d_bilinear_resize_f32")
-    return out
-
-
 def bn_fold(bn):
     """(scale, shift) of an eval-mode BatchNorm: y = scale*x + shift.  Cached on the module and
     recomputed whenever one of its tensors was modified in place (load_state_dict, training)."""
@@ -502,84 +377,6 @@ def bn_fold(bn):
         cache = (ver, scale, shift)
         bn._ffb6d_fold = cache
     return cache[1], cache[2]
-
-
-def affine_act_(x, scale, shift, act=ACT_NONE, slope=0.0, residual=None, res_affine=None):
-    """In-place per-channel affine + optional (affine) residual + activation on [B,C,H,W]
-    (inference only): x <- act(scale*x + shift + res_scale*residual + res_shift)."""
-    _need_gpu(x)
-    lib = _lib.load()
-    if not x.is_contiguous() or x.dtype != torch.float32:
-        raise ValueError("affine_act_ needs a contiguous float32 tensor")
-    B, C = x.shape[0], x.shape[1]
-    HW = x.numel() // (B * C)
-    r = rs = rb = None
-    if residual is not None:
-        r = _f32(residual)
-        if r.shape != x.shape:
-            raise ValueError("residual shape mismatch")
-        if res_affine is not None:
-            rs, rb = res_affine
-    nbytes = 4 * x.numel() * (3 if r is not None else 2)
-    with torch.cuda.device(x.device), _lib.traced("affine_act", nbytes, (C, HW)):
-        rc = lib.ffb6d_affine_act_f32(x.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                      r.data_ptr() if r is not None else None,
-                                      rs.data_ptr() if rs is not None else None,
-                                      rb.data_ptr() if rb is not None else None,
-                                      x.data_ptr(), B, C, HW, int(act), float(slope), _stream(x))
-    _lib.check(rc, "ffb6d_affine_act_f32")
-    return x
-
-
-def channel_log_softmax_(x):
-    """In-place log_softmax over dim 1 of a contiguous [B,C,H,W] float32 map, C in {16,32,64}."""
-    _need_gpu(x)
-    lib = _lib.load()
-    if not x.is_contiguous() or x.dtype != torch.float32:
-        raise ValueError("channel_log_softmax_ needs a contiguous float32 tensor")
-    B, C = x.shape[0], x.shape[1]
-    HW = x.numel() // (B * C)
-    with torch.cuda.device(x.device), _lib.traced("channel_log_softmax", 8 * x.numel(), (C, HW)):
-        rc = lib.ffb6d_channel_log_softmax_f32(x.data_ptr(), x.data_ptr(), B, C, HW, _stream(x))
-    _lib.check(rc, "ffb6d_channel_log_softmax_f32")
-    return x
-
-
-def _int_array(values):
-    import ctypes
-    return (ctypes.c_int * len(values))(*[int(v) for v in values])
-
-
-def psp_pool(x, sizes):
-    """All adaptive average pools of `sizes` of x [B,C,H,W] in one pass -> [B,C,sum(s*s)]
-    (bins of sizes[0] first, row-major inside a level).  Inference only."""
-    _need_gpu(x)
-    lib = _lib.load()
-    xc = _f32(x.detach())
-    B, C, H, W = xc.shape
-    nb = sum(int(s) * int(s) for s in sizes)
-    out = torch.empty((B, C, nb), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device), _lib.traced("psp_pool", 4 * xc.numel() + 4 * out.numel(), (C, H * W)):
-        rc = lib.ffb6d_psp_pool_f32(xc.data_ptr(), out.data_ptr(), B * C, H, W, _int_array(sizes), len(sizes),
-                                    _stream(xc))
-    _lib.check(rc, "ffb6d_psp_pool_f32")
-    return out
-
-
-def psp_prior_sum(z, sizes, size):
-    """z [B,M,sum(s*s)] (packing of psp_pool) -> [B,M,H,W] = sum over levels of the bilinear
-    (align_corners=False) up-sampling of each level to (H,W).  Inference only."""
-    _need_gpu(z)
-    lib = _lib.load()
-    zc = _f32(z.detach())
-    B, M, _ = zc.shape
-    H, W = int(size[0]), int(size[1])
-    out = torch.empty((B, M, H, W), dtype=torch.float32, device=z.device)
-    with torch.cuda.device(z.device), _lib.traced("psp_prior_sum", 4 * zc.numel() + 4 * out.numel(), (M, H * W)):
-        rc = lib.ffb6d_psp_prior_sum_f32(zc.data_ptr(), out.data_ptr(), B * M, H, W, _int_array(sizes), len(sizes),
-                                         _stream(zc))
-    _lib.check(rc, "ffb6d_psp_prior_sum_f32")
-    return out
 
 
 def check_index_range(idx, M):

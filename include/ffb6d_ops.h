@@ -75,11 +75,6 @@ int ffb6d_relative_pos_encoding_f32(const float* xyz, const void* idx, int idx_b
 int ffb6d_att_pool_f32(const float* feat, const float* act, float* out,
                        int64_t B, int64_t C, int64_t N, int K, ffb6d_stream_t stream);
 
-/* Same pooling with the feature set given as two channel blocks, cat(feat1 [B,C1,N,K], feat2 [B,C2,N,K])
- * (RandLANet.py:204,212) without materialising the concatenation; act [B,C1+C2,N,K], out [B,C1+C2,N]. */
-int ffb6d_att_pool2_f32(const float* feat1, int64_t C1, const float* feat2, int64_t C2, const float* act,
-                        float* out, int64_t B, int64_t N, int K, ffb6d_stream_t stream);
-
 /* relative_pos_encoding written channel-major: out [B,10,N,K] (what RandLANet.py:198 permutes to). */
 int ffb6d_relative_pos_encoding_cm_f32(const float* xyz, const void* idx, int idx_bits, float* out,
                                        int64_t B, int64_t N, int K, ffb6d_stream_t stream);
@@ -88,26 +83,6 @@ int ffb6d_relative_pos_encoding_cm_f32(const float* xyz, const void* idx, int id
 int ffb6d_att_pool_bwd_f32(const float* grad_out, const float* feat, const float* act,
                            float* grad_feat, float* grad_act,
                            int64_t B, int64_t C, int64_t N, int K, ffb6d_stream_t stream);
-
-/* Fused shared MLP (1x1 conv + folded BatchNorm + activation, pytorch_utils.py:75-129 and
- * RandLA/pytorch_utils.py:35-111) on channel-major activations, fp32 MFMA:
- *   out[b,m,p] = act( sum_k wt[k,m] * X[b,k,p] + bias[m] + ygather[b,m,gidx[b,p]] )
- * X = [x1 ; x2] stacked along k (replaces torch.cat(dim=1) in front of a conv, ffb6d.py:252,261,277);
- * ygather/gidx (both or neither) add a column gather of a pre-multiplied matrix: conv(cat(a,
- * interp(b))) == W_a*a + gather(W_b*b) (ffb6d.py:247-253,273-279,283-289).
- * wt [k1+k2, cout] (transposed weights, BN folded), bias [cout] or NULL, x1 [B,k1,P] / x2 [B,k2,P]
- * with the given batch strides (in floats; rows contiguous), ygather [B,cout,py], gidx [B,P]
- * (idx_bits 32/64), out [B,cout,P].  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).
- * workspace: ffb6d_shared_mlp_workspace_bytes(...) bytes of device scratch (may be NULL when 0). */
-int ffb6d_shared_mlp_f32(const float* wt, const float* bias, const float* x1, int64_t k1,
-                         int64_t x1_batch_stride, const float* x2, int64_t k2, int64_t x2_batch_stride,
-                         const float* ygather, const void* gidx, int idx_bits, int64_t py,
-                         int64_t yg_batch_stride, float* out, int64_t out_batch_stride, int64_t B,
-                         int64_t cout, int64_t P, int act, void* workspace, size_t workspace_bytes,
-                         ffb6d_stream_t stream);
-/* Scratch for ffb6d_shared_mlp_f32 with K = k1 + k2 (non-zero only for small per-frame P, where the
- * K loop is split across workgroups and reduced by a second kernel). */
-size_t ffb6d_shared_mlp_workspace_bytes(int64_t B, int64_t cout, int64_t K, int64_t P);
 
 /* Valid-pixel sampling + point assembly of Dataset.get_item (linemod_dataset.py:262-289) without a host round trip:
  * per frame a uniformly random N-subset of the pixels with depth > min_depth in uniformly random order (fewer than N valid
@@ -197,7 +172,7 @@ int ffb6d_gather_rows_pm(int dtype, const void* feat, const void* idx, int idx_b
 int ffb6d_relative_pos_encoding_pm(int dtype, const float* xyz, const void* idx, int idx_bits, void* out, int64_t B,
                                    int64_t N, int K, ffb6d_stream_t stream);
 /* out = act( scale[c]*x + shift[c] + (res ? (rscale ? rscale[c]*res + rshift[c] : res) : 0) ) on [rows, C]; scale/shift
- * fp32; act as ffb6d_affine_act_f32.  In place (out == x) allowed. */
+ * fp32; act: 0 none, 1 ReLU, 2 leaky/PReLU with `slope`.  In place (out == x) allowed. */
 int ffb6d_affine_act_pm(int dtype, const void* x, const float* scale, const float* shift, const void* res,
                         const float* rscale, const float* rshift, void* out, int64_t rows, int64_t C, int act, float slope,
                         ffb6d_stream_t stream);
@@ -265,42 +240,6 @@ int ffb6d_psp_pool_pm(int dtype, const void* x, float* out, int64_t B, int64_t H
 /* out[b,y,x,:] = sum over levels of the bilinear (align_corners = 0) up-sampling of float32 z [B, sum(s*s), M] to (H,W). */
 int ffb6d_psp_prior_sum_pm(int dtype, const float* z, void* out, int64_t B, int64_t H, int64_t W, int64_t M, const int* sizes,
                            int nsizes, ffb6d_stream_t stream);
-
-/* Attentive pooling with the score GEMM fused in (Att_pooling.forward, RandLANet.py:243-248, up to
- * the pooled tensor): scores = W_fc * S over the feature set S = cat(x1 [B,k1,N,16], x2 [B,k2,N,16]),
- * out[b,m,n] = sum_k S[b,m,n,k] * softmax_k(scores[b,m,n,:]).  wt = W_fc transposed [k1+k2, k1+k2];
- * the [B,d,N,16] score tensor is never written.  K must be 16. */
-int ffb6d_att_score_pool_f32(const float* wt, const float* x1, int64_t k1, const float* x2, int64_t k2,
-                             float* out, int64_t B, int64_t N, int K, ffb6d_stream_t stream);
-
-/* Bilinear resize of `planes` = B*C independent [IH,IW] float32 images to [OH,OW], the two
- * flavours the colour branch uses: align_corners = 0 (F.upsample(size=...), pspnet.py:24-28) and
- * align_corners = 1 (nn.Upsample(scale_factor=2, align_corners=True), pspnet.py:37-42).
- * Same arithmetic as ATen's upsample_bilinear2d. */
-int ffb6d_bilinear_resize_f32(const float* in, float* out, int64_t planes, int64_t IH, int64_t IW,
-                              int64_t OH, int64_t OW, int align_corners, ffb6d_stream_t stream);
-
-/* Per-channel affine (+ affine residual) + activation on [B,C,HW] maps, in place allowed:
- *   out = act(scale[c]*x + shift[c] + (res ? rscale[c]*res + rshift[c] : 0));  rscale/rshift NULL = 1/0.
- * The eval-mode BatchNorm + ReLU/PReLU + residual-add glue of the colour branch (extractors.py:49-63,
- * pspnet.py:34-45) in one pass.  act: 0 none, 1 ReLU, 2 leaky/PReLU with `slope`.  HW % 4 == 0. */
-int ffb6d_affine_act_f32(const float* x, const float* scale, const float* shift, const float* res,
-                         const float* rscale, const float* rshift, float* out, int64_t B, int64_t C,
-                         int64_t HW, int act, float slope, ffb6d_stream_t stream);
-
-/* log_softmax over the channel axis of [B,C,HW] (pspnet.py:108-112 `final`: nn.LogSoftmax() on a 4-d
- * tensor acts on dim 1), C in {16,32,64}; in place allowed. */
-int ffb6d_channel_log_softmax_f32(const float* x, float* out, int64_t B, int64_t C, int64_t HW,
-                                  ffb6d_stream_t stream);
-
-/* Pyramid pooling helpers (pspnet.py:7-31).  psp_pool: all adaptive average pools of `sizes` (<= 4
- * sizes, e.g. 1,2,3,6) of `planes` = B*C [H,W] maps in one pass; out [planes, sum(s*s)] (bins of size
- * sizes[0] first, row-major).  psp_prior_sum: out[plane,y,x] = sum_i bilinear(z_i)(y,x) for maps
- * z [planes, sum(s*s)] in the same packing, align_corners = False, W % 4 == 0. */
-int ffb6d_psp_pool_f32(const float* x, float* out, int64_t planes, int64_t H, int64_t W,
-                       const int* sizes, int nsizes, ffb6d_stream_t stream);
-int ffb6d_psp_prior_sum_f32(const float* z, float* out, int64_t planes, int64_t H, int64_t W,
-                            const int* sizes, int nsizes, ffb6d_stream_t stream);
 
 /* Depth image -> xyz image, the dataset's dpt_2_pcld (linemod_dataset.py:188-199,258-259) on the device:
  * depth [B,H,W] f32 (raw units), K [B,3,3] f64 row-major intrinsics, out [B,3,H,W] f32 (x,y,z planes),

@@ -105,7 +105,7 @@ def main():
 
     def bench_setup(precision, batch):
         net = T.build(22, 12288, dev)
-        net.two_streams, net.layout, net.precision, net.index_dtype = True, "pm", precision, torch.int64
+        net.two_streams, net.precision, net.index_dtype = True, precision, torch.int64
         fr = distributed.shard_frames(2 if precision == "fp32" else 5, batch, 0, None, n_points=12288)
         base = {"rgb": torch.from_numpy(fr["rgb"]).to(dev).float(), "cld_rgb_nrm": torch.from_numpy(fr["cld_rgb_nrm"]).to(dev),
                 "choose": torch.from_numpy(fr["choose"]).to(dev).long(), "dpt_xyz": torch.from_numpy(fr["dpt_xyz"]).to(dev)}

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "ffb6d_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libsimt_ffb6d.so")
-KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip", "lfa_pm.hip", "train_ops.hip", "upconv.hip", "posenc.hip", "ops_pm.hip", "neighbour_ops.hip", "knn.hip", "knn_pruned.hip", "knn_pick.hip", "pose.hip", "inputs.hip", "holefill.hip", "resize.hip", "shared_mlp.hip"]
+KERNEL_SOURCES = ["errors.hip", "mlp_pm.hip", "lfa_pm.hip", "train_ops.hip", "upconv.hip", "posenc.hip", "ops_pm.hip", "neighbour_ops.hip", "knn.hip", "knn_pruned.hip", "knn_pick.hip", "pose.hip", "inputs.hip", "holefill.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 # statements after which a wave relies on lock-step execution for LDS traffic between its lanes
@@ -71,10 +71,7 @@ def chevrons_to_launch_macro(src):
         pos = e + 1
 
 
-# inline assembly has no host meaning: the one block of the library (row16_max of csrc/shared_mlp.hip: four v_max_f32_dpp with
-# row_ror 8/4/2/1) is replaced by the same reduction written with the row_ror helper above it (update_dpp, emulated)
-ASM_BLOCKS = {"shared_mlp.hip": (re.compile(r'asm volatile\("s_nop 1\\n\\tv_max_f32_dpp.*?: "\+v"\(v\)\);', re.S),
-                                 "v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); v = fmaxf(v, row_ror<1>(v));")}
+ASM_BLOCKS = {}      # (pattern, replacement) per source with inline assembly: none left since csrc/shared_mlp.hip was removed
 
 
 def transformed(name):

@@ -29,7 +29,7 @@ def test_headers_declare_the_expected_entry_points():
                  "cpp_knn_batch_distance_pick", "cpp_knn_batch_distance_pick_omp",
                  "ffb6d_knn_batch_device", "ffb6d_random_sample_f32",
                  "ffb6d_nearest_interpolation_f32", "ffb6d_gather_neighbour_f32",
-                 "ffb6d_relative_pos_encoding_f32", "ffb6d_att_pool_f32", "ffb6d_shared_mlp_f32",
+                 "ffb6d_relative_pos_encoding_f32", "ffb6d_att_pool_f32", "ffb6d_mlp_pm_f32",
                  "ffb6d_vote_sets_f32", "ffb6d_mean_shift_f32", "ffb6d_mean_shift_workspace_bytes",
                  "ffb6d_set_labels_to_points", "ffb6d_refine_mask_by_center", "ffb6d_best_fit_transform_f32"):
         assert must in names

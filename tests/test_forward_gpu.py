@@ -64,20 +64,16 @@ def oracle_on_device(net, inputs):
 # the last two are the benchmarked configurations (BASELINE.json configs 2 and 4: bs=8, N=12288 / N=24576)
 @pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (1, 1, 12288, 480, 640, 22), (4, 1, 24576, 480, 640, 22),
                                  (2, 8, 12288, 480, 640, 22), (4, 8, 24576, 480, 640, 22)])
-@pytest.mark.parametrize("layout", ["pm", "cm"])
-def test_hot_path_matches_plain_torch_on_the_same_device(device, cfg, layout):
+def test_hot_path_matches_plain_torch_on_the_same_device(device, cfg):
     config, bs, n_pts, h, w, n_cls = cfg
-    if layout == "cm" and bs == 8:
-        pytest.skip("channel-major A/B path: covered at bs <= 2")
     frames = synth.make_batch(config, bs, n_points=n_pts, height=h, width=w)
     net = build(n_cls, n_pts, device)
-    net.layout = layout
     inputs = pyramid.frames_to_device(frames, device)
     with torch.no_grad():
         ep = net(inputs)
     ref = oracle_on_device(net, inputs)
     for k in ("pred_rgbd_segs", "pred_kp_ofs", "pred_ctr_ofs"):
-        assert_close_scaled(ep[k].cpu().numpy(), ref[k].cpu().numpy(), HOT_TOL, (cfg, layout, k))
+        assert_close_scaled(ep[k].cpu().numpy(), ref[k].cpu().numpy(), HOT_TOL, (cfg, k))
 
 
 @pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (1, 2, 12288, 480, 640, 22)])
@@ -135,7 +131,7 @@ def test_bf16_forward_matches_fp32_oracle_at_bf16_tolerance(device, cfg):
 
 
 def test_weight_updates_reach_the_fused_kernels(device):
-    """Stale-cache guard (folded / split / padded / channels-last weights are cached per module): a model that already
+    """Stale-cache guard (folded / padded / k-chunked / channels-last weights are cached per module): a model that already
     ran in eval() and then gets other weights -- load_state_dict, an in-place edit -- must answer like a fresh model."""
     frames = synth.make_batch(7, 1, n_points=1024, height=120, width=160)
     with open(os.path.join(GOLDEN, "state_dict_keys.json")) as fh:
@@ -143,30 +139,27 @@ def test_weight_updates_reach_the_fused_kernels(device):
     sd_a = synth.synth_state_dict_from_shapes(shapes, seed=0, n_classes=5)
     sd_b = synth.synth_state_dict_from_shapes(shapes, seed=1, n_classes=5)
     inputs = pyramid.frames_to_device(frames, device)
-    for layout in ("pm", "cm"):
-        net = M.FFB6D(n_classes=5, n_pts=1024)
-        net.load_state_dict(sd_a)
-        net = net.to(device).eval()
-        net.layout = layout
-        fresh = M.FFB6D(n_classes=5, n_pts=1024)
-        fresh.load_state_dict(sd_b)
-        fresh = fresh.to(device).eval()
-        fresh.layout = layout
-        with torch.no_grad():
-            first = {k: v.clone() for k, v in net(inputs).items()}
-            net.load_state_dict(sd_b)                      # same Parameter objects, new values
-            second = net(inputs)
-            want = fresh(inputs)
-            for k in want:
-                assert not torch.equal(first[k], second[k]), (layout, k)
-                assert_close_scaled(second[k].cpu().numpy(), want[k].cpu().numpy(), HOT_TOL, (layout, k, "reload"))
-            w = net.rndla_ds_stages[1].lfa.att_pooling_1.fc.weight
-            w.mul_(1.5)                                    # in-place edit while staying in eval()
-            fresh.rndla_ds_stages[1].lfa.att_pooling_1.fc.weight.mul_(1.5)
-            third, want = net(inputs), fresh(inputs)
-            for k in want:
-                assert_close_scaled(third[k].cpu().numpy(), want[k].cpu().numpy(), HOT_TOL, (layout, k, "edit"))
-            assert any(not torch.equal(third[k], second[k]) for k in want)
+    net = M.FFB6D(n_classes=5, n_pts=1024)
+    net.load_state_dict(sd_a)
+    net = net.to(device).eval()
+    fresh = M.FFB6D(n_classes=5, n_pts=1024)
+    fresh.load_state_dict(sd_b)
+    fresh = fresh.to(device).eval()
+    with torch.no_grad():
+        first = {k: v.clone() for k, v in net(inputs).items()}
+        net.load_state_dict(sd_b)                      # same Parameter objects, new values
+        second = net(inputs)
+        want = fresh(inputs)
+        for k in want:
+            assert not torch.equal(first[k], second[k]), k
+            assert_close_scaled(second[k].cpu().numpy(), want[k].cpu().numpy(), HOT_TOL, (k, "reload"))
+        w = net.rndla_ds_stages[1].lfa.att_pooling_1.fc.weight
+        w.mul_(1.5)                                    # in-place edit while staying in eval()
+        fresh.rndla_ds_stages[1].lfa.att_pooling_1.fc.weight.mul_(1.5)
+        third, want = net(inputs), fresh(inputs)
+        for k in want:
+            assert_close_scaled(third[k].cpu().numpy(), want[k].cpu().numpy(), HOT_TOL, (k, "edit"))
+        assert any(not torch.equal(third[k], second[k]) for k in want)
 
 
 def test_train_mode_without_grad_keeps_training_semantics(device):
@@ -230,7 +223,7 @@ def test_forward_full_size_matches_reference_sample(device):
 
 def test_two_stream_forward_equals_single_stream(device):
     """The point branch runs on a second HIP stream under the colour branch's convolutions
-    (model.FFB6D._forward_two_streams); same kernels, same order per tensor -> same bits, unless
+    (forward_pm.forward); same kernels, same order per tensor -> same bits, unless
     MIOpen picked a split-K convolution that accumulates with atomics (then even two single-stream
     runs differ in the last bits and the comparison falls back to HOT_TOL of the output range).
     Repeated, with a NaN-filled block recycled through the allocator in between, so that a missing
@@ -256,15 +249,15 @@ def test_two_stream_forward_equals_single_stream(device):
                     assert float((got[k] - want[k]).abs().max()) <= HOT_TOL * scale, (rep, k)
 
 
-@pytest.mark.parametrize("layout,two_streams", [("pm", True), ("pm", False), ("cm", True)])
-def test_forward_builds_the_index_pyramid_itself_when_it_is_missing(device, layout, two_streams):
+@pytest.mark.parametrize("two_streams", [True, False])
+def test_forward_builds_the_index_pyramid_itself_when_it_is_missing(device, two_streams):
     """Inputs that carry `dpt_xyz` instead of the 26 index tensors: the forward runs the dataset's 22 KNN searches
     (linemod_dataset.py:299-353) on the device -- the point-major path level by level on a third HIP stream under the
     network (forward_pm.StreamedPyramid) -- and must produce the bits of the forward fed with a prebuilt pyramid.
     Repeated with recycled NaN blocks so that a missing event / record_stream shows up as a race."""
     frames = synth.make_batch(9, 2, n_points=12288, height=480, width=640)
     net = build(22, 12288, device)
-    net.layout, net.two_streams = layout, two_streams
+    net.two_streams = two_streams
     full = pyramid.frames_to_device(frames, device)
     lazy = {k: full[k] for k in ('rgb', 'cld_rgb_nrm', 'choose')}
     lazy['dpt_xyz'] = torch.from_numpy(frames['dpt_xyz']).to(device)

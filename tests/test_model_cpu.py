@@ -51,19 +51,14 @@ def test_batchnorm_folding_is_exact_algebra(flavour, dims):
     x = torch.randn(3, 12, 50) if dims == 1 else torch.randn(3, 12, 50, 4)
     with torch.enable_grad():
         want = mlp(x.clone())                 # unfused conv -> BN -> act
-    wt, b = mlp.folded()                      # what the fused GPU kernel consumes: [Cin,Cout], [Cout]
-    assert wt.shape == (12, 7) and b.shape == (7,)
-    y = torch.einsum("km,bkp->bmp", wt, x.reshape(3, 12, -1)) + b.view(1, -1, 1)
+    from ffb6d_amd import forward_pm
+    w, b = forward_pm.folded(mlp)             # what the fused GPU kernels consume: conv-layout [Cout,Cin], [Cout]
+    assert w.shape == (7, 12) and b.shape == (7,)
+    y = torch.einsum("mk,bkp->bmp", w, x.reshape(3, 12, -1)) + b.view(1, -1, 1)
     y = torch.nn.functional.leaky_relu(y, 0.2) if flavour == "randla" else torch.relu(y)
     torch.testing.assert_close(y.view_as(want), want, rtol=1e-5, atol=1e-5)
-    wa, wb, b2 = mlp.split(5)
-    assert torch.equal(torch.cat([wa, wb]), wt) and b2 is b
-    # point-major operands of the same layer: conv-layout weight (optionally K-padded with zero columns), same bias
-    from ffb6d_amd import forward_pm
-    w_pm, b_pm = forward_pm.folded(mlp)
-    assert torch.equal(w_pm, wt.t()) and torch.equal(b_pm, b)
-    w16, _ = forward_pm.folded(mlp, pad_k=16)
-    assert w16.shape == (7, 16) and torch.equal(w16[:, :12], w_pm) and (w16[:, 12:] == 0).all()
+    w16, b16 = forward_pm.folded(mlp, pad_k=16)       # K-padded with zero columns, same bias
+    assert w16.shape == (7, 16) and torch.equal(w16[:, :12], w) and (w16[:, 12:] == 0).all() and torch.equal(b16, b)
 
 
 def test_folded_weight_caches_follow_in_place_edits_and_load_state_dict():
@@ -73,18 +68,17 @@ def test_folded_weight_caches_follow_in_place_edits_and_load_state_dict():
     from ffb6d_amd import forward_pm
     torch.manual_seed(1)
     mlp = M.SharedMLP(8, 4, flavour="pvn").eval()
-    wt0, b0 = mlp.folded()
-    assert mlp.folded()[0] is wt0                                   # cache hit
+    wt0, b0 = forward_pm.folded(mlp)
+    assert forward_pm.folded(mlp)[0] is wt0                         # cache hit
     with torch.no_grad():
         mlp.conv.weight.mul_(2.0)
-    wt1, _ = mlp.folded()
+    wt1, _ = forward_pm.folded(mlp)
     torch.testing.assert_close(wt1, 2 * wt0)
     with torch.no_grad():
         mlp._bn_module().running_mean.add_(1.0)
-    assert not torch.equal(mlp.folded()[1], b0)
+    assert not torch.equal(forward_pm.folded(mlp)[1], b0)
     other = M.SharedMLP(8, 4, flavour="pvn").eval()
     mlp.load_state_dict(other.state_dict())
-    torch.testing.assert_close(mlp.folded()[0], other.folded()[0])
     torch.testing.assert_close(forward_pm.folded(mlp)[0], forward_pm.folded(other)[0])
     att = M.AttPooling(8, 4).eval()
     w_a = forward_pm.fc_weight(att).clone()

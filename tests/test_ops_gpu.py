@@ -164,164 +164,13 @@ def test_index_range_check(device):
     assert ops.check_index_range(idx.int()[:, :3], 10) == 0
 
 
-@pytest.mark.parametrize("shape,size,ac", [((2, 16, 60, 80), (120, 160), True), ((1, 3, 7, 5), (14, 10), True),
-                                           ((2, 8, 6, 6), (60, 80), False), ((1, 4, 1, 1), (60, 80), False),
-                                           ((1, 5, 3, 3), (9, 7), False), ((1, 2, 240, 320), (480, 640), True)])
-def test_bilinear_resize_matches_torch(device, shape, size, ac):
-    x = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
-    want = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=ac)   # CPU ATen
-    got = ops.bilinear_resize(x.to(device), size, ac).cpu()
-    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
-
-
-def _mlp_ref(x1, w, bias, act, x2=None, gather=None):
-    x = x1 if x2 is None else torch.cat([x1, x2], dim=1)
-    B, K = x.shape[:2]
-    y = torch.einsum("km,bkp->bmp", w.double(), x.reshape(B, K, -1).double())
-    if bias is not None:
-        y = y + bias.double().view(1, -1, 1)
-    if gather is not None:
-        Y, idx = gather
-        y = y + torch.gather(Y.double(), 2, idx.long().unsqueeze(1).expand(-1, Y.shape[1], -1))
-    if act == 1:
-        y = torch.relu(y)
-    elif act == 2:
-        y = torch.nn.functional.leaky_relu(y, 0.2)
-    return y.float()
-
-
-# (B, K1, K2, Cout, P, act, gather) -- shapes of FFB6D's shared MLPs incl. ragged ones
-@pytest.mark.parametrize("B,K1,K2,Cout,P,act,py", [
-    (2, 9, 0, 8, 12288, 2, 0), (1, 10, 0, 16, 3072 * 16, 2, 0), (2, 32, 0, 32, 768 * 16, 0, 0),
-    (2, 64, 64, 64, 3072, 1, 0), (1, 1024, 0, 1024, 4800, 1, 48), (2, 128, 0, 64, 4800, 1, 768),
-    (1, 256, 512, 256, 192, 2, 0), (1, 128, 0, 22, 12288, 0, 0), (3, 17, 5, 37, 301, 1, 13),
-    (1, 2048, 0, 1024, 640, 1, 0), (2, 128, 0, 128, 130, 2, 0),
-    # small per-frame P: flat columns over frames + split-K partial slabs
-    (8, 1024, 0, 512, 48, 1, 0), (8, 512, 512, 256, 192, 2, 0), (8, 256, 0, 256, 192, 1, 48),
-    (4, 128, 0, 22, 768, 0, 0), (2, 48, 16, 40, 1024, 1, 100),
-    # pipelined kernel (per-frame tiles, Cout > 32): K tail (rows past K come back as zeros from the buffer range
-    # check), second source shorter than a k-tile, Cout that is no multiple of the row tile, ragged last column tile
-    (1, 32, 8, 64, 4096, 1, 0), (1, 48, 0, 72, 2052, 2, 50), (2, 16, 16, 128, 2048, 0, 0),
-    (1, 1000, 0, 136, 2048, 1, 0), (2, 64, 24, 132, 2304, 2, 7),
-    # a few ragged columns per frame (pyramid-pooling levels 1x1 and 3x3): padded into the flat kernel
-    (8, 512, 0, 1024, 1, 0, 0), (8, 512, 0, 1024, 9, 0, 0), (2, 64, 32, 128, 7, 1, 0),
-])
-def test_shared_mlp_matches_fp64_reference(device, B, K1, K2, Cout, P, act, py):
-    g = torch.Generator().manual_seed(K1 + Cout + P)
-    x1 = torch.randn(B, K1, P, generator=g)
-    x2 = torch.randn(B, K2, P, generator=g) if K2 else None
-    w = torch.randn(K1 + K2, Cout, generator=g) / (K1 + K2) ** 0.5
-    bias = torch.randn(Cout, generator=g)
-    gather = (torch.randn(B, Cout, py, generator=g), torch.randint(0, py, (B, P), generator=g)) if py else None
-    want = _mlp_ref(x1, w, bias, act, x2, gather)
-    d = lambda t: None if t is None else t.to(device)
-    got = ops.shared_mlp(d(x1), d(w), d(bias), act, x2=d(x2),
-                         gather=None if gather is None else (d(gather[0]), d(gather[1]))).cpu()
-    assert got.shape == want.shape
-    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
-
-
-def test_shared_mlp_ignores_non_finite_neighbours_of_its_operands(device):
-    """The pipelined kernel lets out-of-tile loads wrap into neighbouring rows; what it reads there may only
-    reach accumulator elements that are never stored.  Operands embedded in NaN-filled storage (batch stride
-    larger than K*P, weights inside a larger buffer) must give the same result as clean ones."""
-    g = torch.Generator().manual_seed(9)
-    B, K, C, P = 2, 40, 72, 2052
-    x = torch.randn(B, K, P, generator=g).to(device)
-    w = (torch.randn(K, C, generator=g) / K ** 0.5).to(device)
-    bias = torch.randn(C, generator=g).to(device)
-    want = ops.shared_mlp(x, w, bias, ops.ACT_RELU)
-    big = torch.full((B, K + 24, P), float("nan"), device=device)
-    big[:, :K] = x
-    wbuf = torch.full((K + 16, C), float("nan"), device=device)
-    wbuf[:K] = w
-    got = ops.shared_mlp(big[:, :K], wbuf[:K], bias, ops.ACT_RELU)
-    assert torch.isfinite(got).all()
-    assert torch.equal(got, want)
-
-
-def test_shared_mlp_4d_views_and_channel_slices(device):
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(2, 48, 100, 16, generator=g).to(device)        # [B,C,N,K] like the LFA tensors
-    w = (torch.randn(16, 24, generator=g) / 4).to(device)
-    got = ops.shared_mlp(x[:, 16:32], w, None, ops.ACT_LEAKY)       # channel slice, batch stride != K*P
-    want = _mlp_ref(x[:, 16:32].cpu(), w.cpu(), None, 2).view(2, 24, 100, 16)
-    assert got.shape == (2, 24, 100, 16)
-    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
-
-
-def test_channel_major_variants_match_the_reference_layout_ops(device):
+def test_channel_major_encoding_matches_the_reference_layout_op(device):
     g = torch.Generator().manual_seed(12)
     xyz = (torch.rand(2, 300, 3, generator=g) * 2 - 1).to(device)
     idx = torch.randint(0, 300, (2, 300, 16), generator=g).to(device)
     a = ops.relative_pos_encoding_cm(xyz, idx)
     b = ops.relative_pos_encoding(xyz, idx).permute(0, 3, 1, 2).contiguous()
     assert torch.equal(a, b)
-    f1 = torch.randn(2, 8, 77, 16, generator=g).to(device)
-    f2 = torch.randn(2, 24, 77, 16, generator=g).to(device)
-    act = (3 * torch.randn(2, 32, 77, 16, generator=g)).to(device)
-    assert torch.equal(ops.att_pool2(f1, f2, act), ops.att_pool(torch.cat([f1, f2], 1), act))
-
-
-def test_affine_act_matches_bn_relu_add(device):
-    g = torch.Generator().manual_seed(3)
-    bn = torch.nn.BatchNorm2d(6).eval()
-    bn2 = torch.nn.BatchNorm2d(6).eval()
-    for m in (bn, bn2):
-        m.weight.data.uniform_(0.5, 1.5, generator=g); m.bias.data.normal_(generator=g)
-        m.running_mean.normal_(generator=g); m.running_var.uniform_(0.5, 2, generator=g)
-    x = torch.randn(2, 6, 10, 12, generator=g)
-    r = torch.randn(2, 6, 10, 12, generator=g)
-    want = torch.relu(bn(x) + bn2(r))
-    bn, bn2 = bn.to(device), bn2.to(device)
-    got = ops.affine_act_(x.to(device).clone(), *ops.bn_fold(bn), act=ops.ACT_RELU, residual=r.to(device),
-                          res_affine=ops.bn_fold(bn2))
-    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
-    want = torch.nn.functional.leaky_relu(bn.cpu()(x), 0.25)
-    got = ops.affine_act_(x.to(device).clone(), *ops.bn_fold(bn.to(device)), act=ops.ACT_LEAKY, slope=0.25)
-    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
-    with torch.no_grad():
-        bn.weight.mul_(2.0)                       # in-place edit (optimizer step, load_state_dict) invalidates the fold
-    s2, _ = ops.bn_fold(bn)
-    torch.testing.assert_close(s2, bn.weight * torch.rsqrt(bn.running_var + bn.eps))
-
-
-def test_channel_log_softmax(device):
-    x = torch.randn(2, 64, 30, 40, generator=torch.Generator().manual_seed(1)) * 3
-    want = torch.log_softmax(x, dim=1)
-    got = ops.channel_log_softmax_(x.to(device).clone()).cpu()
-    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
-
-
-def test_psp_pool_and_prior_sum_match_torch(device):
-    g = torch.Generator().manual_seed(4)
-    x = torch.randn(2, 5, 60, 80, generator=g)
-    sizes = [1, 2, 3, 6]
-    got = ops.psp_pool(x.to(device), sizes).cpu()
-    want = torch.cat([torch.nn.functional.adaptive_avg_pool2d(x, (s, s)).reshape(2, 5, -1) for s in sizes], dim=2)
-    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
-    z = torch.randn(2, 7, 50, generator=g)
-    got = ops.psp_prior_sum(z.to(device), sizes, (60, 80)).cpu()
-    want, off = 0, 0
-    for s in sizes:
-        want = want + torch.nn.functional.interpolate(z[:, :, off:off + s * s].reshape(2, 7, s, s), size=(60, 80),
-                                                      mode="bilinear", align_corners=False)
-        off += s * s
-    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
-
-
-@pytest.mark.parametrize("B,d1,d2,N", [(2, 16, 16, 3072), (1, 32, 32, 300), (2, 64, 64, 48), (1, 128, 128, 192), (1, 8, 24, 7)])
-def test_att_score_pool_equals_unfused_attentive_pooling(device, B, d1, d2, N):
-    g = torch.Generator().manual_seed(d1 + N)
-    f1 = torch.randn(B, d1, N, 16, generator=g)
-    f2 = torch.randn(B, d2, N, 16, generator=g)
-    w = torch.randn(d1 + d2, d1 + d2, generator=g) / (d1 + d2) ** 0.5          # fc.weight [out, in]
-    fs = torch.cat([f1, f2], dim=1)
-    att = torch.einsum("oi,binx->bonx", w.double(), fs.double())
-    want = (fs.double() * torch.softmax(att, dim=3)).sum(dim=3, keepdim=True).float()
-    got = ops.att_score_pool(f1.to(device), f2.to(device), w.t().contiguous().to(device)).cpu()
-    assert got.shape == (B, d1 + d2, N, 1)
-    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
 def _grad_pair(fn_ours, fn_ref, x, extra=()):
