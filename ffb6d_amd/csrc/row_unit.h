@@ -16,6 +16,13 @@ template <> struct RowUnit<float> {
         RowUnit u; u.v[0] = f.x; u.v[1] = f.y; u.v[2] = f.z; u.v[3] = f.w;
         return u;
     }
+    static __host__ __device__ __forceinline__ RowUnit unpack(uint4 w)         // a unit fetched earlier as raw bits
+    {
+        RowUnit u;
+        u.v[0] = __builtin_bit_cast(float, w.x); u.v[1] = __builtin_bit_cast(float, w.y);
+        u.v[2] = __builtin_bit_cast(float, w.z); u.v[3] = __builtin_bit_cast(float, w.w);
+        return u;
+    }
     __host__ __device__ __forceinline__ void store(void* base, size_t unit) const
     {
         static_cast<float4*>(base)[unit] = make_float4(v[0], v[1], v[2], v[3]);
@@ -26,7 +33,10 @@ template <> struct RowUnit<__bf16> {
     float v[8];
     static __host__ __device__ __forceinline__ RowUnit load(const void* base, size_t unit)
     {
-        const uint4 w = static_cast<const uint4*>(base)[unit];
+        return unpack(static_cast<const uint4*>(base)[unit]);
+    }
+    static __host__ __device__ __forceinline__ RowUnit unpack(uint4 w)
+    {
         const unsigned int x[4] = {w.x, w.y, w.z, w.w};
         RowUnit u;
 #pragma unroll

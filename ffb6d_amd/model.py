@@ -14,8 +14,10 @@ Two ways through this module tree:
     rows, BatchNorm folded into the GEMMs, one launch per half of the local feature aggregation, three HIP streams;
   * everything else (training, gradients, train() under no_grad, widths the row kernels do not cover): the stock modules below
     -- conv -> BatchNorm -> activation exactly as upstream, so gradients and running statistics behave like the reference --
-    with every gather / pooling / encoding step as one HIP kernel call with an autograd body (ffb6d_amd.ops) instead of
-    index.repeat + torch.gather + permute().contiguous() chains.
+    with every gather / pooling / encoding step as one HIP kernel call with an autograd body instead of index.repeat +
+    torch.gather + permute().contiguous() chains.  Those operators work on channels-last rows in the activation dtype
+    (ffb6d_amd.ops_cl), i.e. on what MIOpen's NHWC convolutions read and write: with the model in channels_last memory format
+    and torch.autocast(bfloat16) no transposing copy and no cast sits between a convolution and a neighbour operator.
 The dense 3x3/7x7 convolutions of the colour branch stay on MIOpen (out of scope for hand-written kernels, SURVEY.md section 2
 row 8).  (Rounds 1-2 also carried a channel-major fused inference path, `layout="cm"`; it was removed in round 3.)
 """
@@ -25,7 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import forward_pm, ops, pyramid
+from . import forward_pm, ops, ops_cl, pyramid
 
 D_OUT = (32, 64, 128, 256)   # ConfigRandLA.d_out (ffb6d/common.py:26)
 IN_C = 9                     # ConfigRandLA.in_c
@@ -76,11 +78,21 @@ class SharedMLP(nn.Module):
     def act_code(self):
         return ops.ACT_NONE if not self.act else (ops.ACT_LEAKY if self.flavour == "randla" else ops.ACT_RELU)
 
-    def forward(self, x):           # conv -> BN -> act as separate modules (the fused inference path folds them: forward_pm.folded)
-        y = self.conv(x)
+    def forward(self, x, pad_k=0):  # conv -> BN -> act as separate modules (the fused inference path folds them: forward_pm.folded)
+        if pad_k:                   # input rows carry pad_k zero channels behind the layer's own (ops_cl.relative_pos_encoding)
+            y = F.conv2d(x, F.pad(self.conv.weight, (0, 0, 0, 0, 0, pad_k)), self.conv.bias)
+        else:
+            y = self.conv(x)
         if self.has_bn:
             y = (self.bn if self.flavour == "randla" else self.normlayer)(y)
         return self.activation(y)
+
+
+def _activation_dtype(x):
+    """dtype the convolutions compute in: the autocast dtype when it is bfloat16, else the tensor's own (float32)"""
+    if x.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        return torch.bfloat16
+    return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
 
 
 def _autograd_path(x, mod=None):
@@ -108,7 +120,7 @@ class AttPooling(nn.Module):
 
     def forward(self, feature_set):
         att = self.fc(feature_set)
-        return self.mlp(ops.att_pool(feature_set, att))
+        return self.mlp(ops_cl.att_pool(feature_set, att))
 
 
 class BuildingBlock(nn.Module):
@@ -122,27 +134,15 @@ class BuildingBlock(nn.Module):
         self.att_pooling_2 = AttPooling(d_out, d_out)
 
     def forward(self, xyz, feature, neigh_idx):
-        if feature.is_cuda:
-            # channel-major throughout: the neighbour gather of a [B,C,N,1] tensor IS a nearest interpolation with
-            # the flattened index (autograd: the LDS-privatised scatter-add), the encoding comes out channel-major -- none of the
-            # reference's transposes / contiguous copies, forward or backward (RandLANet.py:196-214, same arithmetic)
-            B, N, K = neigh_idx.shape
-            flat_idx = neigh_idx.reshape(B, N * K, 1)
-            f_xyz = self.mlp1(ops.relative_pos_encoding_cm(xyz, neigh_idx))
-            f_nei = ops.nearest_interpolation(feature, flat_idx).view(B, -1, N, K)
-            f_agg = self.att_pooling_1(torch.cat([f_nei, f_xyz], dim=1))
-            f_xyz = self.mlp2(f_xyz)
-            f_nei = ops.nearest_interpolation(f_agg, flat_idx).view(B, -1, N, K)
-            return self.att_pooling_2(torch.cat([f_nei, f_xyz], dim=1))
-        f_xyz = ops.relative_pos_encoding(xyz, neigh_idx).permute(0, 3, 1, 2).contiguous()
-        f_xyz = self.mlp1(f_xyz)
-        f_nei = ops.gather_neighbour(feature.squeeze(-1).transpose(1, 2).contiguous(), neigh_idx)
-        f_cat = torch.cat([f_nei.permute(0, 3, 1, 2), f_xyz], dim=1)
-        f_agg = self.att_pooling_1(f_cat)
+        # RandLANet.py:196-214, same arithmetic; every tensor is rows of channels (channels_last memory) in the activation dtype,
+        # written by one kernel each -- none of the reference's permutes / contiguous copies, forward or backward (ops_cl)
+        enc = ops_cl.relative_pos_encoding(xyz, neigh_idx, dtype=_activation_dtype(feature))      # [B,16,N,K]: 10 channels + 6 zeros
+        f_xyz = self.mlp1(enc, pad_k=6)
+        f_nei = ops_cl.gather_neighbour(feature, neigh_idx)
+        f_agg = self.att_pooling_1(torch.cat([f_nei, f_xyz], dim=1))
         f_xyz = self.mlp2(f_xyz)
-        f_nei = ops.gather_neighbour(f_agg.squeeze(-1).transpose(1, 2).contiguous(), neigh_idx)
-        f_cat = torch.cat([f_nei.permute(0, 3, 1, 2), f_xyz], dim=1)
-        return self.att_pooling_2(f_cat)
+        f_nei = ops_cl.gather_neighbour(f_agg, neigh_idx)
+        return self.att_pooling_2(torch.cat([f_nei, f_xyz], dim=1))
 
 
 class DilatedResBlock(nn.Module):
@@ -192,19 +192,88 @@ def res_layer(cin, cout, blocks, stride):
     return nn.Sequential(*layers)
 
 
+def _psp_operators(h, w, sizes, device):
+    """Constant operators of the pyramid pooling module on an h x w map, as matrices over the pixel rows:
+         ind  [nbins, h*w]  0/1 membership of every adaptive-average-pool bin (ATen: rows floor(i*h/s) .. ceil((i+1)*h/s)),
+         inv  [nbins]       1 / bin area,
+         up   [h*w, nbins]  bilinear (align_corners = False) up-sampling weights from the s x s grids back to h x w -- taken from
+                            F.interpolate itself on the s*s unit maps, so they are ATen's weights by construction;
+       bins of sizes[0] first, row-major (the packing of ops_pm.psp_pool)."""
+    key = (h, w, tuple(sizes), str(device))
+    hit = _psp_operators.cache.get(key)
+    if hit is not None:
+        return hit
+    ind, inv, up = [], [], []
+    for s in sizes:
+        for i in range(s):
+            y0, y1 = (i * h) // s, -((-(i + 1) * h) // s)
+            for j in range(s):
+                x0, x1 = (j * w) // s, -((-(j + 1) * w) // s)
+                m = torch.zeros(h, w)
+                m[y0:y1, x0:x1] = 1.0
+                ind.append(m.reshape(-1))
+                inv.append(1.0 / ((y1 - y0) * (x1 - x0)))
+        unit = torch.eye(s * s).view(s * s, 1, s, s)
+        up.append(F.interpolate(unit, size=(h, w), mode="bilinear", align_corners=False).reshape(s * s, h * w).t())
+    out = (torch.stack(ind).to(device), torch.tensor(inv, device=device), torch.cat(up, dim=1).contiguous().to(device))
+    _psp_operators.cache[key] = out
+    return out
+
+
+_psp_operators.cache = {}
+
+
 class PyramidPooling(nn.Module):
     """pspnet.py:7-31."""
 
     def __init__(self, ch=512, out_ch=1024, sizes=(1, 2, 3, 6)):
         super().__init__()
+        self.sizes = tuple(sizes)
         self.stages = nn.ModuleList(
             nn.Sequential(nn.AdaptiveAvgPool2d((s, s)), nn.Conv2d(ch, ch, 1, bias=False)) for s in sizes)
         self.bottleneck = nn.Conv2d(ch * (len(sizes) + 1), out_ch, 1)
 
     def forward(self, x):
+        if x.is_cuda and os.environ.get("FFB6D_PSP_TRAIN_FOLD", "1") != "0":
+            return self.forward_folded(x)
         h, w = x.shape[2:]
         pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]
         return F.relu_(self.bottleneck(torch.cat(pri + [x], 1)))
+
+    def forward_folded(self, x):
+        """The same module with the linear steps reordered (training path on the GPU; autograd through plain matrix products):
+        pooling, the stage convolution, the up-sampling and the bottleneck convolution are all linear, and a 1x1 convolution
+        commutes with the up-sampling, so
+            bottleneck(cat(up(conv_i(pool_i x)), x)) = sum_i up( pool_i(x) (Wb_i Wc_i)^T ) + x Wb_x^T + b.
+        The 2560-channel concatenation and 4/5 of the bottleneck GEMM disappear; the four adaptive pools become one product with
+        the 0/1 bin-membership matrix (exact in bf16; the 1/area scaling is done in fp32 on the 50 bins) and the four up-samplings
+        one product with the bilinear weight matrix, accumulated onto the x term (baddbmm).  Under autocast that matrix is split
+        into two bf16 terms (hi + lo: weights exact to 2^-17) so that the interpolation weights still sum to one."""
+        B, C, h, w = x.shape
+        ind, inv, up = _psp_operators(h, w, self.sizes, x.device)
+        n_s = len(self.sizes)
+        wb = self.bottleneck.weight.view(self.bottleneck.out_channels, -1)                 # [out, (n_s + 1) C]
+        y = F.conv2d(x, wb[:, n_s * C:].reshape(-1, C, 1, 1), self.bottleneck.bias)        # x term (+ bias), autocast dtype
+        dt = y.dtype
+        yr = y.permute(0, 2, 3, 1).reshape(B, h * w, -1)                                    # pixel rows; no copy when channels-last
+        xr = x.permute(0, 2, 3, 1).reshape(B, h * w, C)
+        with torch.autocast("cuda", enabled=False):
+            sums = torch.bmm(ind.to(xr.dtype).unsqueeze(0).expand(B, -1, -1), xr)           # [B, nbins, C] bin sums
+            pooled = sums.float() * inv.view(1, -1, 1)
+            z, off = [], 0
+            for i, s in enumerate(self.sizes):
+                w_eff = wb[:, i * C:(i + 1) * C].float() @ self.stages[i][1].weight.view(C, C).float()   # [out, C]
+                z.append(pooled[:, off:off + s * s] @ w_eff.t())
+                off += s * s
+            z = torch.cat(z, dim=1)                                                         # [B, nbins, out] fp32
+            if dt == torch.float32:
+                out = torch.baddbmm(yr, up.unsqueeze(0).expand(B, -1, -1), z)
+            else:
+                hi = up.to(dt)
+                lo = (up - hi.float()).to(dt)
+                zt = z.to(dt)
+                out = torch.baddbmm(yr, torch.cat([hi, lo], dim=1).unsqueeze(0).expand(B, -1, -1), torch.cat([zt, zt], dim=1))
+        return F.relu_(out).view(B, h, w, -1).permute(0, 3, 1, 2)
 
 
 class UpBlock(nn.Module):
@@ -321,16 +390,16 @@ class FFB6D(nn.Module):
     def _fuse(self, i, pre_p2r, fuse_p2r, pre_r2p, fuse_r2p, rgb_emb0, p_emb0, p2r_idx, r2p_idx):
         """One bidirectional fusion step (ffb6d.py:245-263 / 281-298); both directions read
         the pre-fusion tensors, so they are independent."""
-        bs, c, hr, wr = rgb_emb0.shape
-        p2r = ops.nearest_interpolation(pre_p2r[i](p_emb0), p2r_idx).view(bs, -1, hr, wr)
+        hr, wr = rgb_emb0.shape[2:]
+        p2r = ops_cl.nearest_interpolation(pre_p2r[i](p_emb0), p2r_idx, (hr, wr))
         rgb_emb = fuse_p2r[i](torch.cat((rgb_emb0, p2r), dim=1))
-        r2p = ops.random_sample(rgb_emb0.reshape(bs, c, hr * wr), r2p_idx)
+        r2p = ops_cl.random_sample(rgb_emb0, r2p_idx)
         p_emb = fuse_r2p[i](torch.cat((p_emb0, pre_r2p[i](r2p)), dim=1))
         return rgb_emb, p_emb
 
     def _decode(self, stage, skip, p_emb, interp_idx):
         """RandLA decoder step conv(cat(skip, interp(p))) (ffb6d.py:273-279,302-307)."""
-        return stage(torch.cat([skip, ops.nearest_interpolation(p_emb, interp_idx)], dim=1))
+        return stage(torch.cat([skip, ops_cl.nearest_interpolation(p_emb, interp_idx)], dim=1))
 
     # Fused inference (forward_pm.forward): the point branch on a second HIP stream under the colour branch's convolutions,
     # the index pyramid on a third; two_streams = False keeps everything on the caller's stream (bit-identical results).
@@ -401,7 +470,7 @@ class FFB6D(nn.Module):
                                                           inputs['dpt_xyz'], index_dtype=self.index_dtype))
         if fused and forward_pm.supported(self):
             return forward_pm.forward(self, inputs, end_points, two_streams=self.two_streams, taps=taps)
-        # stock modules + the neighbour operators (training; or widths the row kernels do not cover)
+        # stock modules + the neighbour operators on channels-last rows (training; or widths the fused kernels do not cover)
         rgb_emb = self.cnn_pre_stages(inputs['rgb'])
         p_emb = self.rndla_pre_stages(inputs['cld_rgb_nrm']).unsqueeze(3)
 
@@ -409,7 +478,7 @@ class FFB6D(nn.Module):
         for i in range(4):
             rgb_emb0 = self.cnn_ds_stages[i](rgb_emb)
             f_enc = self.rndla_ds_stages[i](p_emb, inputs['cld_xyz%d' % i], inputs['cld_nei_idx%d' % i])
-            p_emb0 = ops.random_sample(f_enc, inputs['cld_sub_idx%d' % i])
+            p_emb0 = ops_cl.random_sample(f_enc, inputs['cld_sub_idx%d' % i])
             if i == 0:
                 ds_emb.append(f_enc)
             rgb_emb, p_emb = self._fuse(
@@ -433,7 +502,7 @@ class FFB6D(nn.Module):
                              inputs['cld_interp_idx0']).squeeze(-1)
 
         bs = rgb_emb.shape[0]
-        rgb_emb_c = ops.choose_gather(rgb_emb, inputs['choose'])
+        rgb_emb_c = ops_cl.choose_gather(rgb_emb, inputs['choose'])
 
         def head(seq):
             return seq(torch.cat([rgb_emb_c, p_emb], dim=1))

@@ -1,0 +1,217 @@
+"""The neighbour operators of the TRAINING step on channels-last tensors (autograd-capable, float32 or bfloat16).
+
+Same operators and signatures as ffb6d_amd.ops (= the reference's: FFB6D.random_sample / nearest_interpolation ffb6d.py:159-194,
+Building_block.gather_neighbour / relative_pos_encoding RandLANet.py:216-234, the softmax-pool of Att_pooling.forward
+RandLANet.py:245-248), but every [B,C,...] tensor they take or return is read and written as ROWS of C contiguous channels --
+torch's channels_last memory of a [B,C,N,K] tensor, which is what MIOpen's NHWC convolutions produce and consume -- in the
+activation dtype (bf16 under torch.autocast).  A training step built from them has no transposing copy and no bf16 <-> fp32 cast
+between a convolution and a neighbour operator (round 3's profile: 15 + 5 ms of an 82 ms step).
+
+Forward gathers and the max-pool are the inference kernels (csrc/ops_pm.hip); the backward bodies are csrc/train_rows.hip.
+Tensors of other layouts are accepted (one copy into rows); channel counts that are not a multiple of the 16-byte unit
+(4 float32 / 8 bfloat16) fall back to the channel-major operators of ffb6d_amd.ops."""
+import torch
+
+from . import _lib, ops, ops_pm
+
+_need_gpu = ops._need_gpu
+_stream = ops._stream
+_idx = ops._idx
+
+
+def _act(t):
+    """float32 / bfloat16 as they are; float16 (an fp16 autocast) is computed in float32"""
+    return t.float() if t.dtype == torch.float16 else t
+
+
+def _vl(t):
+    return 8 if t.dtype == torch.bfloat16 else 4
+
+
+def _dt(t):
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"float32 or bfloat16 rows expected, got {t.dtype}")
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def to_rows(x):
+    """[B,C,*S] -> [B, prod(S), C] contiguous: a view when x is channels_last (or [B,C,N,1] written by a channels_last
+    convolution), one transposing copy otherwise."""
+    B, C = x.shape[:2]
+    r = x.reshape(B, C, -1).transpose(1, 2)
+    return r if r.is_contiguous() else r.contiguous()
+
+
+def from_rows(r, spatial):
+    """[B,M,C] contiguous rows -> [B,C,*spatial] view with channels_last strides"""
+    B, M, C = r.shape
+    return r.transpose(1, 2).reshape(B, C, *spatial)
+
+
+def _rows_ld(x):
+    """rows of a [B,C,*S] tensor WITHOUT copying channel slices of a channels_last tensor (the gradient of one half of a
+    torch.cat): returns ([B,M,C] tensor, row stride in elements)."""
+    B, C = x.shape[:2]
+    r = x.reshape(B, C, -1).transpose(1, 2)
+    M = r.shape[1]
+    ld = r.stride(1) if M > 1 else C
+    regular = r.stride(2) == 1 and ld >= C and (B == 1 or r.stride(0) == M * ld) and ld % _vl(x) == 0 and r.data_ptr() % 16 == 0 \
+        and (M > 1 or r.is_contiguous())
+    if not regular:
+        r = r.contiguous()
+        ld = C
+    return r, ld
+
+
+def _covers(*ts):
+    """the row kernels cover these tensors' channel counts (axis 1)"""
+    return all(t.shape[1] % _vl(t) == 0 for t in ts)
+
+
+class _GatherRows(torch.autograd.Function):
+    """rows [B,M,C], idx [B,U] -> [B,U,C]; backward = fp32 scatter-add, rounded once to the activation dtype"""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, rows, idx):
+        ctx.save_for_backward(idx)
+        ctx.m = rows.shape[1]
+        return ops_pm.gather_rows(rows, idx)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, U, C = g.shape
+        g = _act(g)
+        gr, ld = _rows_ld(g.transpose(1, 2))
+        i, bits = _idx(idx)
+        acc = torch.zeros((B, ctx.m, C), dtype=torch.float32, device=g.device)
+        nbytes = g.element_size() * B * U * C + (bits // 8) * B * U + 8 * B * ctx.m * C
+        with torch.cuda.device(g.device), _lib.traced("scatter_add_rows", nbytes, (C, ctx.m, U)):
+            rc = _lib.load().ffb6d_scatter_add_rows(_dt(gr), gr.data_ptr(), ld, i.data_ptr(), bits, acc.data_ptr(), B, ctx.m, C, U,
+                                                    _stream(g))
+        _lib.check(rc, "ffb6d_scatter_add_rows")
+        return acc.to(g.dtype), None
+
+
+class _RandomSampleRows(torch.autograd.Function):
+    """rows [B,M,C], pool_idx [B,Np,K] -> [B,Np,C] (max over the K gathered rows)"""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, rows, pool_idx):
+        ctx.save_for_backward(rows, pool_idx)
+        return ops_pm.random_sample(rows, pool_idx)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        rows, pool_idx = ctx.saved_tensors
+        B, M, C = rows.shape
+        Np, K = pool_idx.shape[1], pool_idx.shape[2]
+        g = _act(g)
+        if g.dtype != rows.dtype:
+            g = g.to(rows.dtype)
+        gr, ld = _rows_ld(g.transpose(1, 2))
+        i, bits = _idx(pool_idx)
+        acc = torch.zeros((B, M, C), dtype=torch.float32, device=g.device)
+        nbytes = rows.element_size() * B * C * (Np * K + Np) + (bits // 8) * B * Np * K + 8 * B * M * C
+        with torch.cuda.device(g.device), _lib.traced("random_sample_rows_bwd", nbytes, (C, M, Np)):
+            rc = _lib.load().ffb6d_random_sample_rows_bwd(_dt(rows), rows.data_ptr(), i.data_ptr(), bits, gr.data_ptr(), ld,
+                                                          acc.data_ptr(), B, M, C, Np, K, _stream(g))
+        _lib.check(rc, "ffb6d_random_sample_rows_bwd")
+        return acc.to(rows.dtype), None
+
+
+class _AttPoolRows(torch.autograd.Function):
+    """feat, scores: [B,C,N,K] (rows (n,k) of C channels); -> [B,N,C] rows"""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, feat, scores):
+        B, C, N, K = feat.shape
+        fr, ldf = _rows_ld(feat)
+        sr, lds = _rows_ld(scores)
+        out = torch.empty((B, N, C), dtype=feat.dtype, device=feat.device)
+        nbytes = feat.element_size() * B * C * N * (2 * K + 1)
+        with torch.cuda.device(feat.device), _lib.traced("att_pool_rows", nbytes, (C, N)):
+            rc = _lib.load().ffb6d_att_pool_rows(_dt(feat), fr.data_ptr(), ldf, sr.data_ptr(), lds, out.data_ptr(), B * N, K, C,
+                                                 _stream(feat))
+        _lib.check(rc, "ffb6d_att_pool_rows")
+        ctx.save_for_backward(fr, sr)
+        ctx.meta = (B, C, N, K, ldf, lds)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        fr, sr = ctx.saved_tensors
+        B, C, N, K, ldf, lds = ctx.meta
+        g = _act(g)
+        if g.dtype != fr.dtype:
+            g = g.to(fr.dtype)
+        gr, ldg = _rows_ld(g.transpose(1, 2))
+        gf = torch.empty((B, N * K, C), dtype=fr.dtype, device=g.device)
+        gs = torch.empty((B, N * K, C), dtype=fr.dtype, device=g.device)
+        nbytes = fr.element_size() * B * C * N * (4 * K + 1)
+        with torch.cuda.device(g.device), _lib.traced("att_pool_rows_bwd", nbytes, (C, N)):
+            rc = _lib.load().ffb6d_att_pool_rows_bwd(_dt(fr), gr.data_ptr(), ldg, fr.data_ptr(), ldf, sr.data_ptr(), lds, gf.data_ptr(),
+                                                     gs.data_ptr(), B * N, K, C, _stream(g))
+        _lib.check(rc, "ffb6d_att_pool_rows_bwd")
+        return from_rows(gf, (N, K)), from_rows(gs, (N, K))
+
+
+def nearest_interpolation(feature, interp_idx, spatial=None):
+    """FFB6D.nearest_interpolation (ffb6d.py:179-194): feature [B,C,M,1] (or any [B,C,*S]), interp_idx [B,U,1] -> [B,C,U,1]
+    (or [B,C,*spatial] with prod(spatial) == U: the point -> pixel fusion reshapes to the map right away)."""
+    _need_gpu(feature, interp_idx)
+    feature = _act(feature)
+    B = feature.shape[0]
+    idx = interp_idx.reshape(B, -1)
+    spatial = (idx.shape[1], 1) if spatial is None else tuple(spatial)
+    if not _covers(feature):
+        return ops.nearest_interpolation(feature.reshape(B, feature.shape[1], -1), idx.unsqueeze(2)).reshape(B, -1, *spatial)
+    return from_rows(_GatherRows.apply(to_rows(feature), idx), spatial)
+
+
+def gather_neighbour(feature, neigh_idx):
+    """Building_block.gather_neighbour (RandLANet.py:225-234) on a [B,C,N,1] map: -> [B,C,N,K], rows (n,k) of C channels."""
+    B, N, K = neigh_idx.shape
+    return nearest_interpolation(feature, neigh_idx.reshape(B, N * K, 1), (N, K))
+
+
+def choose_gather(rgb_emb, choose):
+    """the per-point pixel pick of ffb6d.py:309-312: rgb_emb [B,C,H,W], choose [B,1,N] -> [B,C,N]"""
+    return nearest_interpolation(rgb_emb, choose.reshape(choose.shape[0], -1, 1)).squeeze(3)
+
+
+def random_sample(feature, pool_idx):
+    """FFB6D.random_sample (ffb6d.py:159-177): feature [B,C,M,1] / [B,C,H,W] / [B,C,M], pool_idx [B,N',K] -> [B,C,N',1]"""
+    _need_gpu(feature, pool_idx)
+    feature = _act(feature)
+    if not _covers(feature):
+        return ops.random_sample(feature.reshape(feature.shape[0], feature.shape[1], -1), pool_idx)
+    return from_rows(_RandomSampleRows.apply(to_rows(feature), pool_idx), (pool_idx.shape[1], 1))
+
+
+def att_pool(feature_set, att_activation):
+    """sum_K(feature_set * softmax_K(att_activation)) (RandLANet.py:245-248): both [B,C,N,K] -> [B,C,N,1]"""
+    _need_gpu(feature_set, att_activation)
+    if feature_set.shape != att_activation.shape or feature_set.dim() != 4:
+        raise ValueError(f"bad shapes {tuple(feature_set.shape)} / {tuple(att_activation.shape)}")
+    f, a = _act(feature_set), _act(att_activation)
+    if f.dtype != a.dtype:
+        dt = torch.promote_types(f.dtype, a.dtype)
+        f, a = f.to(dt), a.to(dt)
+    if not _covers(f):
+        return ops.att_pool(f, a)
+    return from_rows(_AttPoolRows.apply(f, a), (f.shape[2], 1))
+
+
+def relative_pos_encoding(xyz, neigh_idx, dtype=torch.float32):
+    """relative_pos_encoding (RandLANet.py:216-223), no gradient (xyz is an input): xyz [B,N,3], neigh_idx [B,N,K] ->
+    [B,16,N,K] in channels_last memory: channels [dis, p-q, p, q] + 6 zero channels (the rows are 16 wide so that they stay
+    16-byte units; multiply with the 10-column weight padded by 6 zero columns -- padded_mlp1_weight)."""
+    enc = ops_pm.relative_pos_encoding(xyz, neigh_idx, dtype=dtype)                    # [B,N,K,16]
+    return enc.permute(0, 3, 1, 2)

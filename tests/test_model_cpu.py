@@ -199,3 +199,37 @@ def test_upconv_folded_without_conv_bias_and_with_per_channel_prelu():
     ub.conv[3] = torch.nn.PReLU(4)
     with pytest.raises(NotImplementedError):
         forward_pm.upconv_folded(ub)
+
+
+@pytest.mark.parametrize("h,w", [(15, 20), (7, 9), (60, 80)])
+def test_pyramid_pooling_training_fold_is_the_same_module(h, w):
+    """model.PyramidPooling.forward_folded (the training path on the GPU) against the module as upstream writes it (pspnet.py:7-31):
+    the constant operators are ATen's own pooling bins / bilinear weights, the output and every gradient agree in fp32."""
+    F = torch.nn.functional
+    torch.manual_seed(h * w)
+    sizes = (1, 2, 3, 6)
+    ind, inv, up = M._psp_operators(h, w, sizes, torch.device("cpu"))
+    probe = torch.randn(2, 3, h, w)
+    rows = probe.permute(0, 2, 3, 1).reshape(2, h * w, 3)
+    off = 0
+    for s in sizes:
+        want = F.adaptive_avg_pool2d(probe, s).permute(0, 2, 3, 1).reshape(2, s * s, 3)
+        got = (ind[off:off + s * s] @ rows) * inv[off:off + s * s].view(1, -1, 1)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+        grid = torch.randn(2, 3, s, s)
+        want = F.interpolate(grid, size=(h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).reshape(2, h * w, 3)
+        got = up[:, off:off + s * s] @ grid.permute(0, 2, 3, 1).reshape(2, s * s, 3)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+        off += s * s
+    pp = M.PyramidPooling(16, 24, sizes)
+    outs = []
+    for folded in (False, True):
+        pp.zero_grad()
+        x = torch.randn(2, 16, h, w, generator=torch.Generator().manual_seed(3)).contiguous(memory_format=torch.channels_last)
+        x.requires_grad_(True)
+        y = pp.forward_folded(x) if folded else pp(x)
+        r = torch.linspace(-1, 1, y.numel()).view(2, h, w, -1).permute(0, 3, 1, 2)
+        (y * r).sum().backward()
+        outs.append([y.detach(), x.grad] + [p.grad.clone() for p in pp.parameters()])
+    for a, b in zip(*outs):
+        torch.testing.assert_close(b, a, rtol=1e-4, atol=1e-5 * float(a.abs().max()) + 1e-6)

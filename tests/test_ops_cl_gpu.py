@@ -1,0 +1,149 @@
+"""Channels-last training operators (ffb6d_amd/ops_cl.py, csrc/train_rows.hip) against plain torch on the reference's own
+formulas (ffb6d.py:159-194, RandLANet.py:216-250): forward values and the gradients autograd derives for the torch formulas.
+float32: 1e-5 of range (float atomics reorder sums); bfloat16 rows: one bf16 rounding of the result (2^-8 relative)."""
+import pytest
+import torch
+
+from ffb6d_amd import ops_cl
+
+pytestmark = pytest.mark.gpu
+
+DTS = [torch.float32, torch.bfloat16]
+
+
+def cl(x):
+    """a [B,C,N,K] tensor in channels_last memory (what a channels_last convolution writes)"""
+    return x.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else x
+
+
+def close(got, want, dt, what):
+    scale = float(want.abs().max()) + 1e-12
+    err = float((got.float() - want.float()).abs().max()) / scale
+    assert err <= (1e-5 if dt == torch.float32 else 1.2e-2), (what, err)
+
+
+def ref_gather(feature, idx):                     # ffb6d.py:179-194 on [B,C,M,1], idx [B,U]
+    B, C = feature.shape[:2]
+    return torch.gather(feature.reshape(B, C, -1), 2, idx.unsqueeze(1).expand(-1, C, -1).long())
+
+
+def ref_random_sample(feature, pool_idx):         # ffb6d.py:159-177
+    B, C = feature.shape[:2]
+    Np, K = pool_idx.shape[1:]
+    g = torch.gather(feature.reshape(B, C, -1), 2, pool_idx.reshape(B, 1, Np * K).expand(-1, C, -1).long())
+    return g.reshape(B, C, Np, K).max(dim=3, keepdim=True)[0]
+
+
+def ref_att_pool(feat, scores):                   # RandLANet.py:245-248
+    return (feat * torch.softmax(scores, dim=3)).sum(dim=3, keepdim=True)
+
+
+def grads(fn, *xs):
+    xs = [x.detach().clone().requires_grad_(True) for x in xs]
+    y = fn(*xs)
+    r = torch.linspace(-1.0, 1.0, y.numel(), device=y.device).reshape(y.shape)
+    (y.float() * r).sum().backward()
+    return [y.detach()] + [x.grad for x in xs]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,C,M,U,idt", [(2, 16, 50, 400, torch.int64), (3, 72, 17, 90, torch.int32), (1, 8, 300, 300, torch.int64)])
+def test_nearest_interpolation_rows(device, dt, B, C, M, U, idt):
+    g = torch.Generator().manual_seed(M * U + C)
+    feat = cl(torch.randn(B, C, M, 1, generator=g)).to(device).to(dt)
+    idx = torch.randint(0, M, (B, U, 1), generator=g, dtype=idt).to(device)
+    got = grads(lambda f: ops_cl.nearest_interpolation(f, idx), feat)
+    want = grads(lambda f: ref_gather(f, idx.reshape(B, U)).unsqueeze(3), feat.float())
+    assert got[0].shape == (B, C, U, 1) and got[0].dtype == dt and got[1].dtype == dt
+    assert torch.equal(got[0].float(), want[0])                      # a gather moves bits
+    close(got[1], want[1], dt, "grad")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gather_neighbour_rows_and_the_gradient_of_a_cat_half(device, dt):
+    """[B,C,N,K] output in channels_last memory; the gradient arrives as a channel slice of the concatenation's gradient (row
+    stride = both halves) and is consumed without a copy"""
+    B, C, N, K = 2, 16, 77, 16
+    g = torch.Generator().manual_seed(5)
+    feat = cl(torch.randn(B, C, N, 1, generator=g)).to(device).to(dt)
+    other = cl(torch.randn(B, 24, N, K, generator=g)).to(device).to(dt)
+    idx = torch.randint(0, N, (B, N, K), generator=g).to(device)
+    out = ops_cl.gather_neighbour(feat, idx)
+    assert out.shape == (B, C, N, K) and out.is_contiguous(memory_format=torch.channels_last)
+    got = grads(lambda f: torch.cat([ops_cl.gather_neighbour(f, idx), other], dim=1), feat)
+    want = grads(lambda f: torch.cat([ref_gather(f, idx.reshape(B, N * K)).reshape(B, C, N, K), other.float()], dim=1), feat.float())
+    assert torch.equal(got[0].float(), want[0])
+    close(got[1], want[1], dt, "grad")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,C,M,Np,K", [(2, 16, 200, 50, 16), (1, 64, 48, 12, 16), (2, 8, 30, 30, 5)])
+def test_random_sample_rows(device, dt, B, C, M, Np, K):
+    g = torch.Generator().manual_seed(M + Np)
+    feat = cl(torch.randn(B, C, M, 1, generator=g)).to(device).to(dt)
+    idx = torch.randint(0, M, (B, Np, K), generator=g).to(device)
+    got = grads(lambda f: ops_cl.random_sample(f, idx), feat)
+    want = grads(lambda f: ref_random_sample(f, idx), feat.float())
+    assert got[0].shape == (B, C, Np, 1)
+    assert torch.equal(got[0].float(), want[0])
+    close(got[1], want[1], dt, "grad")          # ties (duplicate indices in a neighbourhood) share one source row: same sum
+    # a pixel map as the source (r2p fusion): [B,C,H,W] channels_last, no reshape copy
+    fmap = cl(torch.randn(B, C, 6, M // 6 + 1, generator=g)).to(device).to(dt)
+    idx2 = torch.randint(0, fmap.shape[2] * fmap.shape[3], (B, Np, K), generator=g).to(device)
+    assert torch.equal(ops_cl.random_sample(fmap, idx2).float(), ref_random_sample(fmap.float(), idx2))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,C,N,K", [(2, 32, 100, 16), (1, 256, 12, 16), (2, 8, 33, 7), (1, 16, 5, 1)])
+def test_att_pool_rows(device, dt, B, C, N, K):
+    g = torch.Generator().manual_seed(C + N)
+    feat = cl(torch.randn(B, C, N, K, generator=g)).to(device).to(dt)
+    sc = cl(3 * torch.randn(B, C, N, K, generator=g)).to(device).to(dt)
+    got = grads(ops_cl.att_pool, feat, sc)
+    want = grads(ref_att_pool, feat.float(), sc.float())
+    assert got[0].shape == (B, C, N, 1) and got[0].dtype == dt
+    for a, b, what in zip(got, want, ("out", "grad_feat", "grad_scores")):
+        close(a, b, dt, what)
+
+
+def test_encoding_rows_are_the_reference_channels_plus_zero_padding(device):
+    from ffb6d_amd import ops
+    g = torch.Generator().manual_seed(12)
+    xyz = (torch.rand(2, 300, 3, generator=g) * 2 - 1).to(device)
+    idx = torch.randint(0, 300, (2, 300, 16), generator=g).to(device)
+    enc = ops_cl.relative_pos_encoding(xyz, idx)
+    assert enc.shape == (2, 16, 300, 16) and enc.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(enc[:, :10], ops.relative_pos_encoding_cm(xyz, idx)) and not enc[:, 10:].any()
+
+
+def test_odd_channel_counts_fall_back_to_the_channel_major_operators(device):
+    g = torch.Generator().manual_seed(1)
+    feat = torch.randn(2, 6, 40, 1, generator=g).to(device)
+    idx = torch.randint(0, 40, (2, 25, 1), generator=g).to(device)
+    assert torch.equal(ops_cl.nearest_interpolation(feat, idx), ref_gather(feat, idx.reshape(2, 25)).unsqueeze(3))
+    pool = torch.randint(0, 40, (2, 10, 4), generator=g).to(device)
+    assert torch.equal(ops_cl.random_sample(feat, pool), ref_random_sample(feat, pool))
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_pyramid_pooling_training_fold_on_the_device(device, autocast, monkeypatch):
+    """model.PyramidPooling: the folded training forward (bin-membership product, per-bin GEMMs, bilinear-weight product added
+    onto the x term) against the module as upstream writes it (pspnet.py:7-31) -- channels_last input, fp32 and under
+    torch.autocast(bfloat16) (the hi + lo split of the interpolation weights): output and parameter gradients."""
+    from ffb6d_amd import model as M
+    torch.manual_seed(3)
+    pp = M.PyramidPooling(64, 96).to(device).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 64, 15, 20, device=device).relu_().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fold in ("0", "1"):
+        monkeypatch.setenv("FFB6D_PSP_TRAIN_FOLD", fold)
+        pp.zero_grad()
+        xs = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            y = pp(xs)
+        r = torch.linspace(-1.0, 1.0, y.numel(), device=device).reshape(2, 15, 20, -1).permute(0, 3, 1, 2)
+        (y.float() * r).sum().backward()
+        outs.append([y.detach().float(), xs.grad] + [p.grad.clone() for p in pp.parameters()])
+    bar = 3e-2 if autocast else 1e-4
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= bar * float(a.abs().max()) + 1e-6
