@@ -61,7 +61,7 @@ SIGNATURES = {
     "ffb6d_bilinear_bwd_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "ffb6d_prelu_fwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp]),
     "ffb6d_prelu_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "ffb6d_scatter_add_rows": (_i32, [_i32, _vp, _i64, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "ffb6d_gather_sum_rows": (_i32, [_i32, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp]),
     "ffb6d_random_sample_rows_bwd": (_i32, [_i32, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_att_pool_rows": (_i32, [_i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _vp]),
     "ffb6d_att_pool_rows_bwd": (_i32, [_i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _vp]),

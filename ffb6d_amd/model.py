@@ -138,10 +138,11 @@ class BuildingBlock(nn.Module):
         # written by one kernel each -- none of the reference's permutes / contiguous copies, forward or backward (ops_cl)
         enc = ops_cl.relative_pos_encoding(xyz, neigh_idx, dtype=_activation_dtype(feature))      # [B,16,N,K]: 10 channels + 6 zeros
         f_xyz = self.mlp1(enc, pad_k=6)
-        f_nei = ops_cl.gather_neighbour(feature, neigh_idx)
+        plan = ops_cl.neighbour_plan(neigh_idx)          # both gathers read through the same indices: one inverse for their backward
+        f_nei = ops_cl.gather_neighbour(feature, neigh_idx, plan)
         f_agg = self.att_pooling_1(torch.cat([f_nei, f_xyz], dim=1))
         f_xyz = self.mlp2(f_xyz)
-        f_nei = ops_cl.gather_neighbour(f_agg, neigh_idx)
+        f_nei = ops_cl.gather_neighbour(f_agg, neigh_idx, plan)
         return self.att_pooling_2(torch.cat([f_nei, f_xyz], dim=1))
 
 
@@ -257,7 +258,7 @@ class PyramidPooling(nn.Module):
         dt = y.dtype
         yr = y.permute(0, 2, 3, 1).reshape(B, h * w, -1)                                    # pixel rows; no copy when channels-last
         xr = x.permute(0, 2, 3, 1).reshape(B, h * w, C)
-        with torch.autocast("cuda", enabled=False):
+        with torch.autocast(x.device.type, enabled=False):
             sums = torch.bmm(ind.to(xr.dtype).unsqueeze(0).expand(B, -1, -1), xr)           # [B, nbins, C] bin sums
             pooled = sums.float() * inv.view(1, -1, 1)
             z, off = [], 0

@@ -298,7 +298,10 @@ class _UpsampleAlign(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, size):
         ctx.in_shape = tuple(x.shape)
-        return torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=True)
+        # autocast lists the up-sampling kernels as float32 operators (a bf16 map would be cast up, interpolated and handed to the
+        # next convolution's cast down: three passes over the largest maps of the decoder); here it stays in the map's own dtype
+        with torch.autocast("cuda", enabled=False):
+            return torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=True)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")

@@ -68,31 +68,55 @@ def _covers(*ts):
     return all(t.shape[1] % _vl(t) == 0 for t in ts)
 
 
+class GatherPlan:
+    """The index tensor of a row gather, idx [B,U] into M source rows per frame, and -- built on the first backward, shared by
+    every gather through the same indices (the two neighbour gathers of a Building_block) -- its inverse as CSR lists: `order` =
+    the gather's flat output rows sorted by the source row they read, `start[r] .. start[r+1]` = the slice of `order` that reads
+    source row r.  One radix sort + one searchsorted (torch / rocprim); lives as long as the autograd graph of one step."""
+
+    def __init__(self, idx, m):
+        self.idx, self.m = idx, int(m)
+        self._csr = None
+
+    def csr(self):
+        if self._csr is None:
+            B, U = self.idx.shape
+            R = B * self.m
+            kd = torch.int32 if R < 2 ** 31 - 1 else torch.int64
+            key = self.idx.to(kd)
+            if B > 1:
+                key = key + (torch.arange(B, device=key.device, dtype=kd) * self.m).unsqueeze(1)
+            skey, order = torch.sort(key.reshape(-1), stable=True)
+            start = torch.searchsorted(skey, torch.arange(R + 1, device=key.device, dtype=kd))
+            self._csr = (order, start)
+        return self._csr
+
+
 class _GatherRows(torch.autograd.Function):
-    """rows [B,M,C], idx [B,U] -> [B,U,C]; backward = fp32 scatter-add, rounded once to the activation dtype"""
+    """rows [B,M,C], plan.idx [B,U] -> [B,U,C]; backward: every source row sums the output rows that read it (fp32), stored once
+    in the activation dtype"""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, rows, idx):
-        ctx.save_for_backward(idx)
-        ctx.m = rows.shape[1]
-        return ops_pm.gather_rows(rows, idx)
+    def forward(ctx, rows, plan):
+        ctx.plan = plan
+        return ops_pm.gather_rows(rows, plan.idx)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        (idx,) = ctx.saved_tensors
+        plan = ctx.plan
         B, U, C = g.shape
         g = _act(g)
         gr, ld = _rows_ld(g.transpose(1, 2))
-        i, bits = _idx(idx)
-        acc = torch.zeros((B, ctx.m, C), dtype=torch.float32, device=g.device)
-        nbytes = g.element_size() * B * U * C + (bits // 8) * B * U + 8 * B * ctx.m * C
-        with torch.cuda.device(g.device), _lib.traced("scatter_add_rows", nbytes, (C, ctx.m, U)):
-            rc = _lib.load().ffb6d_scatter_add_rows(_dt(gr), gr.data_ptr(), ld, i.data_ptr(), bits, acc.data_ptr(), B, ctx.m, C, U,
-                                                    _stream(g))
-        _lib.check(rc, "ffb6d_scatter_add_rows")
-        return acc.to(g.dtype), None
+        order, start = plan.csr()
+        out = torch.empty((B, plan.m, C), dtype=g.dtype, device=g.device)
+        nbytes = g.element_size() * C * B * (U + plan.m) + 8 * B * (U + plan.m)
+        with torch.cuda.device(g.device), _lib.traced("gather_sum_rows", nbytes, (C, plan.m, U)):
+            rc = _lib.load().ffb6d_gather_sum_rows(_dt(gr), gr.data_ptr(), ld, order.data_ptr(), start.data_ptr(), out.data_ptr(),
+                                                   B * plan.m, C, _stream(g))
+        _lib.check(rc, "ffb6d_gather_sum_rows")
+        return out, None
 
 
 class _RandomSampleRows(torch.autograd.Function):
@@ -162,9 +186,10 @@ class _AttPoolRows(torch.autograd.Function):
         return from_rows(gf, (N, K)), from_rows(gs, (N, K))
 
 
-def nearest_interpolation(feature, interp_idx, spatial=None):
+def nearest_interpolation(feature, interp_idx, spatial=None, plan=None):
     """FFB6D.nearest_interpolation (ffb6d.py:179-194): feature [B,C,M,1] (or any [B,C,*S]), interp_idx [B,U,1] -> [B,C,U,1]
-    (or [B,C,*spatial] with prod(spatial) == U: the point -> pixel fusion reshapes to the map right away)."""
+    (or [B,C,*spatial] with prod(spatial) == U: the point -> pixel fusion reshapes to the map right away).
+    `plan`: a GatherPlan of the same indices to share their inverse with other gathers."""
     _need_gpu(feature, interp_idx)
     feature = _act(feature)
     B = feature.shape[0]
@@ -172,13 +197,24 @@ def nearest_interpolation(feature, interp_idx, spatial=None):
     spatial = (idx.shape[1], 1) if spatial is None else tuple(spatial)
     if not _covers(feature):
         return ops.nearest_interpolation(feature.reshape(B, feature.shape[1], -1), idx.unsqueeze(2)).reshape(B, -1, *spatial)
-    return from_rows(_GatherRows.apply(to_rows(feature), idx), spatial)
+    rows = to_rows(feature)
+    if plan is None:
+        plan = GatherPlan(idx, rows.shape[1])
+    elif plan.m != rows.shape[1] or plan.idx.shape != idx.shape:
+        raise ValueError("nearest_interpolation: the GatherPlan belongs to another index tensor")
+    return from_rows(_GatherRows.apply(rows, plan), spatial)
 
 
-def gather_neighbour(feature, neigh_idx):
+def neighbour_plan(neigh_idx):
+    """GatherPlan of a [B,N,K] neighbour index tensor (sources = the N points themselves)"""
+    B, N, K = neigh_idx.shape
+    return GatherPlan(neigh_idx.reshape(B, N * K), N)
+
+
+def gather_neighbour(feature, neigh_idx, plan=None):
     """Building_block.gather_neighbour (RandLANet.py:225-234) on a [B,C,N,1] map: -> [B,C,N,K], rows (n,k) of C channels."""
     B, N, K = neigh_idx.shape
-    return nearest_interpolation(feature, neigh_idx.reshape(B, N * K, 1), (N, K))
+    return nearest_interpolation(feature, neigh_idx.reshape(B, N * K, 1), (N, K), plan)
 
 
 def choose_gather(rgb_emb, choose):

@@ -228,14 +228,16 @@ int ffb6d_prelu_bwd(int dtype, const void* x, const void* grad_out, const float*
 /* Neighbour operators of the training step on rows (csrc/train_rows.hip): `dtype` rows as above, channel counts and row strides
  * (ld*, in elements) multiples of 4 (float32) / 8 (bfloat16); forward gathers and the max-pool are ffb6d_gather_rows_pm /
  * ffb6d_random_sample_pm.
- * ffb6d_scatter_add_rows: backward of a row gather (gather_neighbour RandLANet.py:225-234, nearest_interpolation ffb6d.py:179-194,
- *   the `choose` pick ffb6d.py:309-312): acc[b, idx[b,u], :] += g[b,u,:]; g [B*U rows, ldg], acc float32 [B,M,C], zeroed by the caller.
+ * ffb6d_gather_sum_rows: backward of a row gather (gather_neighbour RandLANet.py:225-234, nearest_interpolation ffb6d.py:179-194,
+ *   the `choose` pick ffb6d.py:309-312) with the index inverted by the caller: out[r,:] = sum_{j in [start[r], start[r+1])}
+ *   g[order[j],:]; g [rows, ldg], order = the gather's flat output rows sorted by their source row, start [R+1] (both int64),
+ *   out [R, C] of `dtype`.
  * ffb6d_random_sample_rows_bwd: backward of FFB6D.random_sample (ffb6d.py:159-177): acc[b, idx[b,n,k*], c] += g[b,n,c] with k* the
  *   first neighbour attaining the maximum of channel c (a NaN wins, as in torch.max); feat [B,M,C], idx [B,Np,K], g [B*Np rows, ldg].
  * ffb6d_att_pool_rows: out[p,:] = sum_k feat[p*K+k,:] * softmax_k(scores[p*K+k,:]) (Att_pooling.forward, RandLANet.py:245-248);
  *   feat / scores [P*K rows, ldf / lds], out [P, C].  _bwd: gfeat = g * s, gscores = g * s * (feat - out), both [P*K, C]. */
-int ffb6d_scatter_add_rows(int dtype, const void* g, int64_t ldg, const void* idx, int idx_bits, float* acc, int64_t B, int64_t M,
-                           int64_t C, int64_t U, ffb6d_stream_t stream);
+int ffb6d_gather_sum_rows(int dtype, const void* g, int64_t ldg, const int64_t* order, const int64_t* start, void* out, int64_t R,
+                          int64_t C, ffb6d_stream_t stream);
 int ffb6d_random_sample_rows_bwd(int dtype, const void* feat, const void* idx, int idx_bits, const void* g, int64_t ldg, float* acc,
                                  int64_t B, int64_t M, int64_t C, int64_t Np, int K, ffb6d_stream_t stream);
 int ffb6d_att_pool_rows(int dtype, const void* feat, int64_t ldf, const void* scores, int64_t lds, void* out, int64_t P, int K,

@@ -125,25 +125,33 @@ def test_odd_channel_counts_fall_back_to_the_channel_major_operators(device):
     assert torch.equal(ops_cl.random_sample(feat, pool), ref_random_sample(feat, pool))
 
 
-@pytest.mark.parametrize("autocast", [False, True])
-def test_pyramid_pooling_training_fold_on_the_device(device, autocast, monkeypatch):
+def test_pyramid_pooling_training_fold_on_the_device(device, monkeypatch):
     """model.PyramidPooling: the folded training forward (bin-membership product, per-bin GEMMs, bilinear-weight product added
-    onto the x term) against the module as upstream writes it (pspnet.py:7-31) -- channels_last input, fp32 and under
-    torch.autocast(bfloat16) (the hi + lo split of the interpolation weights): output and parameter gradients."""
+    onto the x term) against the module as upstream writes it (pspnet.py:7-31), channels_last input.  fp32: same output and
+    gradients (1e-4 of range).  Under torch.autocast(bfloat16) both formulations round in different places (and flip ReLU masks
+    where the output is ~0), so each is compared with the fp32 result: the fold may not be further away than 1.5x the upstream
+    formulation's own bf16 error + 5e-3 of range, per tensor (measured on CPU autocast: equal or smaller everywhere)."""
     from ffb6d_amd import model as M
     torch.manual_seed(3)
     pp = M.PyramidPooling(64, 96).to(device).to(memory_format=torch.channels_last)
     x = torch.randn(2, 64, 15, 20, device=device).relu_().contiguous(memory_format=torch.channels_last)
-    outs = []
-    for fold in ("0", "1"):
+    r = torch.rand(2, 15, 20, 96, generator=torch.Generator().manual_seed(1)).permute(0, 3, 1, 2).to(device)
+    dev_type = "cuda" if torch.cuda.is_available() else "cpu"           # --emulate: CPU tensors, CPU autocast
+
+    def run(fold, autocast):
         monkeypatch.setenv("FFB6D_PSP_TRAIN_FOLD", fold)
         pp.zero_grad()
         xs = x.clone().requires_grad_(True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=autocast):
             y = pp(xs)
-        r = torch.linspace(-1.0, 1.0, y.numel(), device=device).reshape(2, 15, 20, -1).permute(0, 3, 1, 2)
         (y.float() * r).sum().backward()
-        outs.append([y.detach().float(), xs.grad] + [p.grad.clone() for p in pp.parameters()])
-    bar = 3e-2 if autocast else 1e-4
-    for a, b in zip(*outs):
-        assert float((a - b).abs().max()) <= bar * float(a.abs().max()) + 1e-6
+        return [y.detach().float(), xs.grad] + [p.grad.clone() for p in pp.parameters()]
+
+    def err(a, b):
+        return float((a - b).abs().max()) / (float(a.abs().max()) + 1e-12)
+
+    truth = run("0", False)
+    for a, b in zip(truth, run("1", False)):
+        assert err(a, b) <= 1e-4
+    for a, b, c in zip(truth, run("0", True), run("1", True)):
+        assert err(a, c) <= 1.5 * err(a, b) + 5e-3, (tuple(a.shape), err(a, c), err(a, b))
