@@ -1,19 +1,19 @@
 #!/bin/bash
-# First GPU call of a round:  bash scripts/round_start.sh r03
-#   1. kernel stats + PMC FETCH/WRITE passes of the default bench (scripts/profile_round.sh)
-#   2. bench lines of configurations 4 and 5 at the round's starting HEAD (the round-end records are made by scripts/round_end.sh)
-#   3. A/B of what round 2 left unmeasured: tap-blend forms / XCD-band order, stem fusion, bf16 LDS-tiled GEMM prefetch
-TAG=${1:-r03}
+# First GPU call of a round:  bash scripts/round_start.sh r04        (about 6 GPU-minutes)
+#   1. what round 3 left without a wall-clock number: the bf16 training step after the atomic-free gather backward
+#      (csrc/train_rows.hip gather_sum_rows).  MIOpen's cold-cache start-up of the training convolutions alone is ~100 s on a
+#      fresh box: the limit is 400 s on purpose (round 3 lost its last two bench calls to `timeout 100` / `timeout 120`).
+#   2. the same step in fp32
+#   3. kernel statistics of the bf16 step (scripts/prof_train.sh) and of the default inference bench (scripts/profile_round.sh)
+TAG=${1:-r04}
 cd "$(dirname "$0")/.." || exit 1
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
+timeout 400 python bench.py --mode train --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline --cudnn-benchmark 0 \
+    > "$OUT/${TAG}_start_bench_train_bf16.json" 2> "$OUT/${TAG}_start_bench_train_bf16.err"
+cut -c1-260 "$OUT/${TAG}_start_bench_train_bf16.json"
+timeout 300 python bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline --cudnn-benchmark 0 \
+    > "$OUT/${TAG}_start_bench_train_fp32.json" 2> "$OUT/${TAG}_start_bench_train_fp32.err"
+cut -c1-260 "$OUT/${TAG}_start_bench_train_fp32.json"
+timeout 300 bash scripts/prof_train.sh --precision bf16 | head -40
 bash scripts/profile_round.sh "${TAG}_start"
-for C in 4 5; do
-    timeout 300 python bench.py --config $C --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_start_bench_config${C}_run.json" 2> "$OUT/${TAG}_start_bench_config${C}.err"
-done
-{ for F in static select; do FFB6D_UPCONV_COMBINE=$F timeout 60 python scripts/blend_forms_ab.py; done
-  echo "--- row-major workgroup order (FFB6D_UPCONV_XCD=0)"
-  FFB6D_UPCONV_XCD=0 timeout 60 python scripts/blend_forms_ab.py; } > "$OUT/${TAG}_upconv_blend_forms_ab.txt" 2>&1
-FFB6D_STEM_FUSED=0 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_start_bench_stem_unfused.json" 2> /dev/null
-timeout 300 python scripts/lds_probe.py > "$OUT/${TAG}_start_mlp_pm_lds_ab.txt" 2>&1      # bf16 LDS-tiled GEMM after the branch-free prefetch
-tail -12 "$OUT/${TAG}_upconv_blend_forms_ab.txt"
