@@ -17,3 +17,4 @@ timeout 300 python bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline 
 cut -c1-260 "$OUT/${TAG}_start_bench_train_fp32.json"
 timeout 300 bash scripts/prof_train.sh --precision bf16 | head -40
 bash scripts/profile_round.sh "${TAG}_start"
+timeout 300 python scripts/train_copy_census.py > "$OUT/${TAG}_train_copy_census.txt" 2>&1; head -30 "$OUT/${TAG}_train_copy_census.txt"
