@@ -19,6 +19,10 @@
 //                                    in torch.max), not stored by the forward
 //   att_pool_rows / _bwd           : softmax over the K neighbours, weighted sum (Att_pooling.forward, RandLANet.py:245-248) and
 //                                    its gradient with respect to features and scores
+//   log_softmax_rows / _bwd        : LogSoftmax over the channels of a map (`final` of the colour decoder, pspnet.py:108-112) with
+//                                    the map's own element type in and out (fp32 arithmetic): under autocast ATen's version is
+//                                    an fp32 operator -- the two full-resolution maps were cast up, written as fp32 and cast down
+//                                    again by every consumer (~3 GB of traffic per step for 0.6 GB of data)
 //
 // A lane owns one 16-byte unit of a row (4 fp32 / 8 bf16 channels) so that a wave's loads and stores cover whole cache lines;
 // sums are fp32.  Only the max-pool backward still uses float atomics (0.5 ms per step; its fp32 accumulator is rounded to the
@@ -212,6 +216,66 @@ att_pool_rows_bwd_kernel(const void* __restrict__ g, int ldgq, const void* __res
     }
 }
 
+// y[r, :] = (x[r, :] - max) - log(sum exp(x[r, :] - max)): the q = C / VL lanes of a row (a power of two <= 64, consecutive lanes of
+// one wave) reduce with butterfly shuffles; lanes past the end stay in the shuffles and skip the store.
+template <typename T>
+__global__ void __launch_bounds__(BLK)
+log_softmax_rows_kernel(const void* __restrict__ x, void* __restrict__ y, int q, size_t total /* R*q */)
+{
+    using RU = RowUnit<T>;
+    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const bool live = t < total;
+    const RU v = RU::load(x, live ? t : total - 1);
+    float m = v.v[0];
+#pragma unroll
+    for (int e = 1; e < RU::VL; ++e) m = fmaxf(m, v.v[e]);
+    for (int o = q >> 1; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < RU::VL; ++e) s += expf(v.v[e] - m);
+    for (int o = q >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float ls = logf(s);
+    RU o;
+#pragma unroll
+    for (int e = 0; e < RU::VL; ++e) o.v[e] = (v.v[e] - m) - ls;
+    if (live) o.store(y, t);
+}
+
+// gx[r, :] = g[r, :] - softmax(x[r, :]) * sum(g[r, :]); the softmax is recomputed from the forward's INPUT in fp32 (exp of the
+// stored output would carry the output's bf16 rounding: 2^-9 |y| relative, percents for the unlikely channels)
+template <typename T>
+__global__ void __launch_bounds__(BLK)
+log_softmax_rows_bwd_kernel(const void* __restrict__ g, const void* __restrict__ x, void* __restrict__ gx, int q, size_t total)
+{
+    using RU = RowUnit<T>;
+    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const bool live = t < total;
+    const size_t u = live ? t : total - 1;
+    const RU gv = RU::load(g, u), xv = RU::load(x, u);
+    float sg = 0.f, m = xv.v[0];
+#pragma unroll
+    for (int e = 0; e < RU::VL; ++e) {
+        sg += gv.v[e];
+        m = fmaxf(m, xv.v[e]);
+    }
+    for (int o = q >> 1; o >= 1; o >>= 1) {
+        sg += __shfl_xor(sg, o, 64);
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+    }
+    float p[RU::VL], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < RU::VL; ++e) {
+        p[e] = expf(xv.v[e] - m);
+        s += p[e];
+    }
+    for (int o = q >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float k = sg / s;
+    RU o;
+#pragma unroll
+    for (int e = 0; e < RU::VL; ++e) o.v[e] = gv.v[e] - p[e] * k;
+    if (live) o.store(gx, t);
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline bool dt_ok(int dtype) { return dtype == 0 || dtype == 1; }
 inline bool bits_ok(int bits) { return bits == 32 || bits == 64; }
@@ -316,6 +380,42 @@ extern "C" int ffb6d_att_pool_rows_bwd(int dtype, const void* g, int64_t ldg, co
         else
             hipLaunchKernelGGL((att_pool_rows_bwd_kernel<T, 0>), dim3(blocks_for(total)), dim3(BLK), 0, as_stream(stream), g, (int)(ldg / VL),
                                feat, (int)(ldf / VL), scores, (int)(lds / VL), gfeat, gscores, q, K, total);
+    });
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+static bool lsm_shape_ok(int dtype, int64_t C)
+{
+    const int VL = dtype ? 8 : 4;
+    if (C < VL || C % VL) return false;
+    const int64_t q = C / VL;
+    return q <= 64 && (q & (q - 1)) == 0;
+}
+
+extern "C" int ffb6d_log_softmax_rows(int dtype, const void* x, void* y, int64_t R, int64_t C, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(dt_ok(dtype), "log_softmax_rows: dtype must be 0 (f32) or 1 (bf16)");
+    FFB6D_REQUIRE(R >= 0 && lsm_shape_ok(dtype, C), "log_softmax_rows: C / %d must be a power of two <= 64", dtype ? 8 : 4);
+    if (R == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(x && y && al16(x) && al16(y), "log_softmax_rows: null or unaligned pointer");
+    const int q = (int)(C / (dtype ? 8 : 4));
+    const size_t total = (size_t)R * q;
+    FFB6D_ROWS_DT(dtype, T, { hipLaunchKernelGGL((log_softmax_rows_kernel<T>), dim3(blocks_for(total)), dim3(BLK), 0, as_stream(stream), x, y, q, total); });
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+extern "C" int ffb6d_log_softmax_rows_bwd(int dtype, const void* g, const void* x, void* gx, int64_t R, int64_t C, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(dt_ok(dtype), "log_softmax_rows_bwd: dtype must be 0 (f32) or 1 (bf16)");
+    FFB6D_REQUIRE(R >= 0 && lsm_shape_ok(dtype, C), "log_softmax_rows_bwd: C / %d must be a power of two <= 64", dtype ? 8 : 4);
+    if (R == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(g && x && gx && al16(g) && al16(x) && al16(gx), "log_softmax_rows_bwd: null or unaligned pointer");
+    const int q = (int)(C / (dtype ? 8 : 4));
+    const size_t total = (size_t)R * q;
+    FFB6D_ROWS_DT(dtype, T, {
+        hipLaunchKernelGGL((log_softmax_rows_bwd_kernel<T>), dim3(blocks_for(total)), dim3(BLK), 0, as_stream(stream), g, x, gx, q, total);
     });
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;

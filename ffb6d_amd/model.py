@@ -302,6 +302,10 @@ class FinalHead(nn.Sequential):
     def __init__(self, ch=64):
         super().__init__(nn.Conv2d(ch, ch, 1), nn.LogSoftmax(dim=1))
 
+    def forward(self, x):
+        y = self[0](x)
+        return ops_cl.channel_log_softmax(y) if y.is_cuda else self[1](y)      # same operator on rows, in the map's own dtype
+
 
 def _head(cin, cout):
     """ffb6d.py:135-157: three conv1d+BN+ReLU then a plain conv1d (pt_utils.Seq numbering)."""

@@ -186,6 +186,49 @@ class _AttPoolRows(torch.autograd.Function):
         return from_rows(gf, (N, K)), from_rows(gs, (N, K))
 
 
+class _LogSoftmaxRows(torch.autograd.Function):
+    """x [B,C,*S] -> log_softmax over C, same dtype and memory"""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x):
+        rows = to_rows(x)                                                    # [B,M,C]
+        B, M, C = rows.shape
+        y = torch.empty_like(rows)
+        with torch.cuda.device(x.device), _lib.traced("log_softmax_rows", 2 * rows.element_size() * rows.numel(), (C, B * M)):
+            rc = _lib.load().ffb6d_log_softmax_rows(_dt(rows), rows.data_ptr(), y.data_ptr(), B * M, C, _stream(x))
+        _lib.check(rc, "ffb6d_log_softmax_rows")
+        ctx.save_for_backward(rows)                                          # the input: the backward recomputes the softmax in fp32
+        ctx.spatial = tuple(x.shape[2:])
+        return from_rows(y, ctx.spatial)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, M, C = x.shape
+        g = _act(g)
+        gr = to_rows(g if g.dtype == x.dtype else g.to(x.dtype))
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device), _lib.traced("log_softmax_rows_bwd", 3 * x.element_size() * x.numel(), (C, B * M)):
+            rc = _lib.load().ffb6d_log_softmax_rows_bwd(_dt(x), gr.data_ptr(), x.data_ptr(), gx.data_ptr(), B * M, C, _stream(x))
+        _lib.check(rc, "ffb6d_log_softmax_rows_bwd")
+        return from_rows(gx, ctx.spatial)
+
+
+def channel_log_softmax(x):
+    """nn.LogSoftmax over dim 1 of a [B,C,H,W] map (pspnet.py:108-112) in the map's own dtype (fp32 arithmetic).  torch.autocast
+    lists log_softmax as a float32 operator; every consumer of this map is a convolution that rounds its input to the autocast
+    dtype, a row gather or a max over gathered rows -- all of which commute with that (monotonic) rounding -- so rounding once
+    here gives them the same values and keeps the two largest maps of the decoder out of fp32."""
+    _need_gpu(x)
+    x = _act(x)
+    q, r = divmod(x.shape[1], _vl(x))
+    if x.dim() < 3 or r or q > 64 or q & (q - 1) or x.dtype not in (torch.float32, torch.bfloat16):
+        return torch.log_softmax(x, dim=1)
+    return _LogSoftmaxRows.apply(x)
+
+
 def nearest_interpolation(feature, interp_idx, spatial=None, plan=None):
     """FFB6D.nearest_interpolation (ffb6d.py:179-194): feature [B,C,M,1] (or any [B,C,*S]), interp_idx [B,U,1] -> [B,C,U,1]
     (or [B,C,*spatial] with prod(spatial) == U: the point -> pixel fusion reshapes to the map right away).

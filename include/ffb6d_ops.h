@@ -244,6 +244,11 @@ int ffb6d_att_pool_rows(int dtype, const void* feat, int64_t ldf, const void* sc
                         int64_t C, ffb6d_stream_t stream);
 int ffb6d_att_pool_rows_bwd(int dtype, const void* g, int64_t ldg, const void* feat, int64_t ldf, const void* scores, int64_t lds,
                             void* gfeat, void* gscores, int64_t P, int K, int64_t C, ffb6d_stream_t stream);
+/* LogSoftmax over the channels of [R, C] rows (`final` of the colour decoder, pspnet.py:108-112: nn.LogSoftmax() on a 4-d map acts
+ * on dim 1) in the rows' own element type, fp32 arithmetic; C / 4 (float32) resp. C / 8 (bfloat16) a power of two <= 64.
+ * _bwd: gx = g - softmax(x) * sum_c g, recomputed from the forward's input x. */
+int ffb6d_log_softmax_rows(int dtype, const void* x, void* y, int64_t R, int64_t C, ffb6d_stream_t stream);
+int ffb6d_log_softmax_rows_bwd(int dtype, const void* g, const void* x, void* gx, int64_t R, int64_t C, ffb6d_stream_t stream);
 /* Second half of the folded up-convolution (PSPUpsample, pspnet.py:34-45: bilinear x2 with align_corners -> Conv2d 3x3,
  * padding 1 -> BatchNorm -> PReLU).  z [B,IH,IW,9,C] holds, per low-resolution pixel and filter tap (ky*3+kx), the channel
  * mixing (BatchNorm scale * W[:, :, ky, kx]) x -- one ffb6d_mlp_pm GEMM with 9*C output channels -- and
