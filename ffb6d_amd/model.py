@@ -509,8 +509,10 @@ class FFB6D(nn.Module):
         bs = rgb_emb.shape[0]
         rgb_emb_c = ops_cl.choose_gather(rgb_emb, inputs['choose'])
 
+        rgbd_emb = torch.cat([rgb_emb_c, p_emb], dim=1)          # ffb6d.py:318-323: one concatenation feeds the three heads
+
         def head(seq):
-            return seq(torch.cat([rgb_emb_c, p_emb], dim=1))
+            return seq(rgbd_emb)
 
         end_points['pred_rgbd_segs'] = head(self.rgbd_seg_layer)
         end_points['pred_kp_ofs'] = head(self.kp_ofst_layer).view(
