@@ -91,3 +91,59 @@ def test_single_process_group_is_a_noop():
     n = []
     t = D.timed_steps(lambda timed: n.append(timed), warmup=1, steps=2, group=g)
     assert n == [False, True, True] and t >= 0
+
+
+TRAIN_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import pytest, torch
+    from tests.simt import bind
+    mp = pytest.MonkeyPatch()
+    bind.bind(mp)                       # CPU tensors through the emulated kernels: the real training forward / backward
+    from ffb6d_amd import distributed as D, model as M, pyramid
+    g = D.init_from_env(backend="gloo")
+    frames = D.shard_frames(3, 1, g.rank, None, n_points=1024, height=120, width=160)
+    torch.manual_seed(0)                                    # same initial weights on both ranks
+    net = M.FFB6D(n_classes=4, n_pts=1024).train()
+    inputs = pyramid.frames_to_device(frames, torch.device("cpu"))
+    names = ["rndla_ds_stages.0.lfa.att_pooling_1.fc.weight", "cnn_ds_stages.3.0.stages.1.1.weight", "kp_ofst_layer.3.conv.weight",
+             "ds_fuse_p2r_pre_layers.0.conv.weight", "rndla_up_stages.2.conv.weight"]
+    def grads_of(module):
+        module.zero_grad()
+        torch.manual_seed(7)                                # same dropout masks in both passes
+        out = module(inputs)
+        sum((v.float() ** 2).mean() for v in out.values()).backward()
+        params = dict(net.named_parameters())
+        return {n: params[n].grad.flatten()[:64].tolist() for n in names}
+    local = grads_of(net)
+    ddp = D.wrap_ddp(net, torch.device("cpu"))              # gloo: BatchNorm statistics stay per rank
+    synced = grads_of(ddp)
+    print("RESULT " + json.dumps(dict(rank=g.rank, local=local, synced=synced)), flush=True)
+    g.close()
+""") % ROOT
+
+
+def test_two_rank_training_step_averages_gradients_through_the_custom_operators(tmp_path):
+    """BASELINE config 3 on two gloo ranks, one frame each, the REAL network: forward through the stock modules + the channels-last
+    neighbour operators (ops_cl: row gathers with a shared inverted index, max-pool, attentive pooling, row log-softmax, folded
+    pyramid pooling), backward through their kernels on the SIMT emulator, DistributedDataParallel around it (train_lm.py:625-628).
+    Every rank must end with the mean of the two ranks' local gradients -- i.e. every parameter took part in the all-reduce and the
+    custom autograd Functions (non-tensor arguments, shared plans) are DDP-clean."""
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[-3000:] for o in outs]
+    res = sorted((json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs), key=lambda r: r["rank"])
+    for name in res[0]["local"]:
+        l0, l1 = np.array(res[0]["local"][name]), np.array(res[1]["local"][name])
+        s0, s1 = np.array(res[0]["synced"][name]), np.array(res[1]["synced"][name])
+        scale = max(np.abs(l0).max(), np.abs(l1).max())
+        assert scale > 0 and not np.allclose(l0, l1, rtol=1e-3, atol=1e-6 * scale), name          # the ranks saw different frames
+        np.testing.assert_allclose(s0, s1, rtol=0, atol=1e-6 * scale, err_msg=name)                  # one gradient on both ranks
+        np.testing.assert_allclose(s0, (l0 + l1) / 2, rtol=0, atol=2e-5 * scale, err_msg=name)       # = the mean of the local ones
