@@ -65,6 +65,10 @@ def parse():
                     help="infer (default, the BASELINE metric): pyramid + forward, eval, no_grad.  train: BASELINE "
                          "config 3 shape -- pyramid + forward + backward + Adam step in train() mode, wrapped in "
                          "DistributedDataParallel (RCCL gradient all-reduce) when launched with more than one rank")
+    ap.add_argument("--objective", choices=["reference", "proxy"], default="reference",
+                    help="train mode: reference = the reference's objective (2 * focal(gamma=2) on the segmentation + masked L1 on the "
+                         "keypoint and centre offsets, train_lm.py:245-259, ffb6d_amd/loss.py) on seeded synthetic labels / target "
+                         "offsets; proxy = mean of squares of the three outputs (what the round-3 records were taken with)")
     ap.add_argument("--local-bn", action="store_true",
                     help="train mode, >1 rank: per-rank BatchNorm statistics, gradients are the only collective (north_star's "
                          "wording); default = torch.nn.SyncBatchNorm like the reference's apex SyncBN (train_lm.py:592)")
@@ -258,6 +262,14 @@ def main():
     cld = torch.from_numpy(frames["cld"]).to(dev)
     dpt_xyz = torch.from_numpy(frames["dpt_xyz"]).to(dev)
 
+    targets = None
+    if train and args.objective == "reference":
+        from ffb6d_amd import loss as ffb6d_loss
+        tg = [synth.make_targets(synth.frame_seed(args.config, rank * args.batch + s), frames["cld"][s], n_classes=args.n_classes)
+              for s in range(args.batch)]
+        targets = tuple(torch.from_numpy(np.stack([t[k] for t in tg])).to(dev) for k in ("labels", "kp_targ_ofst", "ctr_targ_ofst"))
+        targets = (targets[0].long(),) + targets[1:]
+
     ev = lambda: torch.cuda.Event(enable_timing=True)
     phase = {"pyramid": [], "forward": []}
 
@@ -284,14 +296,15 @@ def main():
                 e1.record()
         inputs.update(rgb=rgb, cld_rgb_nrm=cld_rgb_nrm, choose=choose)
         if train:
-            # proxy objective (the reference's focal + L1 offset losses need labels that synthetic
-            # frames do not have); it touches all three heads so every parameter gets a gradient
             opt.zero_grad(set_to_none=True)
             # --precision bf16: mixed precision as the reference trains (apex amp, train_lm.py:600) -- torch.autocast runs
             # the convolutions / 1x1 layers in bfloat16 with fp32 master weights; the neighbour operators keep fp32
             with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.precision == "bf16"):
                 out = ddp(inputs)
-                loss = sum((v.float() ** 2).mean() for v in out.values())
+                if targets is not None:        # the reference's objective (train_lm.py:245-259) on the synthetic targets
+                    loss = ffb6d_loss.training_loss(out, *targets)[0]
+                else:                          # --objective proxy: touches all three heads, no labels needed
+                    loss = sum((v.float() ** 2).mean() for v in out.values())
             loss.backward()
             opt.step()
         else:
@@ -530,7 +543,9 @@ def main():
                                    " incl. on-device 22-call KNN index pyramid; "
                                    f"bs={args.batch}/GPU, N={args.n_points} pts, 480x640 RGB-D, "
                                    f"{args.n_classes} classes, " + ("bf16 activations/weights with fp32 accumulation" if args.precision == "bf16" else "fp32") +
-                                   f", {'train' if train else 'eval'}",
+                                   f", {'train' if train else 'eval'}" +
+                                   ((", objective: 2 * focal(gamma=2) + masked L1 offsets (train_lm.py:245-259) on synthetic targets"
+                                     if args.objective == "reference" else ", objective: mean of squared outputs (proxy)") if train else ""),
                        "baseline_config": args.config, "global_batch": args.batch * world, "n_points": args.n_points,
                        "index_dtype": args.index_dtype, "layout": "pm",
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "

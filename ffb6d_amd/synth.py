@@ -69,6 +69,26 @@ def make_frame(seed, n_points=12288, height=480, width=640, invalid_frac=0.05, K
     )
 
 
+def make_targets(seed, cld, n_classes=22, n_kps=8, n_objects=3, radius=0.12):
+    """Synthetic training targets of one frame with the dataset's shapes and meaning (linemod_dataset.py:291-297,
+    ycb_dataset.py:214-252): `n_objects` spheres of `radius` metres around seeded surface points, each with a class id in
+    [1, n_classes) and n_kps keypoints; labels [N] int32 = class of the sphere a point falls in (0 = background; the nearest centre
+    wins), kp_targ_ofst [N,n_kps,3] / ctr_targ_ofst [N,1,3] = keypoint / centre minus point for the points of an object, 0 elsewhere.
+    Its own random stream (seed + 7919): make_frame's values and the golden fixtures built from them do not change."""
+    rng = np.random.RandomState(seed + 7919)
+    n = cld.shape[0]
+    centres = cld[rng.choice(n, size=n_objects, replace=False)].astype(np.float64)
+    classes = rng.choice(np.arange(1, max(n_classes, 2)), size=n_objects, replace=n_classes - 1 < n_objects)
+    kps = centres[:, None, :] + 0.05 * rng.standard_normal((n_objects, n_kps, 3))
+    d = np.linalg.norm(cld[:, None, :].astype(np.float64) - centres[None], axis=2)          # [N, objects]
+    owner = d.argmin(axis=1)
+    inside = d[np.arange(n), owner] < radius
+    labels = np.where(inside, classes[owner], 0).astype(np.int32)
+    kp_targ = np.where(inside[:, None, None], kps[owner] - cld[:, None, :], 0.0).astype(np.float32)
+    ctr_targ = np.where(inside[:, None, None], centres[owner][:, None, :] - cld[:, None, :], 0.0).astype(np.float32)
+    return dict(labels=labels, kp_targ_ofst=kp_targ, ctr_targ_ofst=ctr_targ)
+
+
 def make_batch(config, batch_size, **kw):
     """Stack `batch_size` frames with seeds 1000*config + sample."""
     frames = [make_frame(frame_seed(config, s), **kw) for s in range(batch_size)]

@@ -100,9 +100,11 @@ TRAIN_WORKER = textwrap.dedent("""
     from tests.simt import bind
     mp = pytest.MonkeyPatch()
     bind.bind(mp)                       # CPU tensors through the emulated kernels: the real training forward / backward
-    from ffb6d_amd import distributed as D, model as M, pyramid
+    from ffb6d_amd import distributed as D, loss, model as M, pyramid, synth
     g = D.init_from_env(backend="gloo")
     frames = D.shard_frames(3, 1, g.rank, None, n_points=1024, height=120, width=160)
+    tg = synth.make_targets(synth.frame_seed(3, g.rank), frames["cld"][0], n_classes=4)
+    targets = (torch.from_numpy(tg["labels"])[None].long(), torch.from_numpy(tg["kp_targ_ofst"])[None], torch.from_numpy(tg["ctr_targ_ofst"])[None])
     torch.manual_seed(0)                                    # same initial weights on both ranks
     net = M.FFB6D(n_classes=4, n_pts=1024).train()
     inputs = pyramid.frames_to_device(frames, torch.device("cpu"))
@@ -112,7 +114,7 @@ TRAIN_WORKER = textwrap.dedent("""
         module.zero_grad()
         torch.manual_seed(7)                                # same dropout masks in both passes
         out = module(inputs)
-        sum((v.float() ** 2).mean() for v in out.values()).backward()
+        loss.training_loss(out, *targets)[0].backward()      # the reference's objective (train_lm.py:245-259) on synthetic targets
         params = dict(net.named_parameters())
         return {n: params[n].grad.flatten()[:64].tolist() for n in names}
     local = grads_of(net)
