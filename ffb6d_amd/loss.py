@@ -16,7 +16,7 @@ def focal_loss(logits, labels, gamma=2.0):
     """logits [B,C,N] (or [M,C]), labels int [B,N] / [B*N] -> scalar (loss.py:21-44)"""
     if logits.dim() > 2:
         logits = logits.reshape(logits.shape[0], logits.shape[1], -1).transpose(1, 2).reshape(-1, logits.shape[1])
-    logpt = torch.log_softmax(logits, dim=1).gather(1, labels.reshape(-1, 1).long()).reshape(-1)
+    logpt = torch.log_softmax(logits.float(), dim=1).gather(1, labels.reshape(-1, 1).long()).reshape(-1)      # fp32 as under amp
     pt = logpt.detach().exp()
     return (-((1.0 - pt) ** gamma) * logpt).mean()
 
