@@ -260,6 +260,20 @@ def gather_neighbour(feature, neigh_idx, plan=None):
     return nearest_interpolation(feature, neigh_idx.reshape(B, N * K, 1), (N, K), plan)
 
 
+def gather_neighbour_rows(pc, neighbor_idx):
+    """Building_block.gather_neighbour with the reference's own signature (RandLANet.py:225-234): pc [B,N,C] rows, neighbor_idx
+    [B,N,K] -> [B,N,K,C] in pc's dtype -- the reference's layout IS rows; its permute(0,3,1,2) afterwards is a channels_last view."""
+    _need_gpu(pc, neighbor_idx)
+    pc = _act(pc)
+    if pc.dim() != 3 or neighbor_idx.dim() != 3 or pc.shape[0] != neighbor_idx.shape[0]:
+        raise ValueError(f"bad shapes {tuple(pc.shape)} / {tuple(neighbor_idx.shape)}")
+    B, N, K = neighbor_idx.shape
+    if pc.shape[2] % _vl(pc):
+        return ops.gather_neighbour(pc, neighbor_idx)
+    rows = pc if pc.is_contiguous() else pc.contiguous()
+    return _GatherRows.apply(rows, GatherPlan(neighbor_idx.reshape(B, N * K), rows.shape[1])).reshape(B, N, K, -1)
+
+
 def choose_gather(rgb_emb, choose):
     """the per-point pixel pick of ffb6d.py:309-312: rgb_emb [B,C,H,W], choose [B,1,N] -> [B,C,N]"""
     return nearest_interpolation(rgb_emb, choose.reshape(choose.shape[0], -1, 1)).squeeze(3)

@@ -313,12 +313,15 @@ def test_whole_fused_forward_on_the_emulator_matches_the_plain_torch_restatement
 # the drop-in boundary, executed: the UNMODIFIED reference model with our operators patched in
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.reference
-def test_reference_model_with_our_operators_patched_in_equals_the_reference(emu):
+@pytest.mark.parametrize("rows", [False, True])
+def test_reference_model_with_our_operators_patched_in_equals_the_reference(emu, rows):
     """patch.patch_reference on the reference's own FFB6D (ffb6d/models/ffb6d.py, RandLANet.py): random_sample,
     nearest_interpolation, gather_neighbour, relative_pos_encoding and Att_pooling.forward become ffb6d_amd.ops (the
     channel-major kernels of csrc/neighbour_ops.hip, run here on the emulator); everything else -- modules, weights, the
     forward's control flow -- stays the reference's.  Same frame, same weights: the patched forward must reproduce the
-    unpatched one (gathers / max pooling exactly, the attentive pooling's softmax-sum to fp32 rounding)."""
+    unpatched one (gathers / max pooling exactly, the attentive pooling's softmax-sum to fp32 rounding).
+    rows=True: the channels-last operators of ffb6d_amd.ops_cl instead (what this package's training step uses) -- the reference's
+    own permutes / views around them must keep working on their channels_last-strided outputs."""
     import numpy as np
     from ffb6d_amd import patch, synth
     from oracle import knn as oknn
@@ -340,12 +343,13 @@ def test_reference_model_with_our_operators_patched_in_equals_the_reference(emu)
     mp.setattr(ops, "_stream", lambda t: None)
     calls = {}
     for name in ("ffb6d_random_sample_f32", "ffb6d_nearest_interpolation_f32", "ffb6d_gather_neighbour_f32",
-                 "ffb6d_relative_pos_encoding_f32", "ffb6d_att_pool_f32"):
+                 "ffb6d_relative_pos_encoding_f32", "ffb6d_att_pool_f32", "ffb6d_random_sample_pm", "ffb6d_gather_rows_pm",
+                 "ffb6d_att_pool_rows"):
         def counted(*a, _fn=getattr(emu, name), _name=name):
             calls[_name] = calls.get(_name, 0) + 1
             return _fn(*a)
         mp.setattr(emu, name, counted, raising=False)
-    undo = patch.patch_reference(m_ffb6d, m_randla)
+    undo = patch.patch_reference(m_ffb6d, m_randla, rows=rows)
     try:
         with torch.no_grad():
             got = ref_model(dict(inputs))
@@ -354,8 +358,12 @@ def test_reference_model_with_our_operators_patched_in_equals_the_reference(emu)
         mp.undo()
     # the patched forward really went through the five native entry points (ffb6d.py:240-312, RandLANet.py:196-250):
     # 4 + 7 max poolings (sub-sampling, r2p), 4 + 7 interpolations (decoder, p2r), 2 x 4 feature gathers, 4 encodings, 2 x 4 attentive poolings
-    assert calls == {"ffb6d_random_sample_f32": 11, "ffb6d_nearest_interpolation_f32": 11, "ffb6d_gather_neighbour_f32": 8,
-                     "ffb6d_relative_pos_encoding_f32": 4, "ffb6d_att_pool_f32": 8}, calls
+    if rows:                          # row kernels: every gather (interpolation or neighbour) is ffb6d_gather_rows_pm
+        assert calls == {"ffb6d_random_sample_pm": 11, "ffb6d_gather_rows_pm": 19, "ffb6d_relative_pos_encoding_f32": 4,
+                         "ffb6d_att_pool_rows": 8}, calls
+    else:
+        assert calls == {"ffb6d_random_sample_f32": 11, "ffb6d_nearest_interpolation_f32": 11, "ffb6d_gather_neighbour_f32": 8,
+                         "ffb6d_relative_pos_encoding_f32": 4, "ffb6d_att_pool_f32": 8}, calls
     assert sorted(got) == sorted(want)
     for k in want:
         scale = float(want[k].abs().max())
