@@ -175,3 +175,22 @@ def test_channel_log_softmax_rows(device, dt, shape):
         assert got[0].is_contiguous(memory_format=torch.channels_last)
     close(got[0], want[0], dt, "out")
     close(got[1], want[1], dt, "grad", f32_bar=1e-4)     # g - softmax * sum(g): the 256-term sum is ordered differently (butterfly)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gather_neighbour_with_the_reference_signature_on_rows(device, dt):
+    """Building_block.gather_neighbour as the reference calls it (RandLANet.py:225-234): pc [B,N,C], idx [B,N,K] -> [B,N,K,C];
+    values, dtype and gradient against torch.gather"""
+    B, N, C, K = 2, 60, 16, 16
+    g = torch.Generator().manual_seed(9)
+    pc = torch.randn(B, N, C, generator=g).to(device).to(dt)
+    idx = torch.randint(0, N, (B, N, K), generator=g).to(device)
+
+    def ref(p):                        # index.repeat + gather + reshape, as upstream
+        flat = idx.reshape(B, -1, 1).expand(-1, -1, C)
+        return torch.gather(p, 1, flat).reshape(B, N, K, C)
+    got = grads(lambda p: ops_cl.gather_neighbour_rows(p, idx), pc)
+    want = grads(ref, pc.float())
+    assert got[0].shape == (B, N, K, C) and got[0].dtype == dt and got[0].is_contiguous()
+    assert torch.equal(got[0].float(), want[0])
+    close(got[1], want[1], dt, "grad")
