@@ -13,7 +13,7 @@
 //                                    shared by all gathers through the same index tensor); a lane owns one unit of a DESTINATION
 //                                    row, adds up the rows that reference it in fp32 and stores the activation type once.  (The
 //                                    first version scattered with global float atomics: device-scope atomics leave the XCD's L2,
-//                                    13.1 ms per step for the 19 gathers against 2.7 ms for this form's predecessor.)
+//                                    13.1 ms per step for the 19 gathers of the model; this form: 2.1 - 2.6 ms, profiles/r03_*rows*.)
 //   random_sample_rows_bwd         : backward of FFB6D.random_sample (ffb6d.py:159-177): the gradient of an output element goes
 //                                    to the neighbour that won the max -- recomputed from the rows (first maximum; a NaN wins like
 //                                    in torch.max), not stored by the forward

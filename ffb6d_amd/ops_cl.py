@@ -2,7 +2,7 @@
 
 Same operators and signatures as ffb6d_amd.ops (= the reference's: FFB6D.random_sample / nearest_interpolation ffb6d.py:159-194,
 Building_block.gather_neighbour / relative_pos_encoding RandLANet.py:216-234, the softmax-pool of Att_pooling.forward
-RandLANet.py:245-248), but every [B,C,...] tensor they take or return is read and written as ROWS of C contiguous channels --
+RandLANet.py:245-248; plus the LogSoftmax of the colour decoder's `final` layer, pspnet.py:108-112), but every [B,C,...] tensor they take or return is read and written as ROWS of C contiguous channels --
 torch's channels_last memory of a [B,C,N,K] tensor, which is what MIOpen's NHWC convolutions produce and consume -- in the
 activation dtype (bf16 under torch.autocast).  A training step built from them has no transposing copy and no bf16 <-> fp32 cast
 between a convolution and a neighbour operator (round 3's profile: 15 + 5 ms of an 82 ms step).
