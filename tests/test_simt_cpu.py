@@ -410,6 +410,31 @@ def test_knn_kernels_on_the_emulator_are_bit_exact_against_the_oracle(emu, B, S,
     np.testing.assert_array_equal(nn.knn_batch(sup, qry, K, omp=True), oknn.knn_batch(sup, qry, K))
 
 
+def test_knn_on_the_emulator_tie_rule_on_quantised_clouds(emu):
+    """Property test (hypothesis, 12 seeded examples): coordinates quantised to a coarse lattice, so that most neighbourhoods
+    contain exact distance ties and duplicated points -- the answer is only defined by nanoflann's rule (KNNResultSet::addPoint,
+    nanoflann.hpp:115-139: among equal distances the lowest index wins), which the oracle restates.  Small sets take the LDS
+    scan, S >= 2048 the Morton-pruned kernels; K from 1 to 16 including K == S."""
+    import numpy as np
+    from hypothesis import example, given, settings, strategies as st
+    from ffb6d_amd import nearest_neighbors as nn
+    from oracle import knn as oknn
+
+    @settings(max_examples=12, deadline=None, derandomize=True)
+    @example(1, 2048, 8, 16, 3, 1)        # the Morton-pruned row kernel on a lattice of 27 distinct points
+    @example(2, 2048, 8, 1, 2, 2)         # ... and the K = 1 kernel
+    @example(3, 16, 5, 16, 2, 1)          # K == S
+    @given(st.integers(0, 2 ** 31 - 1), st.sampled_from([16, 17, 63, 200, 2048]), st.integers(1, 24), st.integers(1, 16),
+           st.sampled_from([2, 3, 5, 9]), st.integers(1, 2))
+    def check(seed, S, Q, K, levels, B):
+        g = np.random.default_rng(seed)
+        sup = (g.integers(0, levels, (B, S, 3)) / np.float32(levels)).astype(np.float32)
+        qry = (g.integers(0, levels, (B, Q, 3)) / np.float32(levels)).astype(np.float32)
+        K = min(K, S)
+        np.testing.assert_array_equal(nn.knn_batch(sup, qry, K, omp=True), oknn.knn_batch(sup, qry, K))
+    check()
+
+
 @pytest.mark.reference
 def test_knn_on_the_emulator_equals_the_reference_nanoflann(emu):
     """the reference's knn_.cxx + nanoflann compiled in place (oracle/_ref) on the same clouds, tie runs canonicalised"""
