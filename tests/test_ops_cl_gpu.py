@@ -194,3 +194,22 @@ def test_gather_neighbour_with_the_reference_signature_on_rows(device, dt):
     assert got[0].shape == (B, N, K, C) and got[0].dtype == dt and got[0].is_contiguous()
     assert torch.equal(got[0].float(), want[0])
     close(got[1], want[1], dt, "grad")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("C", [8, 24, 64, 256, 512])
+def test_gather_backward_with_skewed_reader_counts(device, dt, C):
+    """gather_sum_rows: 1 .. 8 lanes share a (destination row, unit) depending on C (butterfly reduction), rows with no reader at
+    all, one row read by a third of the outputs, odd list lengths -- against torch's scatter-add of the same gradient"""
+    B, M, U = 2, 37, 301
+    g = torch.Generator().manual_seed(C)
+    idx = torch.randint(3, M, (B, U), generator=g)          # rows 0..2 have no reader
+    idx[:, ::3] = 5                                          # ~100 readers of row 5
+    idx[1, 1::7] = M - 1
+    feat = cl(torch.randn(B, C, M, 1, generator=g)).to(device).to(dt)
+    idx = idx.to(device)
+    got = grads(lambda f: ops_cl.nearest_interpolation(f, idx.unsqueeze(2)), feat, rdt=dt)
+    want = grads(lambda f: ref_gather(f, idx).unsqueeze(3), feat.float(), rdt=dt)
+    assert torch.equal(got[0].float(), want[0])
+    assert not got[1][:, :, :3].any()
+    close(got[1], want[1], dt, "grad")
