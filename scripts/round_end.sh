@@ -5,6 +5,7 @@
 #   3. configurations 4 and 5: bench line with cpu_baseline + rocprofv3 kernel stats -> <tag>_bench_config{4,5}_run.json, <tag>_kernels_config{4,5}.txt
 #   4. per-op / per-shape table on one stream                                      -> <tag>_hot_path_ops_by_shape_one_stream.txt
 #   5. fused LFA: level table and PMC of the level-0 launch; MFMA-busy PMC of the dominant GEMM
+#   6. training step (bf16 autocast and fp32; MIOpen's cold start alone is ~100 s: generous limits) + its kernel statistics
 TAG=${1:-r03}
 cd "$(dirname "$0")/.." || exit 1
 REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
@@ -24,6 +25,11 @@ done
 timeout 200 python scripts/bench_lfa.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_lfa_levels.txt"
 bash scripts/pmc_lfa.sh 0 1 f32 > /dev/null 2>&1; cp "$OUT/lfa_pmc_0_1_f32.txt" "$OUT/${TAG}_lfa_pmc_level0_half1.txt"
 bash scripts/pmc_pm_shape.sh 1024 2304 38400 f32 7 > /dev/null 2>&1; cp "$OUT/pm_shape_pmc_1024_2304_38400_f32_7.txt" "$OUT/${TAG}_mlp_pm_lds_pmc_1024_2304_38400.txt"
+for P in bf16 fp32; do
+    timeout 400 python bench.py --mode train --precision $P --steps 8 --warmup 3 --no-cpu-baseline --cudnn-benchmark 0 \
+        > "$OUT/${TAG}_bench_train_$P.json" 2> "$OUT/${TAG}_bench_train_$P.err"
+done
+timeout 300 bash scripts/prof_train.sh --precision bf16 > /dev/null 2>&1; cp "$OUT/r03_train_kernels.txt" "$OUT/${TAG}_rocprofv3_kernel_stats_train_bf16.txt"
 python -c "
 import json
 for n in ('default', 'config4', 'config5'):
