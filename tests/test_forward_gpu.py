@@ -298,13 +298,13 @@ def test_batch_items_are_independent(device):
         assert float((full[k][1:2] - single[k]).abs().max()) <= 1e-3 * scale, k
 
 
-def test_training_step_gradients_match_plain_torch(device):
+def test_training_step_gradients_match_plain_torch(device, n_pts=1024, height=120, width=160):
     """Config-3 path (DDP training) on one rank: gradients through the custom operators' backward
-    kernels (scatter-add / arg-max / softmax backward) inside the whole network must equal the
+    kernels (inverted-index row sums / arg-max / softmax backward) inside the whole network must equal the
     gradients plain torch autograd produces for the same forward (oracle/forward_ref.py)."""
     from oracle import forward_ref
-    frames = synth.make_batch(7, 2, n_points=1024, height=120, width=160)
-    net = build(5, 1024, device)          # eval(): BatchNorm uses running statistics in both paths
+    frames = synth.make_batch(7, 2, n_points=n_pts, height=height, width=width)
+    net = build(5, n_pts, device)         # eval(): BatchNorm uses running statistics in both paths
     inputs = pyramid.frames_to_device(frames, device)
     names = ["rndla_ds_stages.0.lfa.mlp1.conv.weight", "rndla_ds_stages.2.lfa.att_pooling_1.fc.weight",
              "ds_fuse_r2p_pre_layers.1.conv.weight", "ds_fuse_p2r_pre_layers.0.conv.weight",

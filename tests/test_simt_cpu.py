@@ -264,13 +264,16 @@ def test_posenc_mlp_through_the_real_launcher(emu, B, N, K, cout, dt):
 # ---------------------------------------------------------------------------------------------------------------
 # the whole fused inference forward on the emulator
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_whole_fused_forward_on_the_emulator_matches_the_plain_torch_restatement(emu, precision):
+@pytest.mark.parametrize("precision,n_pts,height,width", [("fp32", 1024, 120, 160), ("bf16", 1024, 120, 160), ("fp32", 1100, 136, 168)])
+def test_whole_fused_forward_on_the_emulator_matches_the_plain_torch_restatement(emu, precision, n_pts, height, width):
     """forward_pm.forward (ffb6d.py:203-337 on point-major rows) with EVERY hand-written kernel of the inference path run
     from its product source on the CPU -- GEMM forms, fused attentive pooling, row gathers / max pooling, fused position
     encoding, BatchNorm glue, pyramid pooling, folded up-convolution -- on a 120x160 frame with 1024 points, the index pyramid
     from the CPU oracle, dense 3x3 convolutions on torch-CPU; against oracle/forward_ref.py: all three outputs and both
-    embeddings after each of the 7 fusion stages, fp32 at the GPU suite's bar (1e-5 of the range), bf16 at its bf16 bars."""
+    embeddings after each of the 7 fusion stages, fp32 at the GPU suite's bar (1e-5 of the range), bf16 at its bf16 bars.
+    The third case is ragged everywhere, like the reference's own default of 12800 points (common.py: 480*640//24 -> levels
+    12800 / 3200 / 800 / 200 / 50): 1100 / 275 / 68 / 17 points and 17 x 21 ... 136 x 168 pixel maps -- no level is a multiple of a
+    tile, a wave or a 16-row group, so every kernel runs its partial-tile paths (buffer range checks, row masks)."""
     import json
     import numpy as np
     from ffb6d_amd import forward_pm, model, synth
@@ -278,14 +281,14 @@ def test_whole_fused_forward_on_the_emulator_matches_the_plain_torch_restatement
     from oracle import knn as oknn
     from oracle import pyramid as opyr
     from conftest import GOLDEN
-    frames = synth.make_batch(9, 1, n_points=1024, height=120, width=160)
+    frames = synth.make_batch(9, 1, n_points=n_pts, height=height, width=width)
     inputs = {"rgb": torch.from_numpy(frames["rgb"]).float(), "cld_rgb_nrm": torch.from_numpy(frames["cld_rgb_nrm"]),
               "choose": torch.from_numpy(frames["choose"]).long()}
     for k, v in opyr.build_batch(frames, oknn.knn_search).items():
         inputs[k] = torch.from_numpy(v.astype(np.int64) if v.dtype == np.int32 else v)
     with open(os.path.join(GOLDEN, "state_dict_keys.json")) as fh:
         sd = synth.synth_state_dict_from_shapes(json.load(fh), seed=0, n_classes=5)
-    net = model.FFB6D(n_classes=5, n_pts=1024)
+    net = model.FFB6D(n_classes=5, n_pts=n_pts)
     net.load_state_dict(sd)
     net.eval()
     net.precision = precision
