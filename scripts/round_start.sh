@@ -18,3 +18,12 @@ cut -c1-260 "$OUT/${TAG}_start_bench_train_fp32.json"
 timeout 300 bash scripts/prof_train.sh --precision bf16 | head -40
 bash scripts/profile_round.sh "${TAG}_start"
 timeout 300 python scripts/train_copy_census.py > "$OUT/${TAG}_train_copy_census.txt" 2>&1; head -30 "$OUT/${TAG}_train_copy_census.txt"
+# the reference's own default geometry (common.py: 12800 points -> 12800 / 3200 / 800 / 200 / 50, ragged against every tile size): parity on the
+# device before it becomes a case of tests/test_forward_gpu.py (round 3 checked the ragged paths on the emulator only)
+timeout 200 python -c "
+import sys; sys.path.insert(0, 'tests')
+import torch, test_forward_gpu as T
+dev = torch.device('cuda:0')
+T.test_hot_path_matches_plain_torch_on_the_same_device(dev, (2, 1, 12800, 480, 640, 22)); print('N=12800 forward parity ok')
+T.test_training_step_gradients_match_plain_torch(dev, n_pts=1100, height=136, width=168); print('ragged training gradients ok')
+" 2>&1 | tail -5
