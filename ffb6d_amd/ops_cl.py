@@ -108,6 +108,8 @@ class _GatherRows(torch.autograd.Function):
         plan = ctx.plan
         B, U, C = g.shape
         g = _act(g)
+        if U == 0:                                           # an empty gather read nothing
+            return torch.zeros((B, plan.m, C), dtype=g.dtype, device=g.device), None
         gr, ld = _rows_ld(g.transpose(1, 2))
         order, start = plan.csr()
         out = torch.empty((B, plan.m, C), dtype=g.dtype, device=g.device)

@@ -213,3 +213,19 @@ def test_gather_backward_with_skewed_reader_counts(device, dt, C):
     assert torch.equal(got[0].float(), want[0])
     assert not got[1][:, :, :3].any()
     close(got[1], want[1], dt, "grad")
+
+
+def test_empty_index_sets(device):
+    """zero outputs: forward shapes, and a zero gradient for the sources (the reference's torch.gather / max formulas do the same)"""
+    feat = cl(torch.randn(2, 16, 9, 1)).to(device).requires_grad_(True)
+    out = ops_cl.nearest_interpolation(feat, torch.zeros(2, 0, 1, dtype=torch.int64, device=device))
+    assert out.shape == (2, 16, 0, 1)
+    out.sum().backward()
+    assert feat.grad.shape == feat.shape and not feat.grad.any()
+    feat.grad = None
+    out = ops_cl.random_sample(feat, torch.zeros(2, 0, 16, dtype=torch.int64, device=device))
+    assert out.shape == (2, 16, 0, 1)
+    out.sum().backward()
+    assert not feat.grad.any()
+    empty = cl(torch.randn(2, 16, 0, 16)).to(device)
+    assert ops_cl.att_pool(empty, empty).shape == (2, 16, 0, 1)
