@@ -264,7 +264,7 @@ def test_posenc_mlp_through_the_real_launcher(emu, B, N, K, cout, dt):
 # ---------------------------------------------------------------------------------------------------------------
 # the whole fused inference forward on the emulator
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision,n_pts,height,width", [("fp32", 1024, 120, 160), ("bf16", 1024, 120, 160), ("fp32", 1100, 136, 168)])
+@pytest.mark.parametrize("precision,n_pts,height,width", [("fp32", 1024, 120, 160), ("bf16", 1024, 120, 160), ("fp32", 1100, 104, 136)])
 def test_whole_fused_forward_on_the_emulator_matches_the_plain_torch_restatement(emu, precision, n_pts, height, width):
     """forward_pm.forward (ffb6d.py:203-337 on point-major rows) with EVERY hand-written kernel of the inference path run
     from its product source on the CPU -- GEMM forms, fused attentive pooling, row gathers / max pooling, fused position
@@ -272,7 +272,7 @@ def test_whole_fused_forward_on_the_emulator_matches_the_plain_torch_restatement
     from the CPU oracle, dense 3x3 convolutions on torch-CPU; against oracle/forward_ref.py: all three outputs and both
     embeddings after each of the 7 fusion stages, fp32 at the GPU suite's bar (1e-5 of the range), bf16 at its bf16 bars.
     The third case is ragged everywhere, like the reference's own default of 12800 points (common.py: 480*640//24 -> levels
-    12800 / 3200 / 800 / 200 / 50): 1100 / 275 / 68 / 17 points and 17 x 21 ... 136 x 168 pixel maps -- no level is a multiple of a
+    12800 / 3200 / 800 / 200 / 50): two frames of 1100 / 275 / 68 / 17 points and 13 x 17 ... 104 x 136 pixel maps -- no level is a multiple of a
     tile, a wave or a 16-row group, so every kernel runs its partial-tile paths (buffer range checks, row masks)."""
     import json
     import numpy as np
