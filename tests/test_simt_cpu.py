@@ -485,7 +485,8 @@ def test_index_pyramid_of_a_frame_on_the_emulator_equals_the_oracle(emu):
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
 
 
-def test_pyramid_builder_with_sets_prepared_together_on_the_emulator(emu):
+@pytest.mark.parametrize("n_pts,height,width", [(4096, 120, 160), (4100, 104, 136)])
+def test_pyramid_builder_with_sets_prepared_together_on_the_emulator(emu, n_pts, height, width):
     """pyramid.PyramidBuilder: the searches planned up front, their Morton-ordered sets prepared together
     (ffb6d_knn_prepare_multi), then level by level -- every tensor equals the CPU oracle's pyramid; the prepared sets are
     byte-identical to sets prepared one by one"""
@@ -494,7 +495,9 @@ def test_pyramid_builder_with_sets_prepared_together_on_the_emulator(emu):
     from ffb6d_amd import pyramid, synth
     from oracle import knn as oknn
     from oracle import pyramid as opyr
-    frames = synth.make_batch(4, 2, n_points=4096, height=120, width=160)      # cloud (4096) and stride-2 grid (4800): pruned searches; the rest scans
+    # cloud (4096) and stride-2 grid (4800): pruned searches, the rest scans; second case: ragged sets (4100 / 1025 / 256 / 64 points,
+    # 52 x 68 ... 13 x 17 grids)
+    frames = synth.make_batch(4, 2, n_points=n_pts, height=height, width=width)
     want = opyr.build_batch(frames, oknn.knn_search)
     got = pyramid.build_index_pyramid(torch.from_numpy(frames['cld']), torch.from_numpy(frames['dpt_xyz']), index_dtype=torch.int32)
     assert sorted(got) == sorted(want)
