@@ -83,6 +83,10 @@ class SharedMLP(nn.Module):
             y = F.conv2d(x, F.pad(self.conv.weight, (0, 0, 0, 0, 0, pad_k)), self.conv.bias)
         else:
             y = self.conv(x)
+        if self.has_bn and y.dim() == 4 and y.is_cuda and os.environ.get("FFB6D_BN_ROWS", "0") == "1":
+            # opt-in (unmeasured): BatchNorm + activation on rows, two passes each way instead of MIOpen's
+            # three launches + the activation's own passes; same statistics, running-stat updates and SyncBatchNorm semantics
+            return ops_cl.batch_norm_act(y, self._bn_module(), self.act_code, 0.2)
         if self.has_bn:
             y = (self.bn if self.flavour == "randla" else self.normlayer)(y)
         return self.activation(y)
