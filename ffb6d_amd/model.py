@@ -182,6 +182,12 @@ class ResBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
+        if x.is_cuda and os.environ.get("FFB6D_BN_ROWS", "0") == "1":          # opt-in, as in SharedMLP.forward
+            y = ops_cl.batch_norm_act(self.conv1(x), self.bn1, ops.ACT_RELU)
+            y = ops_cl.batch_norm_act(self.conv2(y), self.bn2, ops.ACT_NONE)
+            if self.downsample is not None:
+                x = ops_cl.batch_norm_act(self.downsample[0](x), self.downsample[1], ops.ACT_NONE)
+            return F.relu_(y + x)
         y = F.relu_(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         if self.downsample is not None:

@@ -24,7 +24,8 @@ def run(fn, x, bn):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape,act", [((2, 16, 50, 16), 2), ((1, 64, 37, 1), 1), ((3, 24, 5, 7), 0), ((2, 8, 300, 1), 2), ((1, 256, 9, 2), 1)])
+@pytest.mark.parametrize("shape,act", [((2, 16, 50, 16), 2), ((1, 64, 37, 1), 1), ((3, 24, 5, 7), 0), ((2, 8, 300, 1), 2), ((1, 256, 9, 2), 1),
+                                       ((2, 16, 1024, 16), 2)])          # the last: 32768 rows, reductions spread over 64 workgroups
 @pytest.mark.parametrize("training", [True, False])
 def test_batch_norm_act_rows_matches_torch(emu, dt, shape, act, training):
     g = torch.Generator().manual_seed(sum(shape) + act)
@@ -47,8 +48,14 @@ def test_batch_norm_act_rows_matches_torch(emu, dt, shape, act, training):
         assert int(bn.num_batches_tracked) == (1 if training else 0)
     bar = 2e-5 if dt == torch.float32 else 1.5e-2
     for name, a, b in zip(("y", "gx", "gw", "gb", "running_mean", "running_var"), *outs):
-        err = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-12)
-        assert err <= bar, (name, err)
+        rel = (a - b).abs() / (float(a.abs().max()) + 1e-12)
+        if name == "gx":        # a pre-activation within rounding of 0 takes the other branch of the activation's derivative in one of the
+            # two implementations (seen: 1 element of 524288, torch's fp32 against an fp64 reference): a handful of elements may differ
+            # (and their share of the channel's two sums moves the rest of that channel by ~1e-4 when there are 32768 rows)
+            gross = rel > 100 * bar
+            assert int(gross.sum()) <= 3 and float(rel[~gross].max()) <= 10 * bar, (name, int(gross.sum()), float(rel[~gross].max()))
+        else:
+            assert float(rel.max()) <= max(bar, 2e-4 if name in ("gw", "gb") and a.numel() and shape[2] > 500 else bar), (name, float(rel.max()))
 
 
 def test_unsupported_cases_go_to_torch(emu):
@@ -66,4 +73,40 @@ def test_training_step_gradients_with_the_row_batch_norm(emu, monkeypatch):
     real = ops_cl.batch_norm_act
     monkeypatch.setattr(ops_cl, "batch_norm_act", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     TF.test_training_step_gradients_match_plain_torch(torch.device("cpu"))
-    assert len(calls) >= 55                      # the 60 two-dimensional shared MLPs with BatchNorm of one forward
+    assert len(calls) >= 90                      # 60 two-dimensional shared MLPs + 36 BatchNorms of the ResNet blocks, one forward
+
+
+def test_train_mode_network_gradients_equal_the_stock_batch_norm(emu, monkeypatch):
+    """train() mode (batch statistics, dropout with the same seed): the whole network with FFB6D_BN_ROWS=1 against the same network
+    on torch's BatchNorm.  The loss agrees to 1e-5.  The gradients of this synthetic network are ill-conditioned in train mode
+    (ReLU / max-pool decisions flip: scaling the inputs by 1 + 1e-6 moves them by 1.5 - 3 % of their range), so the yardstick is
+    that sensitivity, measured in the test: the row BatchNorm may differ from the stock one by at most 3x what the 1e-6
+    perturbation does to the stock one, per parameter; running statistics after the step agree to 1e-5."""
+    import test_forward_gpu as TF
+    from ffb6d_amd import pyramid, synth
+    frames = synth.make_batch(7, 2, n_points=1024, height=120, width=160)
+    inputs = pyramid.frames_to_device(frames, torch.device("cpu"))
+    names = ["rndla_ds_stages.0.lfa.mlp1.conv.weight", "rndla_ds_stages.2.lfa.att_pooling_1.mlp.bn.bn.weight", "cnn_ds_stages.1.2.bn2.bias",
+             "ds_fuse_r2p_pre_layers.1.conv.weight", "up_fuse_p2r_fuse_layers.0.normlayer.bn.weight", "cnn_ds_stages.0.0.conv1.weight"]
+    outs = []
+    for flag, eps in (("0", 0.0), ("0", 1e-6), ("1", 0.0)):
+        monkeypatch.setenv("FFB6D_BN_ROWS", flag)
+        net = TF.build(5, 1024, torch.device("cpu")).train()
+        params = dict(net.named_parameters())
+        torch.manual_seed(11)
+        inp = dict(inputs, rgb=inputs["rgb"] * (1.0 + eps), cld_rgb_nrm=inputs["cld_rgb_nrm"] * (1.0 + eps))
+        loss = sum((v.float() ** 2).mean() for v in net(inp).values())
+        loss.backward()
+        stats = dict(net.named_buffers())
+        outs.append((float(loss.detach()), {n: params[n].grad.clone() for n in names},
+                     {n: stats[n].clone() for n in ("rndla_ds_stages.1.mlp2.bn.bn.running_var", "cnn_ds_stages.2.0.3.bn1.running_mean")}))
+    (l0, g0, s0), (_, gp, _), (l1, g1, s1) = outs
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    for n in names:
+        scale = float(g0[n].abs().max())
+        noise = float((gp[n] - g0[n]).abs().max()) / scale
+        err = float((g1[n] - g0[n]).abs().max()) / scale
+        print(n, "row BatchNorm vs stock %.3g, 1e-6 input perturbation of stock %.3g" % (err, noise))
+        assert err <= 3.0 * noise + 1e-4, (n, err, noise)
+    for n in s0:
+        torch.testing.assert_close(s1[n], s0[n], rtol=1e-5, atol=1e-6)
