@@ -302,6 +302,8 @@ class UpBlock(nn.Module):
         # (csrc/train_ops.hip: gather instead of ATen's atomic scatter; slope gradient reduced in the kernel)
         _, conv, bn, prelu = self.conv
         y = ops.upsample_align(x, (2 * x.shape[2], 2 * x.shape[3]))
+        if os.environ.get("FFB6D_BN_ROWS", "0") == "1":                      # opt-in, as in SharedMLP.forward
+            return ops.prelu(ops_cl.batch_norm_act(conv(y), bn, ops.ACT_NONE), prelu.weight)
         return ops.prelu(bn(conv(y)), prelu.weight)
 
 

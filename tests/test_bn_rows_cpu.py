@@ -73,7 +73,7 @@ def test_training_step_gradients_with_the_row_batch_norm(emu, monkeypatch):
     real = ops_cl.batch_norm_act
     monkeypatch.setattr(ops_cl, "batch_norm_act", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     TF.test_training_step_gradients_match_plain_torch(torch.device("cpu"))
-    assert len(calls) >= 90                      # 60 two-dimensional shared MLPs + 36 BatchNorms of the ResNet blocks, one forward
+    assert len(calls) >= 93                      # 60 two-dimensional shared MLPs + 36 BatchNorms of the ResNet blocks + 3 of the PSPUpsample blocks, one forward
 
 
 def test_train_mode_network_gradients_equal_the_stock_batch_norm(emu, monkeypatch):
