@@ -28,6 +28,7 @@
 // sums are fp32.  Only the max-pool backward still uses float atomics (0.5 ms per step; its fp32 accumulator is rounded to the
 // activation type by the caller).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "ffb6d_ops.h"
@@ -40,7 +41,39 @@ constexpr int BLK = 256;
 
 __device__ __forceinline__ bool wins(float v, float m) { return v > m || (v != v && m == m); }     // torch.max: NaN beats numbers
 
-// out[r, :] = sum over j in [start[r], start[r+1]) of g[order[j], :].
+// out[r, :] = sum over j in [start[r], start[r+1]) of g[order[j], :];  thread = (destination row r, unit), four rows in flight
+template <typename T>
+__global__ void __launch_bounds__(BLK)
+gather_sum_rows_kernel(const void* __restrict__ g, int ldq /* ldg / VL */, const int64_t* __restrict__ order,
+                       const int64_t* __restrict__ start, void* __restrict__ out, int q, size_t total /* R*q */)
+{
+    using RU = RowUnit<T>;
+    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (t >= total) return;
+    const size_t r = t / q;
+    const int c = (int)(t - r * q);
+    int64_t j = start[r];
+    const int64_t j1 = start[r + 1];
+    RU acc;
+#pragma unroll
+    for (int e = 0; e < RU::VL; ++e) acc.v[e] = 0.f;
+    for (; j + 4 <= j1; j += 4) {
+        const int64_t u0 = order[j], u1 = order[j + 1], u2 = order[j + 2], u3 = order[j + 3];
+        const RU a = RU::load(g, (size_t)u0 * ldq + c), b = RU::load(g, (size_t)u1 * ldq + c);
+        const RU d = RU::load(g, (size_t)u2 * ldq + c), f = RU::load(g, (size_t)u3 * ldq + c);
+#pragma unroll
+        for (int e = 0; e < RU::VL; ++e) acc.v[e] += (a.v[e] + b.v[e]) + (d.v[e] + f.v[e]);
+    }
+    for (; j < j1; ++j) {
+        const RU a = RU::load(g, (size_t)order[j] * ldq + c);
+#pragma unroll
+        for (int e = 0; e < RU::VL; ++e) acc.v[e] += a.v[e];
+    }
+    acc.store(out, t);
+}
+
+// The same sum with several lanes per (row, unit) -- FFB6D_GATHER_SUM_LANES=1; written after round 3's last GPU call, so the default is
+// the form above, which that round ran and measured (111 us per call, 527 GB/s algorithmic: dependent-load latency at ~3 waves per SIMD).
 // A destination row has ~K readers (16 on average for the neighbour gathers, up to ~60) and only q = C / VL units: with one lane per
 // unit the 16-byte loads of a row's readers would be issued one after the other by 2 .. 16 lanes.  Here L = 2^LOG_L lanes share a
 // (row, unit): lane l adds readers l, l + L, ... (independent loads, all in flight), a butterfly over the L lanes finishes the sum.
@@ -48,8 +81,8 @@ __device__ __forceinline__ bool wins(float v, float m) { return v > m || (v != v
 // segment), then l.  L * q <= 64, groups never straddle a wave; lanes past the end stay in the shuffles and skip the store.
 template <typename T>
 __global__ void __launch_bounds__(BLK)
-gather_sum_rows_kernel(const void* __restrict__ g, int ldq /* ldg / VL */, const int64_t* __restrict__ order,
-                       const int64_t* __restrict__ start, void* __restrict__ out, int q, int log_l, size_t total /* R * L * q */)
+gather_sum_rows_lanes_kernel(const void* __restrict__ g, int ldq /* ldg / VL */, const int64_t* __restrict__ order,
+                             const int64_t* __restrict__ start, void* __restrict__ out, int q, int log_l, size_t total /* R * L * q */)
 {
     using RU = RowUnit<T>;
     const int L = 1 << log_l;
@@ -436,16 +469,25 @@ extern "C" int ffb6d_gather_sum_rows(int dtype, const void* g, int64_t ldg, cons
     FFB6D_REQUIRE(g && order && start && out && al16(g) && al16(out), "gather_sum_rows: null or unaligned pointer");
     FFB6D_REQUIRE(ldg / VL < (1LL << 31), "gather_sum_rows: too large");
     const int q = (int)(C / VL);
-    // lanes per (row, unit): as many as fit a wave next to the q units, at most 8 (readers per row: ~16); needs q to be a power of
-    // two (the butterfly's lane distances), else one lane per unit
-    int log_l = 0;
-    if ((q & (q - 1)) == 0)
-        while (log_l < 3 && (q << (log_l + 1)) <= 64) ++log_l;
-    const size_t total = ((size_t)R * q) << log_l;
-    FFB6D_ROWS_DT(dtype, T, {
-        hipLaunchKernelGGL((gather_sum_rows_kernel<T>), dim3(blocks_for(total)), dim3(BLK), 0, as_stream(stream), g, (int)(ldg / VL), order,
-                           start, out, q, log_l, total);
-    });
+    const char* lanes = getenv("FFB6D_GATHER_SUM_LANES");
+    if (lanes && lanes[0] == '1') {
+        // lanes per (row, unit): as many as fit a wave next to the q units, at most 8 (readers per row: ~16); needs q to be a power
+        // of two (the butterfly's lane distances), else one lane per unit
+        int log_l = 0;
+        if ((q & (q - 1)) == 0)
+            while (log_l < 3 && (q << (log_l + 1)) <= 64) ++log_l;
+        const size_t total = ((size_t)R * q) << log_l;
+        FFB6D_ROWS_DT(dtype, T, {
+            hipLaunchKernelGGL((gather_sum_rows_lanes_kernel<T>), dim3(blocks_for(total)), dim3(BLK), 0, as_stream(stream), g, (int)(ldg / VL),
+                               order, start, out, q, log_l, total);
+        });
+    } else {
+        const size_t total = (size_t)R * q;
+        FFB6D_ROWS_DT(dtype, T, {
+            hipLaunchKernelGGL((gather_sum_rows_kernel<T>), dim3(blocks_for(total)), dim3(BLK), 0, as_stream(stream), g, (int)(ldg / VL), order,
+                               start, out, q, total);
+        });
+    }
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }

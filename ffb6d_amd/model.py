@@ -316,7 +316,11 @@ class FinalHead(nn.Sequential):
 
     def forward(self, x):
         y = self[0](x)
-        return ops_cl.channel_log_softmax(y) if y.is_cuda else self[1](y)      # same operator on rows, in the map's own dtype
+        if y.is_cuda and os.environ.get("FFB6D_LOGSOFTMAX_ROWS", "0") == "1":
+            # opt-in until it has run on the device (written after round 3's last GPU call): the same operator on rows, in the
+            # map's own dtype -- under autocast ATen's log_softmax is an fp32 operator
+            return ops_cl.channel_log_softmax(y)
+        return self[1](y)
 
 
 def _head(cin, cout):

@@ -27,4 +27,5 @@ dev = torch.device('cuda:0')
 T.test_hot_path_matches_plain_torch_on_the_same_device(dev, (2, 1, 12800, 480, 640, 22)); print('N=12800 forward parity ok')
 T.test_training_step_gradients_match_plain_torch(dev, n_pts=1100, height=136, width=168); print('ragged training gradients ok')
 " 2>&1 | tail -5
-FFB6D_BN_ROWS=1 timeout 400 python bench.py --mode train --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline --cudnn-benchmark 0 > "$OUT/${TAG}_start_bench_train_bf16_bn_rows.json" 2> /dev/null; cut -c1-200 "$OUT/${TAG}_start_bench_train_bf16_bn_rows.json"   # A/B of the opt-in BatchNorm on rows
+FFB6D_LOGSOFTMAX_ROWS=1 FFB6D_GATHER_SUM_LANES=1 timeout 400 python bench.py --mode train --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline --cudnn-benchmark 0 > "$OUT/${TAG}_start_bench_train_bf16_optin.json" 2> /dev/null; cut -c1-200 "$OUT/${TAG}_start_bench_train_bf16_optin.json"   # A/B of the row LogSoftmax + multi-lane gather backward
+FFB6D_LOGSOFTMAX_ROWS=1 FFB6D_GATHER_SUM_LANES=1 FFB6D_BN_ROWS=1 timeout 400 python bench.py --mode train --precision bf16 --steps 8 --warmup 3 --no-cpu-baseline --cudnn-benchmark 0 > "$OUT/${TAG}_start_bench_train_bf16_bn_rows.json" 2> /dev/null; cut -c1-200 "$OUT/${TAG}_start_bench_train_bf16_bn_rows.json"   # A/B of the opt-in BatchNorm on rows

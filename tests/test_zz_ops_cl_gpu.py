@@ -1,6 +1,8 @@
 """Channels-last training operators (ffb6d_amd/ops_cl.py, csrc/train_rows.hip) against plain torch on the reference's own
 formulas (ffb6d.py:159-194, RandLANet.py:216-250): forward values and the gradients autograd derives for the torch formulas.
-float32: 1e-5 of range (float atomics reorder sums); bfloat16 rows: one bf16 rounding of the result (2^-8 relative)."""
+float32: 1e-5 of range (float atomics reorder sums); bfloat16 rows: one bf16 rounding of the result (2^-8 relative).
+(Named to run after the other GPU test files: it also holds the cases of the forms written after round 3's last GPU call -- row
+LogSoftmax, multi-lane gather backward -- which the device has not executed yet.)"""
 import pytest
 import torch
 
@@ -198,9 +200,11 @@ def test_gather_neighbour_with_the_reference_signature_on_rows(device, dt):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C", [8, 24, 64, 256, 512])
-def test_gather_backward_with_skewed_reader_counts(device, dt, C):
+@pytest.mark.parametrize("lanes", ["0", "1"])
+def test_gather_backward_with_skewed_reader_counts(device, dt, C, lanes, monkeypatch):
     """gather_sum_rows: 1 .. 8 lanes share a (destination row, unit) depending on C (butterfly reduction), rows with no reader at
     all, one row read by a third of the outputs, odd list lengths -- against torch's scatter-add of the same gradient"""
+    monkeypatch.setenv("FFB6D_GATHER_SUM_LANES", lanes)      # 0: one lane per unit (default); 1: the multi-lane form
     B, M, U = 2, 37, 301
     g = torch.Generator().manual_seed(C)
     idx = torch.randint(3, M, (B, U), generator=g)          # rows 0..2 have no reader
