@@ -47,15 +47,39 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _stale(obj, src, headers):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + headers)
+
+
 def build(force=False, verbose=True):
+    """One object per source (recompiled only when the source or a header is newer), compiled in parallel, then linked."""
     if not force and not needs_build():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc_path()] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    cmd += sources() + ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print("[ffb6d_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    headers.append(os.path.abspath(__file__))
+    base = [hipcc_path()] + [f for f in FLAGS if f != "-shared"] + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    jobs = []
+    for src in sources():
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        if force or _stale(obj, src, headers):
+            jobs.append(base + ["-c", src, "-o", obj])
+    if verbose and jobs:
+        print("[ffb6d_amd.build] compiling", " ".join(os.path.basename(j[-3]) for j in jobs), flush=True)
+
+    def run(cmd):
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        list(pool.map(run, jobs))
+    objs = [os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o") for src in sources()]
+    subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + ".tmp"], check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 
