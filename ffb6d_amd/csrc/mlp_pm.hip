@@ -62,6 +62,7 @@ struct PmParams {
     int P, py, px;        // output rows per frame (for the gathers), rows of Y / of X1 per frame
     int act, idx64;
     int n_pt, n_ct;       // point tiles, channel tiles
+    int gc_cap;           // persistent form: channel tiles per block of the XCD walk (launcher: 8 unless a hint overrides it)
 };
 
 // epilogue shared by the GEMM kernels: bias, gathered / added row of Y, activation or log-softmax, store
@@ -759,7 +760,7 @@ mlp_pm_lds_persist_kernel(const PmParams p)
     const int pt_lo = (p.n_pt * xcd) >> 3, npt_x = ((p.n_pt * (xcd + 1)) >> 3) - pt_lo;
     const int ntile_x = npt_x * p.n_ct;
     if (slot >= ntile_x) return;
-    const int GC = min(p.n_ct, 8), GP = 64 / GC;
+    const int GC = min(p.n_ct, p.gc_cap), GP = max(64 / GC, 1);
     const int band = GP * p.n_ct;                     // tiles of a full band of GP point tiles
     auto coords = [&](int idx, int& pt, int& ct) {
         const int pb = min(idx / band, (npt_x - 1) / GP);
@@ -1094,8 +1095,9 @@ void launch_lds(PmParams& p, hipStream_t st)
 }
 
 template <typename T>
-void launch_lds_persist(PmParams& p, hipStream_t st, int spx_cap)
+void launch_lds_persist(PmParams& p, hipStream_t st, int spx_cap, int gc_cap)
 {
+    p.gc_cap = gc_cap > 0 ? gc_cap : 8;
     p.n_ct = (int)ceil_div(p.cout, 128);
     p.n_pt = (int)ceil_div(p.rows, 128);
     constexpr size_t lds = 2 * 2 * 128 * (128 + 16);
@@ -1199,8 +1201,9 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
     p.ldy = (int)ldy; p.ldo = (int)ldo; p.P = (int)(indexed ? rows_per_frame : rows); p.py = (int)y_rows_per_frame;
     p.px = (int)x1_rows_per_frame; p.act = act;
     p.idx64 = idx_bits == 64;
+    p.gc_cap = 8;
     hipStream_t st = as_stream(stream);
-    int choice = tile_hint & 0xff;                  // bits 8.. of a hint: cap on the persistent form's workgroups per XCD (tests)
+    int choice = tile_hint & 0xff;                  // hint bits 8..15 / 16..23: persistent form's workgroups per XCD / channel tiles per block (tests, probes)
     if (tile_hint <= 0) {
         choice = ffb6d_mlp_pm_choice(rows, cout, k1, k2, act, SZ == 2, x1_idx != nullptr);
         if (choice == 6 && !stream_form_ok<T>(p, K)) choice = ffb6d_mlp_pm_tile(rows, cout, K, act);      // misaligned rows
@@ -1254,7 +1257,7 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
             FFB6D_REQUIRE(act != 3 && (K * SZ) % 128 == 0 && (k1 * SZ) % 128 == 0,
                           "mlp_pm: the LDS-tiled form has no log_softmax epilogue and needs k1 * %d and K * %d to be multiples of 128", SZ, SZ);
             FFB6D_REQUIRE(epilogue_vec_ok<T>(p), "mlp_pm: the persistent LDS-tiled form needs cout, ldo, ldy multiples of 4 and aligned rows");
-            launch_lds_persist<T>(p, st, tile_hint > 0 ? tile_hint >> 8 : 0);
+            launch_lds_persist<T>(p, st, tile_hint > 0 ? (tile_hint >> 8) & 0xff : 0, tile_hint > 0 ? (tile_hint >> 16) & 0xff : 0);
             break;
         default: return set_error(FFB6D_ERR_ARG, "mlp_pm: unknown tile_hint %d", tile_hint);
     }

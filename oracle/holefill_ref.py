@@ -49,6 +49,47 @@ def bilateral5(img, sigma_color, sigma_space):
     return (num / den).astype(np.float32)
 
 
+def bilateral5_opencv(img, sigma_color, sigma_space):
+    """cv2.bilateralFilter(img, 5, sigma_color, sigma_space) for one float32 channel as OpenCV 4's bilateralFilter_32f computes it
+    (modules/imgproc/src/bilateral_filter.dispatch.cpp / .simd.hpp): the colour weight comes from a table of
+    kExpNumBinsPerChannel = 4096 bins over the image's value range, linearly interpolated; spatial weights exp(r^2 * coeff) over the
+    13 taps with r <= 2 in row-major order; BORDER_REFLECT_101; a constant image is returned unchanged.  Restated from the published
+    source, NOT executed against cv2 (absent here): `bilateral5` above is the same filter with the exact exponential, and
+    tests/test_f4_pin_cpu.py bounds the difference between the two forms."""
+    img = np.asarray(img, np.float32)
+    H, W = img.shape
+    lo, hi = float(img.min()), float(img.max())
+    if abs(lo - hi) < np.finfo(np.float32).eps:
+        return img.copy()
+    gcc, gsc = -0.5 / (float(sigma_color) * float(sigma_color)), -0.5 / (float(sigma_space) * float(sigma_space))
+    nbins = 1 << 12
+    scale_index = np.float32(nbins / np.float32(hi - lo))
+    lut = np.zeros(nbins + 2, np.float32)
+    last = 1.0
+    for i in range(nbins + 2):
+        if last > 0.0:
+            val = i / float(scale_index)
+            lut[i] = np.float32(np.exp(val * val * gcc))
+            last = float(lut[i])
+    pad = np.pad(img, 2, mode='reflect')
+    num = np.zeros_like(img)
+    den = np.zeros_like(img)
+    for dy in range(-2, 3):
+        for dx in range(-2, 3):
+            r = np.sqrt(float(dy * dy + dx * dx))
+            if r > 2:
+                continue
+            sw = np.float32(np.exp(r * r * gsc))
+            v = pad[2 + dy:2 + dy + H, 2 + dx:2 + dx + W]
+            alpha = (np.abs(v - img) * scale_index).astype(np.float32)
+            idx = np.floor(alpha).astype(np.int64)
+            alpha = (alpha - idx.astype(np.float32)).astype(np.float32)
+            w = (sw * (lut[idx] + alpha * (lut[idx + 1] - lut[idx]))).astype(np.float32)
+            num = (num + v * w).astype(np.float32)
+            den = (den + w).astype(np.float32)
+    return (num / den).astype(np.float32)
+
+
 def top_mask(img):
     """:366-369 / :384-390: True at and below the first valid pixel of each column (all True when the column has none)."""
     top = np.argmax(img > EPS, axis=0)

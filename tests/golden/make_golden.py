@@ -75,7 +75,10 @@ def make_knn():
 
     hashes = {}
     for tag, config, sample, n_points in (("c2_s0_n12288", 2, 0, 12288), ("c2_s1_n12288", 2, 1, 12288),
-                                          ("c4_s0_n24576", 4, 0, 24576)):
+                                          ("c4_s0_n24576", 4, 0, 24576),
+                                          # the reference's own default: common.py:61 n_sample_points = 12800 ->
+                                          # 12800 / 3200 / 800 / 200 / 50 points, ragged against every tile size
+                                          ("c2_s0_n12800", 2, 0, 12800)):
         f = synth.make_frame(synth.frame_seed(config, sample), n_points=n_points)
         pyr = opyr.build_pyramid(f['cld'], f['dpt_xyz'], ref_knn_search)
         entry = {"config": config, "sample": sample, "n_points": n_points,

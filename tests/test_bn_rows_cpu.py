@@ -72,7 +72,7 @@ def test_training_step_gradients_with_the_row_batch_norm(emu, monkeypatch):
     calls = []
     real = ops_cl.batch_norm_act
     monkeypatch.setattr(ops_cl, "batch_norm_act", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
-    TF.test_training_step_gradients_match_plain_torch(torch.device("cpu"))
+    TF.test_training_step_gradients_match_plain_torch(torch.device("cpu"), n_pts=1024, height=120, width=160)
     assert len(calls) >= 93                      # 60 two-dimensional shared MLPs + 36 BatchNorms of the ResNet blocks + 3 of the PSPUpsample blocks, one forward
 
 

@@ -61,9 +61,12 @@ def oracle_on_device(net, inputs):
         return forward_ref.ffb6d_forward(sd, {k: (v.long() if v.dtype == torch.int32 else v) for k, v in inputs.items()})
 
 
-# the last two are the benchmarked configurations (BASELINE.json configs 2 and 4: bs=8, N=12288 / N=24576)
+# (2, 8, ...) and (4, 8, ...) are the benchmarked configurations (BASELINE.json configs 2 and 4: bs=8, N=12288 / N=24576); N=12800 is
+# the reference's own default geometry (common.py:61 n_sample_points -> 12800 / 3200 / 800 / 200 / 50 points, ragged against every
+# tile size of the hand-written kernels), at one frame and at the benchmarked batch; 1100 points on 136 x 168 is the small ragged case
 @pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (1, 1, 12288, 480, 640, 22), (4, 1, 24576, 480, 640, 22),
-                                 (2, 8, 12288, 480, 640, 22), (4, 8, 24576, 480, 640, 22)])
+                                 (2, 8, 12288, 480, 640, 22), (4, 8, 24576, 480, 640, 22),
+                                 (2, 1, 12800, 480, 640, 22), (2, 8, 12800, 480, 640, 22), (7, 3, 1100, 136, 168, 5)])
 def test_hot_path_matches_plain_torch_on_the_same_device(device, cfg):
     config, bs, n_pts, h, w, n_cls = cfg
     frames = synth.make_batch(config, bs, n_points=n_pts, height=h, width=w)
@@ -76,7 +79,7 @@ def test_hot_path_matches_plain_torch_on_the_same_device(device, cfg):
         assert_close_scaled(ep[k].cpu().numpy(), ref[k].cpu().numpy(), HOT_TOL, (cfg, k))
 
 
-@pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (1, 2, 12288, 480, 640, 22)])
+@pytest.mark.parametrize("cfg", [(7, 2, 1024, 120, 160, 5), (1, 2, 12288, 480, 640, 22), (2, 2, 12800, 480, 640, 22)])
 def test_every_fusion_stage_matches_plain_torch(device, cfg):
     """Stage-level parity of the fused point-major path: both embeddings after each of the 4 encoder and 3 decoder
     fusion stages (ffb6d.py:245-263,281-298) against the plain-torch restatement on the same device, each on the
@@ -298,7 +301,8 @@ def test_batch_items_are_independent(device):
         assert float((full[k][1:2] - single[k]).abs().max()) <= 1e-3 * scale, k
 
 
-def test_training_step_gradients_match_plain_torch(device, n_pts=1024, height=120, width=160):
+@pytest.mark.parametrize("n_pts,height,width", [(1024, 120, 160), (1100, 136, 168)])      # the second: ragged against every tile size
+def test_training_step_gradients_match_plain_torch(device, n_pts, height, width):
     """Config-3 path (DDP training) on one rank: gradients through the custom operators' backward
     kernels (inverted-index row sums / arg-max / softmax backward) inside the whole network must equal the
     gradients plain torch autograd produces for the same forward (oracle/forward_ref.py)."""

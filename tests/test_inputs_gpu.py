@@ -152,3 +152,29 @@ def test_fill_missing_matches_the_restatement(device):
                                holefill_ref.fill_missing(d_mm, 1000.0, 2.0, max_depth=6.0), rtol=1e-5, atol=0)
     with pytest.raises(Exception):
         inputs.fill_missing(torch.zeros(1, 4, 4, device=device), 1000.0)
+
+
+def test_f4_kernels_reproduce_the_committed_vectors(device):
+    """tests/golden/f4_vectors.npz (made by tests/golden/make_golden_f4.py from the restatements that tests/test_f4_pin_cpu.py checks
+    primitive by primitive and against analytic planes / spheres): normals bit exact, filled depth within 1e-5 (the bilateral blur's
+    exponential), also against the table-interpolated form OpenCV's float path uses"""
+    import os
+    from conftest import GOLDEN
+    from oracle import holefill_ref
+    g = np.load(os.path.join(GOLDEN, "f4_vectors.npz"))
+    n_cases = 0
+    for k in [k for k in g.files if k.endswith("/depth_mm")]:
+        tag = k.split("/")[0]
+        fx, fy = (float(v) for v in g[tag + "/fxfy"])
+        got = inputs.depth_normal(torch.from_numpy(g[k]).to(device), fx, fy, 5, 2000, 20, False)
+        np.testing.assert_array_equal(got.permute(1, 2, 0).cpu().numpy(), g[tag + "/normals"])
+        n_cases += 1
+    for k in [k for k in g.files if k.endswith("/depth_raw")]:
+        tag = k.split("/")[0]
+        raw = g[k].astype(np.float32)
+        got = inputs.fill_missing(torch.from_numpy(raw).to(device), float(g[tag + "/cam_scale"]), 1).cpu().numpy()
+        want = g[tag + "/filled"]
+        assert ((got > 0) == (want > 0)).all()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+        n_cases += 1
+    assert n_cases == 6

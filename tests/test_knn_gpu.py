@@ -101,7 +101,7 @@ def test_invalid_pixels_at_origin(device):
         np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("tag", ["c2_s0_n12288", "c2_s1_n12288", "c4_s0_n24576"])
+@pytest.mark.parametrize("tag", ["c2_s0_n12288", "c2_s1_n12288", "c4_s0_n24576", "c2_s0_n12800"])
 def test_full_size_pyramid_matches_reference_hashes(device, tag):
     """All 26 index tensors of a 480x640 frame, bit-exact against what the reference's own
     nanoflann produced (hashes committed by tests/golden/make_golden.py)."""
