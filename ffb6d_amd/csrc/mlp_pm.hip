@@ -63,6 +63,7 @@ struct PmParams {
     int act, idx64;
     int n_pt, n_ct;       // point tiles, channel tiles
     int gc_cap;           // persistent form: channel tiles per block of the XCD walk (launcher: 8 unless a hint overrides it)
+    int probe;            // persistent form, hint bits 24..27 (scripts/gemm_persist_probe.py): 1..3 = start spread, 4 = fragment-shaped epilogue, 8 = none
 };
 
 // epilogue shared by the GEMM kernels: bias, gathered / added row of Y, activation or log-softmax, store
@@ -760,6 +761,17 @@ mlp_pm_lds_persist_kernel(const PmParams p)
     const int pt_lo = (p.n_pt * xcd) >> 3, npt_x = ((p.n_pt * (xcd + 1)) >> 3) - pt_lo;
     const int ntile_x = npt_x * p.n_ct;
     if (slot >= ntile_x) return;
+    if (p.probe & 3) {
+        // All workgroups of the launch multiply tiles of one size at one rate: left alone they reach their epilogues TOGETHER, the whole
+        // chip alternates between a phase without stores and a 32 MB burst of them (512 tiles x 64 KB), and since a wave's stores sit in
+        // the same in-order memory counter as its operand loads, every workgroup waits for the burst to drain.  Spreading the start of
+        // the workgroups over a fraction of a tile period turns the bursts into a steady write stream.
+        const int kbytes = (p.k1 + p.k2) * El<T>::SZ;
+        const int period = 2 * (kbytes / 128) * 4096;                        // cycles of a tile with the CU's matrix pipe shared by two workgroups
+        const int span = min(period, 4096 << (p.probe & 3));                 // 8 k / 16 k / 32 k cycles
+        const int ticks = (int)(((unsigned)slot * 2654435769u >> 16) * (unsigned)(span >> 6) >> 16);      // golden-ratio spread, units of 64 cycles
+        for (int i = 0; i < ticks; i += 8) __builtin_amdgcn_s_sleep(8);
+    }
     const int GC = min(p.n_ct, p.gc_cap), GP = max(64 / GC, 1);
     const int band = GP * p.n_ct;                     // tiles of a full band of GP point tiles
     auto coords = [&](int idx, int& pt, int& ct) {
@@ -884,6 +896,71 @@ mlp_pm_lds_persist_kernel(const PmParams p)
         }
     };
 
+    // Epilogue in WHOLE ROWS.  pm_epilogue stores MFMA fragments: one instruction touches 64 rows x 16 bytes (64 tag look-ups per
+    // KB, 32-byte write requests), and the gathered rows of Y are fetched the same way -- measured 2.5 us per tile without and 5 us
+    // with a gathered row, none of it hidden behind the CU's other workgroup (profiles/r04_gemm_pair_probe_fp32.txt: `noepi`).
+    // Here the finished tile goes through the LDS stage that has just been multiplied (free until the next park): two passes of
+    // 64 points x 128 channels (pass j = accumulator tiles [*][j] of every wave), fp32, row stride 528 bytes (an odd multiple of 16:
+    // conflict-free both ways); then a thread owns 4 consecutive channels of 8 rows per pass: one instruction reads, adds the
+    // gathered / added Y rows to and stores TWO whole 512-byte rows.  Same sums in the same order as pm_epilogue: identical results.
+    auto row_epilogue = [&](int c0, int r0, int stage) {
+        constexpr int ORS = 128 + 4;                                  // floats per staged row
+        float* const img = reinterpret_cast<float*>(lds + stage * 2 * IMG);
+        const T* const yb = static_cast<const T*>(p.y);
+        T* const ob = static_cast<T*>(p.out);
+        const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
+        const int chunk = threadIdx.x & 31, rsub = threadIdx.x >> 5;
+        const int ch = c0 + 4 * chunk;
+        const bool ch_ok = ch < p.cout;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && ch_ok) b4 = *reinterpret_cast<const float4*>(p.bias + ch);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // this thread's 8 rows of the pass: staged row rho = rsub + 8 q -> output row r0 + 64 (rho >> 5) + 32 j + (rho & 31)
+            int orow[8];
+            long long yr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int rho = rsub + 8 * q;
+                const int r = r0 + 64 * (rho >> 5) + 32 * j + (rho & 31);
+                orow[q] = r < p.rows && ch_ok ? r : -1;
+                yr[q] = r;
+                if (yb && p.gidx && orow[q] >= 0) {
+                    const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[r] : (long long)static_cast<const int*>(p.gidx)[r];
+                    yr[q] = (long long)(r / p.P) * p.py + gi;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(img + (wn * 32 + l31) * ORS + wm * 64 + i * 32 + 8 * g + 4 * kh) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                               // four rows at a time: loads first, then the arithmetic
+                float4 y4[4], v4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    y4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (yb && orow[4 * h + q] >= 0) y4[q] = El<T>::ld4(yb + yr[4 * h + q] * p.ldy + ch);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const float4*>(img + (rsub + 8 * (4 * h + q)) * ORS + 4 * chunk);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = v4[q];
+                    if (p.bias) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+                    if (yb) { v.x += y4[q].x; v.y += y4[q].y; v.z += y4[q].z; v.w += y4[q].w; }
+                    if (orow[4 * h + q] >= 0)
+                        El<T>::st4(ob + (size_t)orow[4 * h + q] * p.ldo + ch,
+                                   make_float4(activate(v.x, slope), activate(v.y, slope), activate(v.z, slope), activate(v.w, slope)));
+                }
+            }
+            __syncthreads();
+        }
+    };
+
     // compute cursor
     int cq = slot, cs = 0, c0, r0;
     {
@@ -904,7 +981,12 @@ mlp_pm_lds_persist_kernel(const PmParams p)
     __syncthreads();                                                 \
     par ^= 1;                                                        \
     if (++cs == nstage) {                                            \
-        pm_epilogue<T, 2, 2, false, true>(p, acc, c0, r0, wm, wn, l31, kh); \
+        if (p.probe & 8) {            /* PROBE ONLY: no epilogue (timing of the bare operand stream + MFMA) */ \
+            for (int i_ = 0; i_ < 2; ++i_) for (int j_ = 0; j_ < 2; ++j_) FFB6D_KEEP_LIVE(acc[i_][j_]); \
+        } else if (p.probe & 4) {     /* PROBE: the fragment-shaped epilogue of the tile kernels */ \
+            pm_epilogue<T, 2, 2, false, true>(p, acc, c0, r0, wm, wn, l31, kh); \
+        } else                                                       \
+            row_epilogue(c0, r0, par ^ 1);                           \
         cs = 0;                                                      \
         cq += spx;                                                   \
         if (cq >= ntile_x) break;                                    \
@@ -1095,9 +1177,10 @@ void launch_lds(PmParams& p, hipStream_t st)
 }
 
 template <typename T>
-void launch_lds_persist(PmParams& p, hipStream_t st, int spx_cap, int gc_cap)
+void launch_lds_persist(PmParams& p, hipStream_t st, int spx_cap, int gc_cap, int probe)
 {
     p.gc_cap = gc_cap > 0 ? gc_cap : 8;
+    p.probe = probe;
     p.n_ct = (int)ceil_div(p.cout, 128);
     p.n_pt = (int)ceil_div(p.rows, 128);
     constexpr size_t lds = 2 * 2 * 128 * (128 + 16);
@@ -1202,6 +1285,7 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
     p.px = (int)x1_rows_per_frame; p.act = act;
     p.idx64 = idx_bits == 64;
     p.gc_cap = 8;
+    p.probe = 0;
     hipStream_t st = as_stream(stream);
     int choice = tile_hint & 0xff;                  // hint bits 8..15 / 16..23: persistent form's workgroups per XCD / channel tiles per block (tests, probes)
     if (tile_hint <= 0) {
@@ -1257,7 +1341,8 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
             FFB6D_REQUIRE(act != 3 && (K * SZ) % 128 == 0 && (k1 * SZ) % 128 == 0,
                           "mlp_pm: the LDS-tiled form has no log_softmax epilogue and needs k1 * %d and K * %d to be multiples of 128", SZ, SZ);
             FFB6D_REQUIRE(epilogue_vec_ok<T>(p), "mlp_pm: the persistent LDS-tiled form needs cout, ldo, ldy multiples of 4 and aligned rows");
-            launch_lds_persist<T>(p, st, tile_hint > 0 ? (tile_hint >> 8) & 0xff : 0, tile_hint > 0 ? (tile_hint >> 16) & 0xff : 0);
+            launch_lds_persist<T>(p, st, tile_hint > 0 ? (tile_hint >> 8) & 0xff : 0, tile_hint > 0 ? (tile_hint >> 16) & 0xff : 0,
+                                  tile_hint > 0 ? (tile_hint >> 24) & 0xf : 0);
             break;
         default: return set_error(FFB6D_ERR_ARG, "mlp_pm: unknown tile_hint %d", tile_hint);
     }

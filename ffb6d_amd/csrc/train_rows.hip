@@ -72,8 +72,9 @@ gather_sum_rows_kernel(const void* __restrict__ g, int ldq /* ldg / VL */, const
     acc.store(out, t);
 }
 
-// The same sum with several lanes per (row, unit) -- FFB6D_GATHER_SUM_LANES=1; written after round 3's last GPU call, so the default is
-// the form above, which that round ran and measured (111 us per call, 527 GB/s algorithmic: dependent-load latency at ~3 waves per SIMD).
+// The same sum with several lanes per (row, unit): the default wherever the units of a row are a power of two below 64 (the one-lane form
+// above measured 111 us per call, 527 GB/s algorithmic: dependent-load latency at ~3 waves per SIMD; with this form and the row LogSoftmax
+// the bf16 training step went from 61.2 to 54.0 ms, profiles/r04_start_bench_train_bf16_{default,optin}.json).
 // A destination row has ~K readers (16 on average for the neighbour gathers, up to ~60) and only q = C / VL units: with one lane per
 // unit the 16-byte loads of a row's readers would be issued one after the other by 2 .. 16 lanes.  Here L = 2^LOG_L lanes share a
 // (row, unit): lane l adds readers l, l + L, ... (independent loads, all in flight), a butterfly over the L lanes finishes the sum.
@@ -320,125 +321,6 @@ log_softmax_rows_bwd_kernel(const void* __restrict__ g, const void* __restrict__
     if (live) o.store(gx, t);
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// BatchNorm (+ activation) of the shared MLPs in training, on rows.  The normalisation itself is ffb6d_affine_act_pm
-// (csrc/ops_pm.hip) with scale = w * invstd, shift = b - mean * scale; what training adds is two per-channel reductions over
-// all rows (batch statistics; and in backward sum(dz), sum(dz * xhat)) and the input gradient.
-// Thread layout of the two reductions: blockDim = (QX, 256 / QX) with QX the power of two >= q = C / VL (<= 256): thread (tx, ty)
-// owns unit tx of rows ty, ty + RY * gridDim, ...; partial sums meet in LDS across ty, one float atomic per channel and block.
-// ------------------------------------------------------------------------------------------------------------------------
-template <int NACC>
-__device__ __forceinline__ void block_reduce_to_global(float (&acc)[NACC], float* __restrict__ dst /* [NACC / VLs][C] */, int q, int VL,
-                                                       float* lds)
-{
-    // lds[ty][tx][NACC]; reduce over ty by the ty == 0 row of threads
-    const int tx = threadIdx.x, ty = threadIdx.y, QX = blockDim.x, RY = blockDim.y;
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) lds[(ty * QX + tx) * NACC + i] = acc[i];
-    __syncthreads();
-    if (ty == 0 && tx < q) {
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) {
-            float v = 0.f;
-            for (int y = 0; y < RY; ++y) v += lds[(y * QX + tx) * NACC + i];
-            // accumulator i = (statistic i / VL, element i % VL) of unit tx
-            unsafeAtomicAdd(dst + (size_t)(i / VL) * q * VL + tx * VL + (i % VL), v);
-        }
-    }
-}
-
-// sums[0][c] = sum_r (x[r,c] - x[0,c]),  sums[1][c] = sum_r (x[r,c] - x[0,c])^2      (shifted by the first row: no cancellation
-// between a large mean and a small variance)
-template <typename T>
-__global__ void __launch_bounds__(BLK)
-bn_stats_rows_kernel(const void* __restrict__ x, float* __restrict__ sums, int q, int64_t R)
-{
-    using RU = RowUnit<T>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float* lds = reinterpret_cast<float*>(lds_raw);
-    const int tx = threadIdx.x;
-    float acc[2 * RU::VL];
-#pragma unroll
-    for (int i = 0; i < 2 * RU::VL; ++i) acc[i] = 0.f;
-    if (tx < q) {
-        const RU k = RU::load(x, tx);
-        for (int64_t r = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; r < R; r += (int64_t)gridDim.x * blockDim.y) {
-            const RU v = RU::load(x, (size_t)r * q + tx);
-#pragma unroll
-            for (int e = 0; e < RU::VL; ++e) {
-                const float d = v.v[e] - k.v[e];
-                acc[e] += d;
-                acc[RU::VL + e] += d * d;
-            }
-        }
-    }
-    block_reduce_to_global<2 * RU::VL>(acc, sums, q, RU::VL, lds);
-}
-
-__device__ __forceinline__ float act_slope(float z, int act, float slope)      // derivative of the activation at pre-activation z
-{
-    return act == 0 ? 1.f : (z > 0.f ? 1.f : (act == 1 ? 0.f : slope));
-}
-
-// z = x * scale + shift (the forward's pre-activation), dz = gy * act'(z), xhat = (x - mean) * invstd:
-// sums[0][c] = sum_r dz,  sums[1][c] = sum_r dz * xhat
-template <typename T>
-__global__ void __launch_bounds__(BLK)
-bn_act_bwd_reduce_rows_kernel(const void* __restrict__ gy, const void* __restrict__ x, const float* __restrict__ scale,
-                              const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-                              float slope, float* __restrict__ sums, int q, int64_t R)
-{
-    using RU = RowUnit<T>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float* lds = reinterpret_cast<float*>(lds_raw);
-    const int tx = threadIdx.x;
-    float acc[2 * RU::VL];
-#pragma unroll
-    for (int i = 0; i < 2 * RU::VL; ++i) acc[i] = 0.f;
-    if (tx < q) {
-        float sc[RU::VL], sh[RU::VL], mu[RU::VL], is[RU::VL];
-#pragma unroll
-        for (int e = 0; e < RU::VL; ++e) {
-            sc[e] = scale[tx * RU::VL + e], sh[e] = shift[tx * RU::VL + e];
-            mu[e] = mean[tx * RU::VL + e], is[e] = invstd[tx * RU::VL + e];
-        }
-        for (int64_t r = (int64_t)blockIdx.x * blockDim.y + threadIdx.y; r < R; r += (int64_t)gridDim.x * blockDim.y) {
-            const RU xv = RU::load(x, (size_t)r * q + tx), gv = RU::load(gy, (size_t)r * q + tx);
-#pragma unroll
-            for (int e = 0; e < RU::VL; ++e) {
-                const float dz = gv.v[e] * act_slope(xv.v[e] * sc[e] + sh[e], act, slope);
-                acc[e] += dz;
-                acc[RU::VL + e] += dz * ((xv.v[e] - mu[e]) * is[e]);
-            }
-        }
-    }
-    block_reduce_to_global<2 * RU::VL>(acc, sums, q, RU::VL, lds);
-}
-
-// dx = k1[c] * (dz - m_dz[c] - xhat * m_dzx[c]);  k1 = w * invstd, m_dz = sum(dz) / count, m_dzx = sum(dz * xhat) / count
-// (eval-mode statistics: the caller passes m_dz = m_dzx = 0).  thread = (row, unit)
-template <typename T>
-__global__ void __launch_bounds__(BLK)
-bn_act_bwd_dx_rows_kernel(const void* __restrict__ gy, const void* __restrict__ x, const float* __restrict__ scale,
-                          const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-                          const float* __restrict__ k1, const float* __restrict__ m_dz, const float* __restrict__ m_dzx, int act, float slope,
-                          void* __restrict__ gx, int q, size_t total /* R*q */)
-{
-    using RU = RowUnit<T>;
-    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
-    if (t >= total) return;
-    const int c = (int)(t % q) * RU::VL;
-    const RU xv = RU::load(x, t), gv = RU::load(gy, t);
-    RU o;
-#pragma unroll
-    for (int e = 0; e < RU::VL; ++e) {
-        const float dz = gv.v[e] * act_slope(xv.v[e] * scale[c + e] + shift[c + e], act, slope);
-        const float xhat = (xv.v[e] - mean[c + e]) * invstd[c + e];
-        o.v[e] = k1[c + e] * (dz - m_dz[c + e] - xhat * m_dzx[c + e]);
-    }
-    o.store(gx, t);
-}
-
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline bool dt_ok(int dtype) { return dtype == 0 || dtype == 1; }
 inline bool bits_ok(int bits) { return bits == 32 || bits == 64; }
@@ -469,13 +351,12 @@ extern "C" int ffb6d_gather_sum_rows(int dtype, const void* g, int64_t ldg, cons
     FFB6D_REQUIRE(g && order && start && out && al16(g) && al16(out), "gather_sum_rows: null or unaligned pointer");
     FFB6D_REQUIRE(ldg / VL < (1LL << 31), "gather_sum_rows: too large");
     const int q = (int)(C / VL);
-    const char* lanes = getenv("FFB6D_GATHER_SUM_LANES");
-    if (lanes && lanes[0] == '1') {
-        // lanes per (row, unit): as many as fit a wave next to the q units, at most 8 (readers per row: ~16); needs q to be a power
-        // of two (the butterfly's lane distances), else one lane per unit
-        int log_l = 0;
-        if ((q & (q - 1)) == 0)
-            while (log_l < 3 && (q << (log_l + 1)) <= 64) ++log_l;
+    // lanes per (row, unit): as many as fit a wave next to the q units, at most 8 (readers per row: ~16); needs q to be a power
+    // of two (the butterfly's lane distances), else one lane per unit
+    int log_l = 0;
+    if ((q & (q - 1)) == 0)
+        while (log_l < 3 && (q << (log_l + 1)) <= 64) ++log_l;
+    if (log_l > 0) {
         const size_t total = ((size_t)R * q) << log_l;
         FFB6D_ROWS_DT(dtype, T, {
             hipLaunchKernelGGL((gather_sum_rows_lanes_kernel<T>), dim3(blocks_for(total)), dim3(BLK), 0, as_stream(stream), g, (int)(ldg / VL),
@@ -593,78 +474,6 @@ extern "C" int ffb6d_log_softmax_rows_bwd(int dtype, const void* g, const void* 
     const size_t total = (size_t)R * q;
     FFB6D_ROWS_DT(dtype, T, {
         hipLaunchKernelGGL((log_softmax_rows_bwd_kernel<T>), dim3(blocks_for(total)), dim3(BLK), 0, as_stream(stream), g, x, gx, q, total);
-    });
-    FFB6D_LAUNCH_CHECK();
-    return FFB6D_OK;
-}
-
-namespace {
-struct ReduceLaunch { dim3 grid, block; size_t lds; };
-ReduceLaunch reduce_launch(int q, int64_t R, int VL)
-{
-    int QX = 1;
-    while (QX < q) QX <<= 1;
-    const int RY = BLK / QX;
-    const int64_t want = ceil_div(R, (int64_t)RY * 8);                 // ~8 rows per thread before another block pays its atomics
-    ReduceLaunch l;
-    l.block = dim3((unsigned)QX, (unsigned)RY);
-    l.grid = dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, 2048)));
-    l.lds = (size_t)BLK * 2 * VL * sizeof(float);
-    return l;
-}
-}  // namespace
-
-extern "C" int ffb6d_bn_stats_rows(int dtype, const void* x, float* sums, int64_t R, int64_t C, ffb6d_stream_t stream)
-{
-    FFB6D_REQUIRE(dt_ok(dtype), "bn_stats_rows: dtype must be 0 (f32) or 1 (bf16)");
-    const int VL = dtype ? 8 : 4;
-    FFB6D_REQUIRE(R >= 1 && C >= VL && C % VL == 0 && C / VL <= BLK, "bn_stats_rows: R >= 1, C a multiple of %d, at most %d units", VL, BLK);
-    FFB6D_REQUIRE(x && sums && al16(x), "bn_stats_rows: null or unaligned pointer");
-    hipStream_t st = as_stream(stream);
-    FFB6D_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)2 * C * sizeof(float), st));
-    const int q = (int)(C / VL);
-    const ReduceLaunch l = reduce_launch(q, R, VL);
-    FFB6D_ROWS_DT(dtype, T, { hipLaunchKernelGGL((bn_stats_rows_kernel<T>), l.grid, l.block, l.lds, st, x, sums, q, R); });
-    FFB6D_LAUNCH_CHECK();
-    return FFB6D_OK;
-}
-
-extern "C" int ffb6d_bn_act_bwd_reduce_rows(int dtype, const void* gy, const void* x, const float* scale, const float* shift,
-                                            const float* mean, const float* invstd, int act, float slope, float* sums, int64_t R, int64_t C,
-                                            ffb6d_stream_t stream)
-{
-    FFB6D_REQUIRE(dt_ok(dtype) && act >= 0 && act <= 2, "bn_act_bwd_reduce_rows: dtype 0/1, act 0 (none) / 1 (ReLU) / 2 (leaky)");
-    const int VL = dtype ? 8 : 4;
-    FFB6D_REQUIRE(R >= 1 && C >= VL && C % VL == 0 && C / VL <= BLK, "bn_act_bwd_reduce_rows: R >= 1, C a multiple of %d, at most %d units", VL,
-                  BLK);
-    FFB6D_REQUIRE(gy && x && scale && shift && mean && invstd && sums && al16(gy) && al16(x), "bn_act_bwd_reduce_rows: null or unaligned pointer");
-    hipStream_t st = as_stream(stream);
-    FFB6D_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)2 * C * sizeof(float), st));
-    const int q = (int)(C / VL);
-    const ReduceLaunch l = reduce_launch(q, R, VL);
-    FFB6D_ROWS_DT(dtype, T, {
-        hipLaunchKernelGGL((bn_act_bwd_reduce_rows_kernel<T>), l.grid, l.block, l.lds, st, gy, x, scale, shift, mean, invstd, act, slope, sums,
-                           q, R);
-    });
-    FFB6D_LAUNCH_CHECK();
-    return FFB6D_OK;
-}
-
-extern "C" int ffb6d_bn_act_bwd_dx_rows(int dtype, const void* gy, const void* x, const float* scale, const float* shift, const float* mean,
-                                        const float* invstd, const float* k1, const float* m_dz, const float* m_dzx, int act, float slope,
-                                        void* gx, int64_t R, int64_t C, ffb6d_stream_t stream)
-{
-    FFB6D_REQUIRE(dt_ok(dtype) && act >= 0 && act <= 2, "bn_act_bwd_dx_rows: dtype 0/1, act 0 (none) / 1 (ReLU) / 2 (leaky)");
-    const int VL = dtype ? 8 : 4;
-    FFB6D_REQUIRE(R >= 0 && C >= VL && C % VL == 0, "bn_act_bwd_dx_rows: C a multiple of %d", VL);
-    if (R == 0) return FFB6D_OK;
-    FFB6D_REQUIRE(gy && x && scale && shift && mean && invstd && k1 && m_dz && m_dzx && gx && al16(gy) && al16(x) && al16(gx),
-                  "bn_act_bwd_dx_rows: null or unaligned pointer");
-    const int q = (int)(C / VL);
-    const size_t total = (size_t)R * q;
-    FFB6D_ROWS_DT(dtype, T, {
-        hipLaunchKernelGGL((bn_act_bwd_dx_rows_kernel<T>), dim3(blocks_for(total)), dim3(BLK), 0, as_stream(stream), gy, x, scale, shift, mean,
-                           invstd, k1, m_dz, m_dzx, act, slope, gx, q, total);
     });
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;

@@ -83,10 +83,6 @@ class SharedMLP(nn.Module):
             y = F.conv2d(x, F.pad(self.conv.weight, (0, 0, 0, 0, 0, pad_k)), self.conv.bias)
         else:
             y = self.conv(x)
-        if self.has_bn and y.dim() == 4 and y.is_cuda and os.environ.get("FFB6D_BN_ROWS", "0") == "1":
-            # opt-in (unmeasured): BatchNorm + activation on rows, two passes each way instead of MIOpen's
-            # three launches + the activation's own passes; same statistics, running-stat updates and SyncBatchNorm semantics
-            return ops_cl.batch_norm_act(y, self._bn_module(), self.act_code, 0.2)
         if self.has_bn:
             y = (self.bn if self.flavour == "randla" else self.normlayer)(y)
         return self.activation(y)
@@ -182,12 +178,6 @@ class ResBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        if x.is_cuda and os.environ.get("FFB6D_BN_ROWS", "0") == "1":          # opt-in, as in SharedMLP.forward
-            y = ops_cl.batch_norm_act(self.conv1(x), self.bn1, ops.ACT_RELU)
-            y = ops_cl.batch_norm_act(self.conv2(y), self.bn2, ops.ACT_NONE)
-            if self.downsample is not None:
-                x = ops_cl.batch_norm_act(self.downsample[0](x), self.downsample[1], ops.ACT_NONE)
-            return F.relu_(y + x)
         y = F.relu_(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         if self.downsample is not None:
@@ -302,8 +292,6 @@ class UpBlock(nn.Module):
         # (csrc/train_ops.hip: gather instead of ATen's atomic scatter; slope gradient reduced in the kernel)
         _, conv, bn, prelu = self.conv
         y = ops.upsample_align(x, (2 * x.shape[2], 2 * x.shape[3]))
-        if os.environ.get("FFB6D_BN_ROWS", "0") == "1":                      # opt-in, as in SharedMLP.forward
-            return ops.prelu(ops_cl.batch_norm_act(conv(y), bn, ops.ACT_NONE), prelu.weight)
         return ops.prelu(bn(conv(y)), prelu.weight)
 
 
@@ -316,9 +304,10 @@ class FinalHead(nn.Sequential):
 
     def forward(self, x):
         y = self[0](x)
-        if y.is_cuda and os.environ.get("FFB6D_LOGSOFTMAX_ROWS", "0") == "1":
-            # opt-in until it has run on the device (written after round 3's last GPU call): the same operator on rows, in the
-            # map's own dtype -- under autocast ATen's log_softmax is an fp32 operator
+        if y.is_cuda:
+            # the same operator on rows, in the map's own dtype: under autocast ATen's log_softmax is an fp32 operator that writes the two
+            # largest maps of the decoder as fp32 (measured with the multi-lane gather backward: 61.2 -> 54.0 ms
+            # per bf16 training step, profiles/r04_start_bench_train_bf16_{default,optin}.json)
             return ops_cl.channel_log_softmax(y)
         return self[1](y)
 

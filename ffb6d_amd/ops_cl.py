@@ -231,120 +231,6 @@ def channel_log_softmax(x):
     return _LogSoftmaxRows.apply(x)
 
 
-class _BatchNormActRows(torch.autograd.Function):
-    """x [B,C,*S] (rows) -> act(batch_norm(x)); batch statistics when bn.training, running statistics otherwise"""
-
-    @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, x, weight, bias, bn, act, slope, group):
-        lib = _lib.load()
-        rows = to_rows(x)
-        B, M, C = rows.shape
-        R = B * M
-        dt = _dt(rows)
-        dev = x.device
-        if bn.training:
-            sums = torch.empty((2, C), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev), _lib.traced("bn_stats_rows", rows.element_size() * rows.numel(), (C, R)):
-                rc = lib.ffb6d_bn_stats_rows(dt, rows.data_ptr(), sums.data_ptr(), R, C, _stream(x))
-            _lib.check(rc, "ffb6d_bn_stats_rows")
-            k = rows[0, 0].float()
-            count = float(R)
-            if group is not None:            # synchronised statistics: raw moments (every rank shifted by its own first row), one all-reduce
-                s1 = sums[0] + count * k
-                s2 = sums[1] + 2.0 * k * sums[0] + count * k * k
-                packed = torch.cat([s1, s2, torch.full((1,), count, dtype=torch.float32, device=dev)])
-                torch.distributed.all_reduce(packed, group=group)
-                count = packed[-1]           # stays on the device: no host synchronisation
-                mean = packed[:C] / count
-                var = (packed[C:2 * C] / count - mean * mean).clamp_min_(0.0)
-                unbias = count / (count - 1.0).clamp_min(1.0)
-            else:
-                d = sums[0] / count
-                mean = k + d
-                var = (sums[1] / count - d * d).clamp_min_(0.0)
-                unbias = count / max(count - 1.0, 1.0)
-            invstd = torch.rsqrt(var + bn.eps)
-            if bn.track_running_stats and bn.running_mean is not None:
-                m = bn.momentum
-                with torch.no_grad():
-                    bn.running_mean.mul_(1.0 - m).add_(mean.to(bn.running_mean.dtype), alpha=m)
-                    bn.running_var.mul_(1.0 - m).add_((var * unbias).to(bn.running_var.dtype), alpha=m)
-                    bn.num_batches_tracked += 1
-        else:
-            mean = bn.running_mean.float()
-            invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
-            count = float(R)
-        w, b = weight.float(), bias.float()
-        scale = (w * invstd).contiguous()
-        shift = (b - mean * scale).contiguous()
-        y = torch.empty_like(rows)
-        with torch.cuda.device(dev), _lib.traced("affine_act_pm", 2 * rows.element_size() * rows.numel(), (C, R)):
-            rc = lib.ffb6d_affine_act_pm(dt, rows.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, None, y.data_ptr(), R, C,
-                                         int(act), float(slope), _stream(x))
-        _lib.check(rc, "ffb6d_affine_act_pm")
-        ctx.save_for_backward(rows, scale, shift, mean.contiguous(), invstd.contiguous())
-        ctx.meta = (tuple(x.shape[2:]), int(act), float(slope), bool(bn.training), count, group, weight.dtype, bias.dtype)
-        return from_rows(y, x.shape[2:])
-
-    @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, g):
-        lib = _lib.load()
-        rows, scale, shift, mean, invstd = ctx.saved_tensors
-        spatial, act, slope, training, count, group, wdt, bdt = ctx.meta
-        B, M, C = rows.shape
-        R = B * M
-        dt = _dt(rows)
-        g = _act(g)
-        gr = to_rows(g if g.dtype == rows.dtype else g.to(rows.dtype))
-        sums = torch.empty((2, C), dtype=torch.float32, device=rows.device)
-        with torch.cuda.device(rows.device), _lib.traced("bn_act_bwd_reduce_rows", 2 * rows.element_size() * rows.numel(), (C, R)):
-            rc = lib.ffb6d_bn_act_bwd_reduce_rows(dt, gr.data_ptr(), rows.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                                                  invstd.data_ptr(), act, slope, sums.data_ptr(), R, C, _stream(rows))
-        _lib.check(rc, "ffb6d_bn_act_bwd_reduce_rows")
-        grad_bias, grad_weight = sums[0].clone(), sums[1].clone()        # local sums: DDP averages parameter gradients itself
-        if training:
-            tot = sums
-            if group is not None:
-                tot = sums.clone()
-                torch.distributed.all_reduce(tot, group=group)
-            m_dz, m_dzx = (tot[0] / count).contiguous(), (tot[1] / count).contiguous()
-        else:
-            m_dz = m_dzx = torch.zeros(C, dtype=torch.float32, device=rows.device)
-        gx = torch.empty_like(rows)
-        with torch.cuda.device(rows.device), _lib.traced("bn_act_bwd_dx_rows", 3 * rows.element_size() * rows.numel(), (C, R)):
-            rc = lib.ffb6d_bn_act_bwd_dx_rows(dt, gr.data_ptr(), rows.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                                              invstd.data_ptr(), scale.data_ptr(), m_dz.data_ptr(), m_dzx.data_ptr(), act, slope,
-                                              gx.data_ptr(), R, C, _stream(rows))
-        _lib.check(rc, "ffb6d_bn_act_bwd_dx_rows")
-        return from_rows(gx, spatial), grad_weight.to(wdt), grad_bias.to(bdt), None, None, None, None
-
-
-def batch_norm_act(x, bn, act=0, slope=0.2):
-    """act(bn(x)) for the conv -> BatchNorm -> ReLU / LeakyReLU(0.2) of a shared MLP (pytorch_utils.py:75-129,
-    RandLA/pytorch_utils.py:35-111) on a [B,C,*S] map in rows: batch statistics by one column-reduction pass (shifted sums, fp32),
-    normalisation + activation in one pass, backward in two (reductions; input gradient) -- MIOpen's spatial BatchNorm takes three
-    launches each way plus the activation's own forward and backward passes.  `bn` is the module (nn.BatchNorm1d/2d or
-    nn.SyncBatchNorm: its parameters, running statistics, momentum and eps are used and updated exactly as F.batch_norm would;
-    a SyncBatchNorm all-reduces the raw moments over its process group -- one collective per layer and direction).  act: 0 none,
-    1 ReLU, 2 LeakyReLU(slope).  Anything the kernels do not cover goes to torch."""
-    _need_gpu(x)
-    x = _act(x)
-    C = x.shape[1]
-    ok = (x.dtype in (torch.float32, torch.bfloat16) and x.dim() >= 3 and C % _vl(x) == 0 and C // _vl(x) <= 256 and bn.affine
-          and (not bn.training or (bn.momentum is not None and x.numel() // C >= 2))
-          and (bn.training or (bn.track_running_stats and bn.running_mean is not None)) and x.numel() > 0)
-    if not ok:
-        y = bn(x)
-        return y if act == 0 else (torch.relu_(y) if act == 1 else torch.nn.functional.leaky_relu_(y, slope))
-    group = None
-    if isinstance(bn, torch.nn.SyncBatchNorm) and bn.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
-            and torch.distributed.get_world_size(bn.process_group) > 1:
-        group = bn.process_group if bn.process_group is not None else torch.distributed.group.WORLD
-    return _BatchNormActRows.apply(x, bn.weight, bn.bias, bn, act, slope, group)
-
-
 def nearest_interpolation(feature, interp_idx, spatial=None, plan=None):
     """FFB6D.nearest_interpolation (ffb6d.py:179-194): feature [B,C,M,1] (or any [B,C,*S]), interp_idx [B,U,1] -> [B,C,U,1]
     (or [B,C,*spatial] with prod(spatial) == U: the point -> pixel fusion reshapes to the map right away).

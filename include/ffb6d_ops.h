@@ -249,20 +249,6 @@ int ffb6d_att_pool_rows_bwd(int dtype, const void* g, int64_t ldg, const void* f
  * _bwd: gx = g - softmax(x) * sum_c g, recomputed from the forward's input x. */
 int ffb6d_log_softmax_rows(int dtype, const void* x, void* y, int64_t R, int64_t C, ffb6d_stream_t stream);
 int ffb6d_log_softmax_rows_bwd(int dtype, const void* g, const void* x, void* gx, int64_t R, int64_t C, ffb6d_stream_t stream);
-/* Train-mode BatchNorm (+ activation) of a shared MLP on [R, C] rows (pytorch_utils.py:75-129, RandLA/pytorch_utils.py:35-111:
- * conv -> BatchNorm -> ReLU / LeakyReLU(0.2)); C / 4 resp. C / 8 <= 256.  The normalisation itself is ffb6d_affine_act_pm with
- * scale = w * invstd, shift = b - mean * scale.
- * ffb6d_bn_stats_rows: sums[0][c] = sum_r (x[r,c] - x[0,c]), sums[1][c] = sum_r (x[r,c] - x[0,c])^2 (float32 [2, C]).
- * ffb6d_bn_act_bwd_reduce_rows: with z = x * scale + shift, dz = gy * act'(z), xhat = (x - mean) * invstd:
- *   sums[0][c] = sum_r dz (= grad of the bias), sums[1][c] = sum_r dz * xhat (= grad of the weight).
- * ffb6d_bn_act_bwd_dx_rows: gx = k1[c] * (dz - m_dz[c] - xhat * m_dzx[c]); k1 = w * invstd, m_* = the sums above / count (batch
- *   statistics) or 0 (running statistics).  act: 0 none, 1 ReLU, 2 leaky with `slope`. */
-int ffb6d_bn_stats_rows(int dtype, const void* x, float* sums, int64_t R, int64_t C, ffb6d_stream_t stream);
-int ffb6d_bn_act_bwd_reduce_rows(int dtype, const void* gy, const void* x, const float* scale, const float* shift, const float* mean,
-                                 const float* invstd, int act, float slope, float* sums, int64_t R, int64_t C, ffb6d_stream_t stream);
-int ffb6d_bn_act_bwd_dx_rows(int dtype, const void* gy, const void* x, const float* scale, const float* shift, const float* mean,
-                             const float* invstd, const float* k1, const float* m_dz, const float* m_dzx, int act, float slope, void* gx,
-                             int64_t R, int64_t C, ffb6d_stream_t stream);
 /* Second half of the folded up-convolution (PSPUpsample, pspnet.py:34-45: bilinear x2 with align_corners -> Conv2d 3x3,
  * padding 1 -> BatchNorm -> PReLU).  z [B,IH,IW,9,C] holds, per low-resolution pixel and filter tap (ky*3+kx), the channel
  * mixing (BatchNorm scale * W[:, :, ky, kx]) x -- one ffb6d_mlp_pm GEMM with 9*C output channels -- and

@@ -21,10 +21,14 @@ SHAPES = [(38400, 1024, 0, 2304, 0, False, "z0 1024->2304"), (38400, 1024, 0, 10
           (98304, 128, 0, 128, 0, False, "head 128->128")]
 if BF:
     SHAPES = [(2 * r, k1, k2, c, py, xg, n) for r, k1, k2, c, py, xg, n in SHAPES]
-FORMS = [("7", 7), ("8", 8), ("8 gc=n_ct", 8 + (64 << 16)), ("8 gc=4", 8 + (4 << 16)), ("8 gc=2", 8 + (2 << 16)), ("8 spx=32", 8 + (32 << 8)),
-         ("8 spx=48", 8 + (48 << 8))]
-if "--quick" in sys.argv:
-    FORMS = FORMS[:2]
+FORMS = [("7", 7), ("8", 8)]
+if "--epi" in sys.argv:        # probe forms of the persistent kernel's epilogue (hint bits 24..27): fragment-shaped stores, none at all
+    FORMS += [("8 frag", 8 + (4 << 24)), ("8 noepi", 8 + (8 << 24))]
+if "--spread" in sys.argv:     # start of the workgroups spread over 8 k / 16 k / 32 k cycles (at most one tile period), row and fragment epilogues
+    FORMS += [("8 s8k", 8 + (1 << 24)), ("8 s16k", 8 + (2 << 24)), ("8 s32k", 8 + (3 << 24)), ("8 frag s16k", 8 + (6 << 24)), ("8 frag s32k", 8 + (7 << 24)),
+              ("8 noepi", 8 + (8 << 24))]
+if "--walk" in sys.argv:
+    FORMS += [("8 gc=n_ct", 8 + (64 << 16)), ("8 gc=4", 8 + (4 << 16)), ("8 gc=2", 8 + (2 << 16)), ("8 spx=32", 8 + (32 << 8)), ("8 spx=48", 8 + (48 << 8))]
 ROUNDS, REPS = 5, 6
 
 

@@ -245,6 +245,10 @@ typedef simt::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) simt::mfma_32x32x16_bf16(a, b, c)
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* the kernels only pass wave-uniform values */
 #define __builtin_amdgcn_sched_barrier(x) simt::wave_sync()
+// scheduling hints and hardware-id reads: no functional effect on the emulator (workgroups run one after the other)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_getreg(x) (0u)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __shfl_xor(v, mask, ...) simt::shfl_xor(v, mask)

@@ -149,67 +149,3 @@ def test_two_rank_training_step_averages_gradients_through_the_custom_operators(
         assert scale > 0 and not np.allclose(l0, l1, rtol=1e-3, atol=1e-6 * scale), name          # the ranks saw different frames
         np.testing.assert_allclose(s0, s1, rtol=0, atol=1e-6 * scale, err_msg=name)                  # one gradient on both ranks
         np.testing.assert_allclose(s0, (l0 + l1) / 2, rtol=0, atol=2e-5 * scale, err_msg=name)       # = the mean of the local ones
-
-
-BN_WORKER = textwrap.dedent("""
-    import json, os, sys
-    sys.path.insert(0, %r)
-    import pytest, torch
-    import torch.distributed as dist
-    from tests.simt import bind
-    mp = pytest.MonkeyPatch()
-    bind.bind(mp)
-    from ffb6d_amd import distributed as D, ops_cl
-    g = D.init_from_env(backend="gloo")
-    gen = torch.Generator().manual_seed(100 + g.rank)
-    x = (1.5 * torch.randn(2, 16, 20 + 3 * g.rank, 4, generator=gen) + 2.0).contiguous(memory_format=torch.channels_last)   # ranks differ in size too
-    torch.manual_seed(0)
-    sbn = torch.nn.SyncBatchNorm(16, eps=1e-5, momentum=0.1).train()
-    with torch.no_grad():
-        sbn.weight.uniform_(0.5, 1.5); sbn.bias.normal_()
-    xs = x.clone().requires_grad_(True)
-    y = ops_cl.batch_norm_act(xs, sbn, 2, 0.2)
-    r = torch.rand(y.shape, generator=torch.Generator().manual_seed(9 + g.rank))
-    (y * r).sum().backward()
-    mine = x.permute(0, 2, 3, 1).reshape(-1, 16).contiguous()
-    out = dict(rank=g.rank, x=mine.tolist(), r=r.permute(0, 2, 3, 1).reshape(-1, 16).tolist(), y=y.detach().permute(0, 2, 3, 1).reshape(-1, 16).tolist(),
-               gx=xs.grad.permute(0, 2, 3, 1).reshape(-1, 16).tolist(), gw=sbn.weight.grad.tolist(), gb=sbn.bias.grad.tolist(),
-               rm=sbn.running_mean.tolist(), rv=sbn.running_var.tolist(), w=sbn.weight.tolist(), b=sbn.bias.tolist())
-    with open(os.path.join(os.environ["BN_OUT"], "rank%%d.json" %% g.rank), "w") as fh:      # (large: a pipe would fill up and stall the rank)
-        json.dump(out, fh)
-    g.close()
-""") % ROOT
-
-
-def test_synchronised_row_batch_norm_equals_one_process_on_all_rows(tmp_path):
-    """ops_cl.batch_norm_act with an nn.SyncBatchNorm on two gloo ranks (different numbers of rows per rank), kernels on the SIMT
-    emulator: output, input gradient and running statistics must be those of ONE BatchNorm over both ranks' rows together, and the
-    ranks' weight / bias gradients must add up to its gradients (DDP averages them afterwards) -- train_lm.py:592's recipe with one
-    all-reduce of the raw moments per layer and direction."""
-    import torch
-    script = tmp_path / "bn_worker.py"
-    script.write_text(BN_WORKER)
-    port = free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2", BN_OUT=str(tmp_path))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=300)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), [o[-3000:] for o in outs]
-    res = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
-    x = torch.cat([torch.tensor(r["x"]) for r in res]).requires_grad_(True)          # [rows of rank 0 ; rows of rank 1, 16]
-    wts = torch.cat([torch.tensor(r["r"]) for r in res])
-    bn = torch.nn.BatchNorm1d(16, eps=1e-5, momentum=0.1).train()
-    with torch.no_grad():
-        bn.weight.copy_(torch.tensor(res[0]["w"])); bn.bias.copy_(torch.tensor(res[0]["b"]))
-    y = torch.nn.functional.leaky_relu(bn(x), 0.2)
-    (y * wts).sum().backward()
-    n0 = len(res[0]["x"])
-    close = lambda a, b: torch.testing.assert_close(torch.as_tensor(a), b, rtol=2e-5, atol=2e-5)       # noqa: E731
-    close(res[0]["y"], y[:n0].detach()); close(res[1]["y"], y[n0:].detach())
-    close(res[0]["gx"], x.grad[:n0]); close(res[1]["gx"], x.grad[n0:])
-    close(torch.tensor(res[0]["gw"]) + torch.tensor(res[1]["gw"]), bn.weight.grad)
-    close(torch.tensor(res[0]["gb"]) + torch.tensor(res[1]["gb"]), bn.bias.grad)
-    for r in res:
-        close(r["rm"], bn.running_mean); close(r["rv"], bn.running_var)

@@ -175,6 +175,7 @@ def test_f4_kernels_reproduce_the_committed_vectors(device):
         got = inputs.fill_missing(torch.from_numpy(raw).to(device), float(g[tag + "/cam_scale"]), 1).cpu().numpy()
         want = g[tag + "/filled"]
         assert ((got > 0) == (want > 0)).all()
-        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+        # 1e-5 per element, or 1e-6 of the map's range where the final `max_depth - d` cancels (pixels near max_depth)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6 * float(want.max()))
         n_cases += 1
     assert n_cases == 6

@@ -200,11 +200,9 @@ def test_gather_neighbour_with_the_reference_signature_on_rows(device, dt):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C", [8, 24, 64, 256, 512])
-@pytest.mark.parametrize("lanes", ["0", "1"])
-def test_gather_backward_with_skewed_reader_counts(device, dt, C, lanes, monkeypatch):
+def test_gather_backward_with_skewed_reader_counts(device, dt, C):
     """gather_sum_rows: 1 .. 8 lanes share a (destination row, unit) depending on C (butterfly reduction), rows with no reader at
     all, one row read by a third of the outputs, odd list lengths -- against torch's scatter-add of the same gradient"""
-    monkeypatch.setenv("FFB6D_GATHER_SUM_LANES", lanes)      # 0: one lane per unit (default); 1: the multi-lane form
     B, M, U = 2, 37, 301
     g = torch.Generator().manual_seed(C)
     idx = torch.randint(3, M, (B, U), generator=g)          # rows 0..2 have no reader
