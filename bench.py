@@ -10,8 +10,8 @@
 A *step* is one pass of the hot path over one batch of synthetic RGB-D frames that is already
 resident in HBM: the on-device index pyramid (the 22 exact-KNN searches per frame that the
 reference runs on the CPU in its DataLoader, linemod_dataset.py:318-353) followed by
-FFB6D.forward (ffb6d.py:203-337) in fp32, eval mode -- by default the forward builds the pyramid itself, level by
-level on a third HIP stream under the network (--overlap-pyramid 0: pyramid first, then the forward).
+FFB6D.forward (ffb6d.py:203-337) in fp32, eval mode -- by default the forward builds the pyramid itself (one batch of
+searches) on a third HIP stream under the colour stem (--overlap-pyramid 0: pyramid first, then the forward).
 Workload = BASELINE.json configs[1]:
 bs=8, N=12288 points, 480x640, 4 encoder + 3 decoder fusion layers, one MI355X.  With N>1
 ranks every rank runs its own batch of 8 (weak scaling, no data-path collective: batch items
@@ -80,9 +80,9 @@ def parse():
                     help="2: point branch on a second HIP stream under the colour branch (inference); "
                          "1: everything on one stream")
     ap.add_argument("--overlap-pyramid", type=int, default=1,
-                    help="1 (default, inference with --streams 2): the forward builds the index pyramid itself, level by "
-                         "level on a third HIP stream (forward_pm.StreamedPyramid), so the point branch starts after the "
-                         "level-0 searches and the rest runs under the network; 0: whole pyramid first, then the forward")
+                    help="1 (default, inference with --streams 2): the forward builds the index pyramid itself on a third HIP "
+                         "stream (forward_pm.StreamedPyramid: all 22 searches as one batch, ~1 ms, under the colour stem); "
+                         "0: whole pyramid first, then the forward")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="BASELINE.json workload: 2 = bs=8, N=12288, 22 classes, fp32 (the headline metric, default); "
                          "4 = YCB-shaped bs=8, N=24576, 22 classes, fp32; 5 = bs=16, N=12288, bf16 mixed precision "
@@ -446,16 +446,23 @@ def main():
         roofline = None
         r = roofline_of(tracer, roof_op) if roof_op else None
         if r:
-            traffic = None
+            traffic, traffic_set = None, None
             pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            # HBM bytes per launch measured offline with rocprofv3 --pmc on the default workload (config 2, fp32, pm)
+            # HBM bytes per launch measured offline with rocprofv3 --pmc on the default workload (config 2, fp32, pm).  The table holds
+            # the mean over ALL launches of the kernel instantiation in a step -- both sides of the ridge -- so `traffic_set` gives the
+            # algorithmic bytes per launch over that same set of launches (the figure to set `traffic` beside), not this group's only
             if os.path.exists(pmc_file) and args.precision == "fp32" and args.config == 2:
                 with open(pmc_file) as fh:
                     table = json.load(fh)
                     key = roof_op.replace(",mfma>", ">").replace(",hbm>", ">")
                     traffic = table.get(key, table.get(key.split("<")[0], {})).get("hbm_bytes_per_launch")
+                    same = [v for n, v in summary.items() if n.replace(",mfma>", ">").replace(",hbm>", ">") == key]
+                    nl = sum(v["launches"] for v in same)
+                    if traffic is not None and nl:
+                        traffic_set = {"kernel": key, "launches_per_step": nl / N_FULL,
+                                       "algorithmic_bytes_per_launch": sum(v["bytes"] for v in same) / nl}
             roofline = {"bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
-                        "frac": r["frac"], "traffic": traffic, "kernel": r["kernel"],
+                        "frac": r["frac"], "traffic": traffic, "traffic_set": traffic_set, "kernel": r["kernel"],
                         "launches_per_step": r["launches"] / args.steps, "avg_launch_us": r["avg_launch_us"],
                         "algorithmic_bytes_per_step": r["bytes"] / args.steps}
             if r["bound"] == "mfma":
@@ -551,7 +558,7 @@ def main():
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "
                                       f"{args.dist_backend if world > 1 else 'no'} process group)"},
             "breakdown_ms": ({"step": fwd_ms, "knn_pyramid_alone": pyr_alone_ms,
-                              "note": "the forward builds the index pyramid itself, level by level on a third HIP stream, "
+                              "note": "the forward builds the index pyramid itself (all 22 searches as one batch) on a third HIP stream, "
                                       "under the network (forward_pm.StreamedPyramid); knn_pyramid_alone = the same 22 "
                                       "searches run by themselves after the timed region"}
                              if pyramid_on_side else {"knn_pyramid": pyr_ms, "forward": fwd_ms}),

@@ -21,6 +21,17 @@ constexpr int kNumXCD = 8;        // MI355X: 8 XCDs, each with a private L2
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Kernel attributes (dynamic LDS limit) and occupancy answers belong to a DEVICE: a process that drives several GPUs must set /
+// query them once per device, not once per process.  Slot of the calling thread's current device in a per-call-site cache
+// (`static int cache[kMaxDevices]`, 0 = not initialised yet; racing initialisers write the same value).
+constexpr int kMaxDevices = 64;
+inline int device_slot()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+
 }  // namespace ffb6d
 
 #define FFB6D_HIP_TRY(expr)                                                              \

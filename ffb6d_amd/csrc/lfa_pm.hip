@@ -527,23 +527,24 @@ lfa_pm_kernel(const LfaParams p)
 }
 
 template <typename T, int D, int MODE, int P, bool WLDS, int NW = 4>
-void launch_lfa(LfaParams& p, hipStream_t st)
+void launch_lfa(LfaParams& p, hipStream_t st, int wg_cap)
 {
     using G = LfaGeom<T, D, MODE, P, WLDS>;
     p.n_grp = (int)ceil_div(p.npts, P);
     const void* fn = reinterpret_cast<const void*>(&lfa_pm_kernel<T, D, MODE, P, WLDS, NW>);
     // persistent workgroups: as many as are resident at once (registers + LDS), each walks its share of the point groups
-    static const int per_cu = [&] {
+    static int per_cu_of[kMaxDevices];                                     // per device (common.h: device_slot)
+    int& per_cu = per_cu_of[device_slot()];
+    if (per_cu == 0) {
         int n = 0;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64 * NW, G::LDS) != hipSuccess || n < 1)
             n = 1;
-        return n;
-    }();
+        per_cu = n;
+    }
     const int64_t per_xcd = ceil_div(p.n_grp, 8);                          // groups of one XCD
-    // FFB6D_LFA_WG_PER_XCD: cap on the workgroups per XCD (tuning; the tests use 1 to make every workgroup loop)
-    const char* e = getenv("FFB6D_LFA_WG_PER_XCD");
-    const int64_t cap = e && atoi(e) > 0 ? (int64_t)atoi(e) : (int64_t)1 << 30;
+    // wg_cap (p_hint bits 8..15): cap on the workgroups per XCD (the tests use 1 to make every workgroup walk several groups)
+    const int64_t cap = wg_cap > 0 ? (int64_t)wg_cap : (int64_t)1 << 30;
     const unsigned grid = 8u * (unsigned)std::min<int64_t>(std::min<int64_t>(per_xcd, (int64_t)32 * per_cu), cap);
     hipLaunchKernelGGL((lfa_pm_kernel<T, D, MODE, P, WLDS, NW>), dim3(grid), dim3(64 * NW), G::LDS, st, p);
 }
@@ -551,21 +552,21 @@ void launch_lfa(LfaParams& p, hipStream_t st)
 // points per workgroup: 16 P d elements of pair image = 64 KB (fp32) whatever the level; `small` halves it (more, smaller
 // workgroups).  wlds: fc / mlp / mlp2 weights resident in LDS (d <= 64 only: they must fit beside the pair image).
 template <typename T, int D, int MODE>
-void launch_lfa_p(LfaParams& p, int size, bool wlds, hipStream_t st)
+void launch_lfa_p(LfaParams& p, int size, bool wlds, hipStream_t st, int wg_cap)
 {
     constexpr int P = 1024 / D;
     if constexpr (D <= 64) {
         if (wlds) {
-            if (size == 3) launch_lfa<T, D, MODE, P / 4, true>(p, st);
-            else if (size == 2) launch_lfa<T, D, MODE, P / 2, true>(p, st);
-            else launch_lfa<T, D, MODE, P, true>(p, st);
+            if (size == 3) launch_lfa<T, D, MODE, P / 4, true>(p, st, wg_cap);
+            else if (size == 2) launch_lfa<T, D, MODE, P / 2, true>(p, st, wg_cap);
+            else launch_lfa<T, D, MODE, P, true>(p, st, wg_cap);
             return;
         }
-        if (size == 3) { launch_lfa<T, D, MODE, P / 4, false>(p, st); return; }
-        if (size == 4) { launch_lfa<T, D, MODE, 128 / D, false, 1>(p, st); return; }      // one wave per workgroup: 4 / 2 points each
+        if (size == 3) { launch_lfa<T, D, MODE, P / 4, false>(p, st, wg_cap); return; }
+        if (size == 4) { launch_lfa<T, D, MODE, 128 / D, false, 1>(p, st, wg_cap); return; }      // one wave per workgroup: 4 / 2 points each
     }
-    if (size >= 2) launch_lfa<T, D, MODE, P / 2, false>(p, st);
-    else launch_lfa<T, D, MODE, P, false>(p, st);
+    if (size >= 2) launch_lfa<T, D, MODE, P / 2, false>(p, st, wg_cap);
+    else launch_lfa<T, D, MODE, P, false>(p, st, wg_cap);
 }
 
 template <typename T>
@@ -605,8 +606,8 @@ int lfa_pm_impl(int mode, const float* xyz4, int64_t xfs, const void* nei, int i
     const bool wlds = d <= 64 && size != 4 && (w_hint == 1 || (w_hint == 0 && (choice >> 3) == 1));
 #define FFB6D_LFA_D(D_)                                                              \
     do {                                                                             \
-        if (mode == 1) launch_lfa_p<T, D_, 1>(p, size, wlds, st);                    \
-        else launch_lfa_p<T, D_, 2>(p, size, wlds, st);                              \
+        if (mode == 1) launch_lfa_p<T, D_, 1>(p, size, wlds, st, (p_hint >> 8) & 0xff); \
+        else launch_lfa_p<T, D_, 2>(p, size, wlds, st, (p_hint >> 8) & 0xff);        \
     } while (0)
     switch (d) {
         case 32: FFB6D_LFA_D(32); break;

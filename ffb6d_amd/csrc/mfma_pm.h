@@ -8,13 +8,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// keeps a value (and the instructions that produce it) alive in a timing probe that drops its consumer
-#if defined(__AMDGCN__)
-#define FFB6D_KEEP_LIVE(x) asm volatile("" ::"v"(x))
-#else
-#define FFB6D_KEEP_LIVE(x) ((void)(x))
-#endif
-
 namespace ffb6d {
 namespace pm {
 

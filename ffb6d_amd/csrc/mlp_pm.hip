@@ -62,14 +62,11 @@ struct PmParams {
     int P, py, px;        // output rows per frame (for the gathers), rows of Y / of X1 per frame
     int act, idx64;
     int n_pt, n_ct;       // point tiles, channel tiles
-    int gc_cap;           // persistent form: channel tiles per block of the XCD walk (launcher: 8 unless a hint overrides it)
-    int probe;            // persistent form, hint bits 24..27 (scripts/gemm_persist_probe.py): 1..3 = start spread, 4 = fragment-shaped epilogue, 8 = none
 };
 
 // epilogue shared by the GEMM kernels: bias, gathered / added row of Y, activation or log-softmax, store
 // LSM = false compiles the log-softmax branch out (it needs all channels of a point live at once: 16 * TM more registers)
-// VEC = true: the launcher has checked the 16-byte alignment of the 4-channel groups (rows, bias): no scalar fallback compiled in
-template <typename T, int TM, int TN, bool LSM = true, bool VEC = false>
+template <typename T, int TM, int TN, bool LSM = true>
 __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM][TN], int c0, int r0, int wm, int wn, int l31, int kh)
 {
     constexpr int SZ = El<T>::SZ;
@@ -78,9 +75,9 @@ __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM]
     T* ob = static_cast<T*>(p.out);
     const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
     constexpr int AL = 4 * SZ - 1;                         // alignment mask of a 4-channel group
-    const bool vec = VEC || ((p.cout & 3) == 0 && (p.ldo & 3) == 0 && (p.ldy & 3) == 0 &&
-                             ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.y)) & AL) == 0 &&
-                             (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+    const bool vec = (p.cout & 3) == 0 && (p.ldo & 3) == 0 && (p.ldy & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.y)) & AL) == 0 &&
+                     (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = r0 + (wn * TN + j) * 32 + l31;
@@ -164,7 +161,7 @@ __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM]
                             El<T>::st4(orow + ch, make_float4(v[i][g].x - lse, v[i][g].y - lse, v[i][g].z - lse, v[i][g].w - lse));
                     }
             }
-        } else if (!VEC && live) {
+        } else if (live) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -577,6 +574,27 @@ mlp_pm_stream_kernel(const PmParams p)
 //     the loads of step s + 1 are in flight while step s is multiplied, one barrier per step;
 //   * each wave multiplies its 64 x 64 tile (2 x 2 MFMA tiles) out of the images; epilogue = pm_epilogue.
 // Same products and the same k order per accumulator as mlp_pm_kernel -> identical results.
+//
+// Round 4 built the PERSISTENT form of this kernel three times (workgroups walking tile lists, the operand stream running across tile
+// boundaries: static lists per workgroup; lists per XCD handed out with atomics and stealing; the same with a one-load look at all
+// counters) and kept none of them -- the records are under profiles/r04_gemm_*_probe_*.txt and profiles/r04_mid_bench_default_*.json:
+//   * alone on the chip the static form is 3 % faster in fp32 and 12 % in bf16 (sum over the ten launches of the step: 4108 against
+//     4221 us), the dynamic forms 1 % slower (the hand-out costs the short launches: 768 tiles on 512 workgroups);
+//   * inside the benchmarked three-stream step every persistent form is SLOWER than this kernel: driver-style roofline 0.584 (static)
+//     and 0.615-0.623 (dynamic) against 0.652, frames/s 349-358 against 356: resident workgroups that hold 72 KB of LDS and 250
+//     registers for the whole launch get in the way of the side streams' kernels and the other way round, and one tile per
+//     workgroup lets the hardware dispatcher do the balancing;
+//   * what the tile boundary costs is the EPILOGUE, not the prologue the persistent loop hides: without its stores the same loop runs
+//     the ten launches in 3553 us (118-132 TFLOP/s fp32: 0.75-0.84 of the 2.4 GHz peak at the ~2.1 GHz the chip sustains); the
+//     epilogue adds output bytes / ~5 TB/s in fp32 and half that rate in bf16 (~100 cycles per store instruction and CU, whatever
+//     its width), and the CU's second workgroup hides none of it although it hides about half of an idle wait of the same length.
+//     Measured and NOT the cause: the shape of the stores (whole 512-byte rows through the free LDS stage: within 1 % of the
+//     fragment-shaped epilogue), the two workgroups of a CU running in step (s_setprio on one of them, or starting it half a tile
+//     late: no change; census: blocks b and b + 256 share a CU, profiles/r04_wg_census.txt), all workgroups bursting together (start
+//     spread over 8-32 k cycles: no change), the L2 footprint of the tile walk (blocks of 2 .. all channel tiles: no change).
+//   What would remove it is an accumulator-to-memory path that does not sit in the in-order vector-memory queue of the waves that
+//   multiply (a second accumulator set drained during the next tile needs the 96 staging registers back: LDS-DMA operand loads) --
+//   a different kernel, not a variant of this one.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(BLK, 2)            // two workgroups per CU (LDS allows two): at most 256 registers per lane
@@ -732,287 +750,6 @@ mlp_pm_lds_kernel(const PmParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Persistent form of the LDS-tiled GEMM (tile_hint 8).  Same tile, same LDS images, same MFMA order per accumulator as
-// mlp_pm_lds_kernel (bit-identical results), but a workgroup WALKS a list of tiles and its operand stream never stops at a
-// tile boundary:
-//   * the (tile, step) pairs of a workgroup form ONE stream of 128-byte steps; the three register sets always hold the three
-//     steps after the one being multiplied, whichever tile they belong to -- a tile's first steps are in flight while the
-//     previous tile is still being multiplied, and the epilogue (bias, gathered row, activation, stores) of tile i runs with
-//     tile i + 1's first step already in LDS and its next two on their way;
-//   * 8 x spx workgroups (spx <= 64 per XCD = two per CU); XCD x owns a contiguous eighth of the point tiles, walks it in
-//     blocks of GP point tiles x GC channel tiles (GP * GC ~ 64 = the tiles in flight on the XCD, channel tile fastest), slot j
-//     of the XCD takes the block-ordered tiles j, j + spx, ...: the rows an XCD's L2 has to hold at any moment are the (GP + GC)
-//     x 128 rows of one block instead of all weight rows plus a few point tiles;
-//   * operand-gather indices (`choose`) of a tile are fetched one tile ahead of the offsets they turn into.
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(BLK, 2)
-mlp_pm_lds_persist_kernel(const PmParams p)
-{
-    constexpr int SZ = El<T>::SZ;
-    constexpr int CB = 128;                           // bytes of every row per step
-    constexpr int RS = CB + 16;                       // image row stride
-    constexpr int IMG = 128 * RS;                     // one operand image
-    constexpr int OOB = 0x7ffffff0;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [2 stages][W image | X image]
-
-    // this workgroup's tile list
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, spx = gridDim.x >> 3;
-    const int pt_lo = (p.n_pt * xcd) >> 3, npt_x = ((p.n_pt * (xcd + 1)) >> 3) - pt_lo;
-    const int ntile_x = npt_x * p.n_ct;
-    if (slot >= ntile_x) return;
-    if (p.probe & 3) {
-        // All workgroups of the launch multiply tiles of one size at one rate: left alone they reach their epilogues TOGETHER, the whole
-        // chip alternates between a phase without stores and a 32 MB burst of them (512 tiles x 64 KB), and since a wave's stores sit in
-        // the same in-order memory counter as its operand loads, every workgroup waits for the burst to drain.  Spreading the start of
-        // the workgroups over a fraction of a tile period turns the bursts into a steady write stream.
-        const int kbytes = (p.k1 + p.k2) * El<T>::SZ;
-        const int period = 2 * (kbytes / 128) * 4096;                        // cycles of a tile with the CU's matrix pipe shared by two workgroups
-        const int span = min(period, 4096 << (p.probe & 3));                 // 8 k / 16 k / 32 k cycles
-        const int ticks = (int)(((unsigned)slot * 2654435769u >> 16) * (unsigned)(span >> 6) >> 16);      // golden-ratio spread, units of 64 cycles
-        for (int i = 0; i < ticks; i += 8) __builtin_amdgcn_s_sleep(8);
-    }
-    const int GC = min(p.n_ct, p.gc_cap), GP = max(64 / GC, 1);
-    const int band = GP * p.n_ct;                     // tiles of a full band of GP point tiles
-    auto coords = [&](int idx, int& pt, int& ct) {
-        const int pb = min(idx / band, (npt_x - 1) / GP);
-        const int rem = idx - pb * band;
-        const int gp = min(GP, npt_x - pb * GP);
-        const int cb = min(rem / (gp * GC), (p.n_ct - 1) / GC);
-        const int rem2 = rem - cb * gp * GC;
-        const int gc = min(GC, p.n_ct - cb * GC);
-        const int pp = rem2 / gc;
-        pt = pt_lo + pb * GP + pp;
-        ct = cb * GC + (rem2 - pp * gc);
-    };
-
-    const int lane = threadIdx.x & 63;
-    const int l31 = lane & 31, kh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int K = p.k1 + p.k2;
-    const int kb1 = p.k1 * SZ, kbt = K * SZ;          // row bytes of x1, of [x1 | x2] (= of a W row)
-    const int nstage = kbt / CB;                      // the launcher guarantees whole steps
-
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)kbt);
-    const unsigned x1_rows = p.xidx ? (unsigned)(p.rows / p.P) * (unsigned)p.px : (unsigned)p.rows;
-    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, span_bytes(x1_rows, p.ld1, p.k1, SZ));
-    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? span_bytes((unsigned)p.rows, p.ld2, p.k2, SZ) : 0u);
-
-    // loader (as in mlp_pm_lds_kernel): thread -> 16-byte chunk lchunk of the segment of rows lrow + 32 i
-    const int lchunk = threadIdx.x & 7, lrow = threadIdx.x >> 3;
-
-    // prefetch cursor: tile pq of the list, step ps, the byte offsets of its rows; a cursor past the list reads zeros
-    int pq = slot, ps = 0;
-    int w_off[4], x1_off[4], x2_off[4], xi[4];
-    auto fetch_idx = [&](int q) {                     // operand-gather indices of the rows tile q will load (one tile ahead)
-        if (!p.xidx) return;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xi[i] = 0;
-        if (q >= ntile_x) return;
-        int pt, ct;
-        coords(q, pt, ct);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                 // rows past the end: the last row's index (loaded, never used)
-            const int r = min(pt * 128 + lrow + 32 * i, p.rows - 1);
-            xi[i] = p.idx64 ? (int)static_cast<const long long*>(p.xidx)[r] : static_cast<const int*>(p.xidx)[r];
-        }
-    };
-    auto set_offsets = [&](int q) {
-        const bool live = q < ntile_x;
-        int pt = 0, ct = 0;
-        if (live) coords(q, pt, ct);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = ct * 128 + lrow + 32 * i, r = pt * 128 + lrow + 32 * i;
-            w_off[i] = live && ch < p.cout ? ch * kbt + lchunk * 16 : OOB;
-            x1_off[i] = OOB;
-            x2_off[i] = OOB;
-            if (live && r < p.rows) {
-                const int xr = p.xidx ? (r / p.P) * p.px + xi[i] : r;
-                x1_off[i] = xr * p.ld1 * SZ + lchunk * 16;
-                x2_off[i] = r * p.ld2 * SZ + lchunk * 16;
-            }
-        }
-    };
-
-    struct Step { u32x4 w[4], x[4]; };                // one step of loads: 8 x 16 bytes per thread
-    auto gload = [&](Step& v) {                       // the step under the prefetch cursor; the cursor moves on
-        const int seg = ps * CB;
-        const bool first = seg < kb1;
-        const __amdgpu_buffer_rsrc_t rx = first ? rs_x1 : rs_x2;
-        const int xseg = first ? seg : seg - kb1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_off[i], seg, 0);
-            v.x[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, first ? x1_off[i] : x2_off[i], xseg, 0);
-        }
-        if (++ps == nstage) {
-            ps = 0;
-            pq += spx;
-            set_offsets(pq);
-            fetch_idx(pq + spx);
-        }
-    };
-    auto park = [&](const Step& v, int stage) {
-        unsigned char* wi = lds + stage * 2 * IMG;
-        unsigned char* xi_ = wi + IMG;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(wi + (lrow + 32 * i) * RS + lchunk * 16) = v.w[i];
-            *reinterpret_cast<u32x4*>(xi_ + (lrow + 32 * i) * RS + lchunk * 16) = v.x[i];
-        }
-    };
-
-    f32x16 acc[2][2];
-    auto clear = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    };
-    clear();
-
-    auto multiply = [&](int stage) {
-        const unsigned char* wi = lds + stage * 2 * IMG + (wm * 64 + l31) * RS + kh * 16;
-        const unsigned char* xim = lds + stage * 2 * IMG + IMG + (wn * 64 + l31) * RS + kh * 16;
-        u32x4 wa[2][2], xb[2][2];
-        auto frags = [&](int ks, u32x4 (&a)[2], u32x4 (&b)[2]) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const u32x4*>(wi + i * 32 * RS + ks * 32);
-                b[i] = *reinterpret_cast<const u32x4*>(xim + i * 32 * RS + ks * 32);
-            }
-        };
-        frags(0, wa[0], xb[0]);
-#pragma unroll
-        for (int ks = 0; ks < CB / 32; ++ks) {
-            if (ks + 1 < CB / 32) frags(ks + 1, wa[(ks + 1) & 1], xb[(ks + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_step<T, 2, 2>(acc, wa[ks & 1], xb[ks & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // Epilogue in WHOLE ROWS.  pm_epilogue stores MFMA fragments: one instruction touches 64 rows x 16 bytes (64 tag look-ups per
-    // KB, 32-byte write requests), and the gathered rows of Y are fetched the same way -- measured 2.5 us per tile without and 5 us
-    // with a gathered row, none of it hidden behind the CU's other workgroup (profiles/r04_gemm_pair_probe_fp32.txt: `noepi`).
-    // Here the finished tile goes through the LDS stage that has just been multiplied (free until the next park): two passes of
-    // 64 points x 128 channels (pass j = accumulator tiles [*][j] of every wave), fp32, row stride 528 bytes (an odd multiple of 16:
-    // conflict-free both ways); then a thread owns 4 consecutive channels of 8 rows per pass: one instruction reads, adds the
-    // gathered / added Y rows to and stores TWO whole 512-byte rows.  Same sums in the same order as pm_epilogue: identical results.
-    auto row_epilogue = [&](int c0, int r0, int stage) {
-        constexpr int ORS = 128 + 4;                                  // floats per staged row
-        float* const img = reinterpret_cast<float*>(lds + stage * 2 * IMG);
-        const T* const yb = static_cast<const T*>(p.y);
-        T* const ob = static_cast<T*>(p.out);
-        const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
-        const int chunk = threadIdx.x & 31, rsub = threadIdx.x >> 5;
-        const int ch = c0 + 4 * chunk;
-        const bool ch_ok = ch < p.cout;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && ch_ok) b4 = *reinterpret_cast<const float4*>(p.bias + ch);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            // this thread's 8 rows of the pass: staged row rho = rsub + 8 q -> output row r0 + 64 (rho >> 5) + 32 j + (rho & 31)
-            int orow[8];
-            long long yr[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int rho = rsub + 8 * q;
-                const int r = r0 + 64 * (rho >> 5) + 32 * j + (rho & 31);
-                orow[q] = r < p.rows && ch_ok ? r : -1;
-                yr[q] = r;
-                if (yb && p.gidx && orow[q] >= 0) {
-                    const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[r] : (long long)static_cast<const int*>(p.gidx)[r];
-                    yr[q] = (long long)(r / p.P) * p.py + gi;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(img + (wn * 32 + l31) * ORS + wm * 64 + i * 32 + 8 * g + 4 * kh) =
-                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-            __syncthreads();
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {                               // four rows at a time: loads first, then the arithmetic
-                float4 y4[4], v4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    y4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (yb && orow[4 * h + q] >= 0) y4[q] = El<T>::ld4(yb + yr[4 * h + q] * p.ldy + ch);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const float4*>(img + (rsub + 8 * (4 * h + q)) * ORS + 4 * chunk);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v = v4[q];
-                    if (p.bias) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-                    if (yb) { v.x += y4[q].x; v.y += y4[q].y; v.z += y4[q].z; v.w += y4[q].w; }
-                    if (orow[4 * h + q] >= 0)
-                        El<T>::st4(ob + (size_t)orow[4 * h + q] * p.ldo + ch,
-                                   make_float4(activate(v.x, slope), activate(v.y, slope), activate(v.z, slope), activate(v.w, slope)));
-                }
-            }
-            __syncthreads();
-        }
-    };
-
-    // compute cursor
-    int cq = slot, cs = 0, c0, r0;
-    {
-        int pt, ct;
-        coords(cq, pt, ct);
-        c0 = ct * 128;
-        r0 = pt * 128;
-    }
-    fetch_idx(pq);
-    set_offsets(pq);
-    fetch_idx(pq + spx);
-
-#define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
-#define FFB6D_LDS_ITER(FILL, NEXT)                                   \
-    gload(FILL);                        FFB6D_PIN();                 \
-    multiply(par);                      FFB6D_PIN();                 \
-    park(NEXT, par ^ 1);                                             \
-    __syncthreads();                                                 \
-    par ^= 1;                                                        \
-    if (++cs == nstage) {                                            \
-        if (p.probe & 8) {            /* PROBE ONLY: no epilogue (timing of the bare operand stream + MFMA) */ \
-            for (int i_ = 0; i_ < 2; ++i_) for (int j_ = 0; j_ < 2; ++j_) FFB6D_KEEP_LIVE(acc[i_][j_]); \
-        } else if (p.probe & 4) {     /* PROBE: the fragment-shaped epilogue of the tile kernels */ \
-            pm_epilogue<T, 2, 2, false, true>(p, acc, c0, r0, wm, wn, l31, kh); \
-        } else                                                       \
-            row_epilogue(c0, r0, par ^ 1);                           \
-        cs = 0;                                                      \
-        cq += spx;                                                   \
-        if (cq >= ntile_x) break;                                    \
-        clear();                                                     \
-        int pt, ct;                                                  \
-        coords(cq, pt, ct);                                          \
-        c0 = ct * 128;                                               \
-        r0 = pt * 128;                                               \
-    }
-    Step va, vb, vc;
-    gload(va);
-    gload(vb);
-    gload(vc);
-    park(va, 0);
-    __syncthreads();
-    int par = 0;
-    while (true) {
-        FFB6D_LDS_ITER(va, vb)
-        FFB6D_LDS_ITER(vb, vc)
-        FFB6D_LDS_ITER(vc, va)
-    }
-#undef FFB6D_LDS_ITER
-#undef FFB6D_PIN
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Attentive pooling with the score GEMM fused in (Att_pooling.forward up to the pooled tensor, RandLANet.py:243-248):
 //     S[(n,k), :] = [ F[nei[n,k], :] | G[(n,k), :] ]           feature set: gathered point rows | per-pair rows
 //     A = S * W_fc^T                                           scores, never written
@@ -1164,33 +901,22 @@ void launch_pm(PmParams& p, hipStream_t st)
 }
 
 template <typename T>
-void launch_lds(PmParams& p, hipStream_t st)
+bool launch_lds(PmParams& p, hipStream_t st)
 {
     p.n_ct = (int)ceil_div(p.cout, 128);
     p.n_pt = (int)ceil_div(p.rows, 128);
     constexpr size_t lds = 2 * 2 * 128 * (128 + 16);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pm_lds_kernel<T>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
+    static int attr_set[kMaxDevices];                                      // per device (common.h: device_slot)
+    int& done = attr_set[device_slot()];
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pm_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return false;
+        done = 1;
+    }
     const unsigned grid = (unsigned)(ceil_div(p.n_pt, 8) * p.n_ct * 8);
     hipLaunchKernelGGL((mlp_pm_lds_kernel<T>), dim3(grid), dim3(BLK), lds, st, p);
-}
-
-template <typename T>
-void launch_lds_persist(PmParams& p, hipStream_t st, int spx_cap, int gc_cap, int probe)
-{
-    p.gc_cap = gc_cap > 0 ? gc_cap : 8;
-    p.probe = probe;
-    p.n_ct = (int)ceil_div(p.cout, 128);
-    p.n_pt = (int)ceil_div(p.rows, 128);
-    constexpr size_t lds = 2 * 2 * 128 * (128 + 16);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pm_lds_persist_kernel<T>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
-    // slots per XCD: two workgroups per CU (LDS), fewer when an XCD's share of the tiles is smaller
-    const int64_t per_xcd = ceil_div(p.n_pt, 8) * p.n_ct;
-    const unsigned spx = (unsigned)std::min<int64_t>(spx_cap > 0 ? std::min(spx_cap, 64) : 64, per_xcd);
-    hipLaunchKernelGGL((mlp_pm_lds_persist_kernel<T>), dim3(8 * spx), dim3(BLK), lds, st, p);
+    return true;
 }
 
 template <typename T, int TM, int NS, bool LSM, bool TWO, bool HASY = false>
@@ -1203,13 +929,15 @@ void launch_stream(PmParams& p, hipStream_t st)
     constexpr size_t lds = 4 * IMG + (size_t)32 * TM * XS + (size_t)32 * TM * 4;                        // + the bias
     const void* fn = reinterpret_cast<const void*>(&mlp_pm_stream_kernel<T, TM, NS, LSM, TWO, HASY>);
     // resident workgroups per CU: registers (the X sets in flight + accumulators) and LDS (four wave images + the W copy)
-    static const int per_cu = [&] {
+    static int per_cu_of[kMaxDevices];                                     // per device (common.h: device_slot)
+    int& per_cu = per_cu_of[device_slot()];
+    if (per_cu == 0) {
         int n = 0;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, BLK, lds) != hipSuccess || n < 1)
             n = 1;
-        return n;
-    }();
+        per_cu = n;
+    }
     const unsigned grid = (unsigned)std::min<int64_t>(p.n_pt, (int64_t)256 * per_cu);
     hipLaunchKernelGGL((mlp_pm_stream_kernel<T, TM, NS, LSM, TWO, HASY>), dim3(grid), dim3(BLK), lds, st, p);
 }
@@ -1234,15 +962,6 @@ bool stream_form_ok(const PmParams& p, int64_t K)
            (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 &&
            (!p.y || ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.y) & (4 * SZ - 1)) == 0)) &&
            ((int64_t)p.rows + 256) * p.ldo * SZ < (1LL << 31) && !(p.act == 3 && (p.k2 > 0 || p.cout > 64));
-}
-
-// alignment of the 4-channel groups of the epilogue (what pm_epilogue's VEC form assumes)
-template <typename T>
-bool epilogue_vec_ok(const PmParams& p)
-{
-    constexpr uintptr_t AL = 4 * El<T>::SZ - 1;
-    return (p.cout & 3) == 0 && (p.ldo & 3) == 0 && (p.ldy & 3) == 0 &&
-           ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.y)) & AL) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
 }
 
 template <typename T>
@@ -1284,14 +1003,11 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
     p.ldy = (int)ldy; p.ldo = (int)ldo; p.P = (int)(indexed ? rows_per_frame : rows); p.py = (int)y_rows_per_frame;
     p.px = (int)x1_rows_per_frame; p.act = act;
     p.idx64 = idx_bits == 64;
-    p.gc_cap = 8;
-    p.probe = 0;
     hipStream_t st = as_stream(stream);
-    int choice = tile_hint & 0xff;                  // hint bits 8..15 / 16..23: persistent form's workgroups per XCD / channel tiles per block (tests, probes)
-    if (tile_hint <= 0) {
+    int choice = tile_hint;
+    if (choice <= 0) {
         choice = ffb6d_mlp_pm_choice(rows, cout, k1, k2, act, SZ == 2, x1_idx != nullptr);
         if (choice == 6 && !stream_form_ok<T>(p, K)) choice = ffb6d_mlp_pm_tile(rows, cout, K, act);      // misaligned rows
-        if (choice == 8 && !epilogue_vec_ok<T>(p)) choice = 7;
     }
     switch (choice) {
         case 1: launch_pm<T, 2, 2, 2, 2, false>(p, st); break;      // 128 ch x 128 pt
@@ -1335,14 +1051,7 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
         case 7:                                                     // LDS-tiled form: 128 ch x 128 pt, whole-row staging
             FFB6D_REQUIRE(act != 3 && (K * SZ) % 128 == 0 && (k1 * SZ) % 128 == 0,
                           "mlp_pm: the LDS-tiled form has no log_softmax epilogue and needs k1 * %d and K * %d to be multiples of 128", SZ, SZ);
-            launch_lds<T>(p, st);
-            break;
-        case 8:                                                     // the same, persistent workgroups, operand stream across tiles
-            FFB6D_REQUIRE(act != 3 && (K * SZ) % 128 == 0 && (k1 * SZ) % 128 == 0,
-                          "mlp_pm: the LDS-tiled form has no log_softmax epilogue and needs k1 * %d and K * %d to be multiples of 128", SZ, SZ);
-            FFB6D_REQUIRE(epilogue_vec_ok<T>(p), "mlp_pm: the persistent LDS-tiled form needs cout, ldo, ldy multiples of 4 and aligned rows");
-            launch_lds_persist<T>(p, st, tile_hint > 0 ? (tile_hint >> 8) & 0xff : 0, tile_hint > 0 ? (tile_hint >> 16) & 0xff : 0,
-                                  tile_hint > 0 ? (tile_hint >> 24) & 0xf : 0);
+            if (!launch_lds<T>(p, st)) return set_error(FFB6D_ERR_HIP, "mlp_pm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
             break;
         default: return set_error(FFB6D_ERR_ARG, "mlp_pm: unknown tile_hint %d", tile_hint);
     }

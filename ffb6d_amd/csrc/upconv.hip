@@ -40,19 +40,6 @@ upconv_combine_block_pm_kernel(const upconv::CombineArgs a)
     upconv::combine_block_body<T, FORM>(a, (int)by, (int)(bx * BLK + threadIdx.x));
 }
 
-// FFB6D_UPCONV_COMBINE = simple | select | static (A/B): one pixel per thread; 2 x 4 block with operand selects; the same
-// block with the compile-time operand pattern per tap (default: measured 2.2 - 2.8 TB/s, profiles/r03_upconv_blend_forms_ab.txt)
-int combine_form()
-{
-    static const int form = [] {
-        const char* v = getenv("FFB6D_UPCONV_COMBINE");
-        if (v && strcmp(v, "simple") == 0) return 0;
-        if (v && strcmp(v, "select") == 0) return 1;
-        return 2;
-    }();
-    return form;
-}
-
 }  // namespace
 }  // namespace ffb6d
 
@@ -79,18 +66,15 @@ extern "C" int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* sh
     a.rh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;       // ATen area_pixel_compute_scale, align_corners
     a.rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
     a.slope = slope;
-    const int form = combine_form();
-    static const bool banded = [] { const char* v = getenv("FFB6D_UPCONV_XCD"); return !(v && strcmp(v, "0") == 0); }();
-    a.banded = banded ? 1 : 0;
-    if (OH == 2 * IH && OW == 2 * IW && OW % 4 == 0 && dtype == 0 && form > 0) {
+    a.banded = 1;         // XCD-band workgroup order (measured +0-6 %, profiles/r03_upconv_blend_forms_ab.txt)
+    if (OH == 2 * IH && OW == 2 * IW && OW % 4 == 0 && dtype == 0) {
         // fp32 rows only: with 8-channel bf16 units the 2 x 4 block does not fit the register file without spilling
         a.nbx = (unsigned)ceil_div(OW / 4 * (int64_t)a.q, BLK);
         a.nby = (unsigned)(B * OH / 2);
         const dim3 grid((unsigned)(8 * ceil_div((int64_t)a.nbx * a.nby, 8)));
-        if (form == 2)
-            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, 2>), grid, dim3(BLK), 0, as_stream(stream), a);
-        else
-            hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, 1>), grid, dim3(BLK), 0, as_stream(stream), a);
+        // 2 x 4 output pixels per thread with the compile-time operand pattern per tap: 2.2-2.8 TB/s against 1.5-1.8 for one pixel
+        // per thread and 1.9-2.4 for per-element operand selects (profiles/r02_upconv_blend_forms_ab.txt; both A/B forms removed)
+        hipLaunchKernelGGL((upconv_combine_block_pm_kernel<float, 2>), grid, dim3(BLK), 0, as_stream(stream), a);
     } else {
         a.nbx = (unsigned)ceil_div(OW * (int64_t)a.q, BLK);
         a.nby = (unsigned)(B * OH);

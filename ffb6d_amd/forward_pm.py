@@ -100,16 +100,15 @@ def fc_weight(att, dt=F32):
 # ----------------------------------------------------------------------------------------------------
 # point branch
 # ----------------------------------------------------------------------------------------------------
-# relative_pos_encoding + lfa.mlp1 as one vector-ALU pass (csrc/posenc.hip; default) instead of the padded encoding tensor +
-# a K = 16 GEMM (FFB6D_POSENC_FUSED=0, kept for A/B: profiles/r02_opt_in_forms_ab.json)
-POSENC_FUSED = __import__("os").environ.get("FFB6D_POSENC_FUSED", "1").strip() not in ("", "0")
-# BatchNorm + ReLU + MaxPool2d(3,2,1) of the colour stem as one kernel (FFB6D_STEM_FUSED=0: affine_act + torch's max pooling)
-STEM_FUSED = __import__("os").environ.get("FFB6D_STEM_FUSED", "1").strip() not in ("", "0")
-
-
-# One launch per half of the local feature aggregation (csrc/lfa_pm.hip; default): the per-pair tensors live in LDS only.
-# FFB6D_LFA_FUSED=0 keeps the round-2 chain posenc_mlp -> att_pool -> mlp (six launches, [B,N,16,d/2] through HBM) for A/B.
-LFA_FUSED = __import__("os").environ.get("FFB6D_LFA_FUSED", "1").strip() not in ("", "0")
+# Module attributes, not environment switches: the measured forms are the defaults; tests and A/B scripts flip an attribute to
+# reach the chain a fused kernel replaced (profiles/r02_opt_in_forms_ab.json, profiles/r03_lfa_levels.txt).
+# relative_pos_encoding + lfa.mlp1 as one vector-ALU pass (csrc/posenc.hip) instead of the padded encoding tensor + a K = 16 GEMM
+POSENC_FUSED = True
+# BatchNorm + ReLU + MaxPool2d(3,2,1) of the colour stem as one kernel (False: affine_act + torch's max pooling)
+STEM_FUSED = True
+# One launch per half of the local feature aggregation (csrc/lfa_pm.hip): the per-pair tensors live in LDS only.
+# False: the round-2 chain posenc_mlp -> att_pool -> mlp (six launches, [B,N,16,d/2] through HBM).
+LFA_FUSED = True
 LFA_WIDTHS = (32, 64, 128, 256)
 
 
@@ -213,23 +212,11 @@ def pyramid_pooling(pp, x):
     return ops_pm.mlp(x, wx, pp.bottleneck.bias.detach().float(), ops.ACT_RELU, add=prior, role="cnn")
 
 
-# Which PSPUpsample blocks run in the folded form (csrc/upconv.hip).  FFB6D_UPCONV_FOLD: "auto" (default) = every block in
-# fp32, none in bf16 (measured, profiles/r02_opt_in_forms_ab.json: fp32 step 28.8 -> 23.8 ms; in bf16 MIOpen's convolution of
-# the up-sampled map is faster than the z GEMM + the tap blend, 17.2 -> 18.1 ms); "0" = none, "1" = every block in both
-# precisions, or a comma-separated list of input widths ("1024,256").
-def _fold_setting():
-    import os
-    v = os.environ.get("FFB6D_UPCONV_FOLD", "auto").strip()
-    if v == "auto":
-        return "auto"
-    if v in ("", "0"):
-        return frozenset()
-    if v == "1":
-        return None                                       # every block
-    return frozenset(int(t) for t in v.split(","))
-
-
-UPCONV_FOLD = _fold_setting()
+# Which PSPUpsample blocks run in the folded form (csrc/upconv.hip): "auto" = every block in fp32, none in bf16 (measured,
+# profiles/r02_opt_in_forms_ab.json: fp32 step 28.8 -> 23.8 ms; in bf16 MIOpen's convolution of the up-sampled map is faster than the
+# z GEMM + the tap blend, 17.2 -> 18.1 ms); None = every block in both precisions; a frozenset of input widths = those blocks
+# (tests / A/B set the attribute).
+UPCONV_FOLD = "auto"
 
 
 def _fold_block(cin, dtype):
@@ -339,10 +326,10 @@ PYRAMID_KEYS = ([k % i for i in range(4) for k in ('cld_xyz%d', 'cld_nei_idx%d',
 
 
 class StreamedPyramid(dict):
-    """The input dict of a forward whose index pyramid (linemod_dataset.py:299-353) is not built yet: the seven levels
-    are enqueued, in the order the network consumes them, on a third (high-priority) HIP stream; `level(i, stream)` /
-    `up_level(i, stream)` make `stream` wait for that level only.  The point branch starts after ~0.5 ms of searches
-    instead of the whole 2.2 ms pyramid, the rest runs under the network."""
+    """The input dict of a forward whose index pyramid (linemod_dataset.py:299-353) is not built yet: it is built on a third
+    (high-priority) HIP stream under the colour stem; `level(i, stream)` / `up_level(i, stream)` make `stream` wait for the event of
+    that level.  Since round 3 the builder launches all 22 searches as one batch (pyramid.PyramidBuilder), so the events of all seven
+    levels fire together ~1 ms after the forward starts (round 2: level 0 after 0.5 ms, the last one after 2.2 ms)."""
 
     def __init__(self, net, inputs, main, side):
         super().__init__(inputs)

@@ -234,8 +234,10 @@ class PyramidPooling(nn.Module):
             nn.Sequential(nn.AdaptiveAvgPool2d((s, s)), nn.Conv2d(ch, ch, 1, bias=False)) for s in sizes)
         self.bottleneck = nn.Conv2d(ch * (len(sizes) + 1), out_ch, 1)
 
+    fold_in_training = True      # class attribute (tests flip it): the module's linear maps folded into matrix products (forward_folded)
+
     def forward(self, x):
-        if x.is_cuda and os.environ.get("FFB6D_PSP_TRAIN_FOLD", "1") != "0":
+        if x.is_cuda and self.fold_in_training:
             return self.forward_folded(x)
         h, w = x.shape[2:]
         pri = [F.interpolate(st(x), size=(h, w), mode="bilinear", align_corners=False) for st in self.stages]

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-end records on the GPU box, all from HEAD's defaults:  bash scripts/round_end.sh r03   (through gpurun; ~12 minutes)
+# Round-end records on the GPU box, all from HEAD's defaults:  bash scripts/round_end.sh r04   (through gpurun; ~12 minutes)
 #   1. scripts/profile_round.sh: kernel stats + PMC FETCH_SIZE / WRITE_SIZE passes of the default bench
 #   2. the default bench line with cpu_baseline                                   -> <tag>_bench_default_run.json
 #   3. configurations 4 and 5: bench line with cpu_baseline + rocprofv3 kernel stats -> <tag>_bench_config{4,5}_run.json, <tag>_kernels_config{4,5}.txt
 #   4. per-op / per-shape table on one stream                                      -> <tag>_hot_path_ops_by_shape_one_stream.txt
 #   5. fused LFA: level table and PMC of the level-0 launch; MFMA-busy PMC of the dominant GEMM
 #   6. training step (bf16 autocast and fp32; MIOpen's cold start alone is ~100 s: generous limits) + its kernel statistics
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.." || exit 1
 REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
 bash scripts/profile_round.sh "$TAG" > /dev/null
@@ -29,7 +29,7 @@ for P in bf16 fp32; do
     timeout 400 python bench.py --mode train --precision $P --steps 8 --warmup 3 --no-cpu-baseline --cudnn-benchmark 0 \
         > "$OUT/${TAG}_bench_train_$P.json" 2> "$OUT/${TAG}_bench_train_$P.err"
 done
-timeout 300 bash scripts/prof_train.sh --precision bf16 > /dev/null 2>&1; cp "$OUT/r03_train_kernels.txt" "$OUT/${TAG}_rocprofv3_kernel_stats_train_bf16.txt"
+timeout 300 bash scripts/prof_train.sh --precision bf16 > /dev/null 2>&1; cp "$OUT/train_kernels.txt" "$OUT/${TAG}_rocprofv3_kernel_stats_train_bf16.txt"; cp "$OUT/train_under_rocprof.json" "$OUT/${TAG}_bench_train_bf16_under_rocprof.json"
 python -c "
 import json
 for n in ('default', 'config4', 'config5'):

@@ -101,7 +101,7 @@ def build():
         return LIB
     os.makedirs(OUT, exist_ok=True)
     srcs = [transformed(n) for n in KERNEL_SOURCES] + [os.path.join(HERE, "simt.cpp")]
-    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value",
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value", "-Wno-psabi",
            "-Wno-unknown-attributes", "-I" + os.path.join(HERE, "fake"), "-I" + HERE, "-I" + os.path.join(ROOT, "include"),
            "-I" + CSRC] + srcs + ["-o", LIB + ".tmp"]
     subprocess.run(cmd, check=True)

@@ -54,6 +54,7 @@ static inline hipError_t hipMemcpy(void* d, const void* s_, size_t n, hipMemcpyK
 static inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s_, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 #define HIP_SYMBOL(x) (&(x))
 static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n) { memcpy(sym, src, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
@@ -71,6 +72,8 @@ static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 template <typename T> static inline T atomicMax(T* p, T v) { const T old = *p; if (v > old) *p = v; return old; }
 template <typename T> static inline T atomicMin(T* p, T v) { const T old = *p; if (v < old) *p = v; return old; }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned old = *p; *p = old + v; return old; }
 static inline float atomicAdd(float* p, float v) { const float old = *p; *p = old + v; return old; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long old = *p; *p = old + v; return old; }
@@ -248,7 +251,7 @@ typedef simt::Rsrc __amdgpu_buffer_rsrc_t;
 // scheduling hints and hardware-id reads: no functional effect on the emulator (workgroups run one after the other)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
-#define __builtin_amdgcn_s_getreg(x) (0u)
+#define __builtin_amdgcn_s_getreg(reg_) ((((reg_) & 63) == 20) ? (unsigned)(blockIdx.x & 7u) : 0u)      /* HW_REG_XCC_ID: workgroup b on XCD b % 8 */
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __shfl_xor(v, mask, ...) simt::shfl_xor(v, mask)

@@ -40,3 +40,34 @@ def test_bench_train_mode_wraps_ddp_on_two_ranks():
                   "--batch", "1", "--cudnn-benchmark", "0")
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2
     assert "train" in line["metric"] and line["value"] > 0
+
+
+def test_bench_spawns_eight_ranks_on_the_one_gpu():
+    """the 8-GPU launch of BASELINE configuration 3's inference half, rehearsed on one GPU: eight processes (per-rank MIOpen caches, eight
+    contexts in 288 GB, batch 2 per rank to keep it short) over gloo -- spawn, sharding, barrier and MAX-over-ranks timing as the driver's
+    `--gpus 8` run will exercise them"""
+    line = _bench("--gpus", "8", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--cudnn-benchmark", "0",
+                  "--batch", "2", timeout=900)
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
+    assert abs(line["value"] - 16 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+
+
+def test_bench_train_mode_wraps_ddp_on_eight_ranks():
+    """... and the training half: DistributedDataParallel over eight ranks (one frame each), gradient all-reduce every step"""
+    line = _bench("--gpus", "8", "--dist-backend", "gloo", "--mode", "train", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                  "--batch", "1", "--cudnn-benchmark", "0", timeout=1200)
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8
+    assert "train" in line["metric"] and line["value"] > 0
+
+
+def test_training_step_record_in_bf16(capsys):
+    """the single-GPU training step of BASELINE configuration 3's shape (forward + backward + Adam, bs = 8, N = 12288, bf16 autocast, the
+    reference's objective): the record the driver's GPU-test log carries for SURVEY 8f-3.  Measured 148 frames/s
+    (profiles/r04_start_bench_train_bf16_optin.json); the floor asserted here is what round 3 had measured (110) -- a regression guard,
+    not a target."""
+    line = _bench("--mode", "train", "--precision", "bf16", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--cudnn-benchmark", "0",
+                  timeout=900)
+    with capsys.disabled():
+        print("\n[train bf16 bs=8] %.1f frames/s, %.1f ms/step" % (line["value"], line["ms_per_step"]))
+    assert "train" in line["metric"] and line["config"]["global_batch"] == 8
+    assert line["value"] >= 110.0, line["value"]

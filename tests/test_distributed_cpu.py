@@ -12,6 +12,33 @@ import numpy as np
 from conftest import ROOT
 
 
+def run_ranks(script, world, tmp_path, timeout, **extra_env):
+    """one process per rank; every rank's output goes to its own FILE (a pipe that the parent reads rank by rank fills up when a
+    later rank is chatty -- e.g. rebuilds the emulated library -- and the ranks then deadlock in their first collective)"""
+    port = free_port()
+    procs, logs = [], []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   **extra_env)
+        log = open(tmp_path / ("rank%d.log" % rank), "w+")
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=log, stderr=subprocess.STDOUT, text=True))
+    try:
+        for p in procs:
+            p.wait(timeout=timeout)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    outs = []
+    for log in logs:
+        log.seek(0)
+        outs.append(log.read())
+        log.close()
+    assert all(p.returncode == 0 for p in procs), [o[-3000:] for o in outs]
+    return outs
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -53,15 +80,7 @@ WORKER = textwrap.dedent("""
 def test_two_rank_gloo_harness(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    port = free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=120)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    outs = run_ranks(script, 2, tmp_path, 120)
     res = [json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs]
     res.sort(key=lambda r: r["rank"])
     assert [r["world"] for r in res] == [2, 2]
@@ -91,6 +110,41 @@ def test_single_process_group_is_a_noop():
     n = []
     t = D.timed_steps(lambda timed: n.append(timed), warmup=1, steps=2, group=g)
     assert n == [False, True, True] and t >= 0
+
+
+EIGHT_WORKER = textwrap.dedent("""
+    import hashlib, json, os, sys
+    sys.path.insert(0, %r)
+    import torch
+    from ffb6d_amd import distributed as D
+    g = D.init_from_env(backend="gloo")
+    frames = D.shard_frames(3, 2, g.rank, None, n_points=256, height=60, width=80)
+    digests = [hashlib.sha256(frames["cld"][i].tobytes() + frames["rgb"][i].tobytes()).hexdigest() for i in range(2)]
+    t = D.timed_steps(lambda timed: None, warmup=1, steps=2, group=g)
+    total = g.sum_over_ranks(float(g.rank))
+    slowest = g.max_over_ranks(float(g.rank))
+    print("RESULT " + json.dumps(dict(rank=g.rank, world=g.world, digests=digests, total=total, slowest=slowest, t=t)))
+    g.close()
+""") % ROOT
+
+
+def test_eight_rank_sharding_is_disjoint_and_covers_the_global_batch(tmp_path):
+    """BASELINE configuration 3's launch shape on CPU: eight gloo ranks, two frames each -- every rank holds frames
+    [2r, 2r + 2) of the synthetic stream (all sixteen different, the same frames a single process would generate for those seeds),
+    the control collectives (barrier, MAX / SUM over ranks) see all eight ranks"""
+    from ffb6d_amd import synth
+    script = tmp_path / "eight_worker.py"
+    script.write_text(EIGHT_WORKER)
+    outs = run_ranks(script, 8, tmp_path, 600, OMP_NUM_THREADS="1")
+    res = sorted((json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs), key=lambda r: r["rank"])
+    assert [r["rank"] for r in res] == list(range(8)) and all(r["world"] == 8 for r in res)
+    assert all(r["total"] == 28.0 and r["slowest"] == 7.0 for r in res)
+    digests = [d for r in res for d in r["digests"]]
+    assert len(set(digests)) == 16
+    import hashlib
+    for s in (0, 5, 15):            # rank s // 2 holds sample s of the stream
+        f = synth.make_frame(synth.frame_seed(3, s), n_points=256, height=60, width=80)
+        assert hashlib.sha256(f["cld"].tobytes() + f["rgb"].tobytes()).hexdigest() == digests[s]
 
 
 TRAIN_WORKER = textwrap.dedent("""
@@ -133,14 +187,7 @@ def test_two_rank_training_step_averages_gradients_through_the_custom_operators(
     custom autograd Functions (non-tensor arguments, shared plans) are DDP-clean."""
     script = tmp_path / "train_worker.py"
     script.write_text(TRAIN_WORKER)
-    port = free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="4")
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=900)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), [o[-3000:] for o in outs]
+    outs = run_ranks(script, 2, tmp_path, 900, OMP_NUM_THREADS="4")
     res = sorted((json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]) for o in outs), key=lambda r: r["rank"])
     for name in res[0]["local"]:
         l0, l1 = np.array(res[0]["local"][name]), np.array(res[1]["local"][name])

@@ -287,18 +287,30 @@ def test_forward_builds_the_index_pyramid_itself_when_it_is_missing(device, two_
 
 
 def test_batch_items_are_independent(device):
-    """Every op on the path is per-sample in eval mode: a frame's
-    result must not depend on its batch neighbours -- the property multi-GPU sharding relies on."""
-    frames = synth.make_batch(7, 3, n_points=1024, height=120, width=160)
-    net = build(5, 1024, device)
-    inputs = pyramid.frames_to_device(frames, device)
-    one = {k: v[1:2].contiguous() for k, v in inputs.items()}
-    with torch.no_grad():
-        full = net(inputs)
-        single = net(one)
-    for k in full:   # MIOpen may pick another algorithm per batch size: compare at range scale
-        scale = float(full[k].abs().max())
-        assert float((full[k][1:2] - single[k]).abs().max()) <= 1e-3 * scale, k
+    """Every op on the path is per-sample in eval mode: a frame's result must not depend on its batch
+    neighbours -- the property multi-GPU sharding relies on.  Two checks: (1) the same frame between DIFFERENT neighbours in batches
+    of the same size (same MIOpen algorithms, cudnn.benchmark off: whatever differs comes from the batch neighbours) -- equal to
+    1e-6 of the output range (measured: bit-identical; the bar leaves room for an atomics-based MIOpen algorithm); (2) the frame alone
+    against the frame in a batch of three, where MIOpen may pick another algorithm per batch size: 1e-3 of range as before."""
+    keep = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
+    try:
+        frames = synth.make_batch(7, 5, n_points=1024, height=120, width=160)
+        net = build(5, 1024, device)
+        inputs = pyramid.frames_to_device(frames, device)
+        pick = lambda idx: {k: v[idx].contiguous() for k, v in inputs.items()}       # noqa: E731
+        with torch.no_grad():
+            a = net(pick([0, 1, 2]))
+            b = net(pick([3, 1, 4]))
+            single = net(pick([1]))
+        for k in a:
+            scale = float(a[k].abs().max())
+            err = float((a[k][1] - b[k][1]).abs().max()) / scale
+            print(k, "same frame, other neighbours: max err / range", err)
+            assert err <= 1e-6, (k, err)
+            assert float((a[k][1:2] - single[k]).abs().max()) <= 1e-3 * scale, k
+    finally:
+        torch.backends.cudnn.benchmark = keep
 
 
 @pytest.mark.parametrize("n_pts,height,width", [(1024, 120, 160), (1100, 136, 168)])      # the second: ragged against every tile size

@@ -171,17 +171,14 @@ def test_forward_on_cpu_tensors_fails_loudly():
         net(inputs)
 
 
-def test_upconv_fold_switch_parsing(monkeypatch):
-    """FFB6D_UPCONV_FOLD: auto (fp32 only, default) / 0 / 1 / list of input widths (forward_pm._fold_setting)"""
+def test_upconv_fold_policy(monkeypatch):
+    """forward_pm.UPCONV_FOLD: "auto" (fp32 only, the default) / None (every block) / a set of input widths"""
     import torch
     from ffb6d_amd import forward_pm
-    for env, want32, want16, want_other in (("auto", True, False, True), (None, True, False, True), ("0", False, False, False),
-                                            ("1", True, True, True), ("1024,256", True, True, False)):
-        if env is None:
-            monkeypatch.delenv("FFB6D_UPCONV_FOLD", raising=False)
-        else:
-            monkeypatch.setenv("FFB6D_UPCONV_FOLD", env)
-        monkeypatch.setattr(forward_pm, "UPCONV_FOLD", forward_pm._fold_setting())
+    assert forward_pm.UPCONV_FOLD == "auto"
+    for setting, want32, want16, want_other in (("auto", True, False, True), (frozenset(), False, False, False),
+                                                (None, True, True, True), (frozenset((1024, 256)), True, True, False)):
+        monkeypatch.setattr(forward_pm, "UPCONV_FOLD", setting)
         assert forward_pm._fold_block(1024, torch.float32) is want32
         assert forward_pm._fold_block(1024, torch.bfloat16) is want16
         assert forward_pm._fold_block(64, torch.float32) is want_other

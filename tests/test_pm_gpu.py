@@ -47,10 +47,6 @@ CASES += [(2, 777, 40, 24, 72, 2, 50, 6), (1, 100000, 64, 0, 64, 1, 0, 6), (2, 5
 # test_..._operand_gather; the last one is picked by tile_hint 0
 CASES += [(1, 4800, 1024, 0, 1024, 1, 48, 7), (2, 777, 32, 32, 72, 2, 50, 7), (1, 4100, 256, 0, 200, 1, -1, 7), (8, 192, 512, 256, 256, 2, 0, 7),
           (3, 301, 96, 0, 37, 1, 13, 7), (1, 130, 32, 0, 8, 0, 0, 7), (1, 70000, 256, 0, 256, 1, 0, 0)]
-# the persistent LDS-tiled form (hint 8: workgroups walk tile lists, the operand stream crosses tile boundaries); the second and
-# third cap the workgroups per XCD (hint bits 8..) so that every workgroup walks many tiles
-CASES += [(1, 4800, 1024, 0, 1024, 1, 48, 8), (2, 7770, 32, 32, 72, 2, 50, 8 + (1 << 8)), (1, 41000, 256, 0, 200, 1, -1, 8 + (5 << 8)),
-          (8, 192, 512, 256, 256, 2, 0, 8), (3, 301, 96, 0, 36, 1, 13, 8), (1, 130, 32, 0, 8, 0, 0, 8)]
 
 
 @pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", CASES)
@@ -87,35 +83,6 @@ def test_mlp_pm_channel_slices_and_int32_indices(device):
     assert torch.isnan(out_wide[..., :16]).all() and torch.isnan(out_wide[..., 64:]).all()   # neighbours untouched
 
 
-# the bench step's launches of the LDS-tiled form (bs = 8): (rows, K1, K2, cout, gathered epilogue rows per frame, `choose` gather)
-PERSIST_SHAPES = [(38400, 1024, 0, 1024, 48, False), (38400, 512, 0, 512, 192, False), (153600, 256, 0, 256, 192, False),
-                  (98304, 64, 64, 128, 0, True), (153600, 256, 0, 576, 0, False), (102400, 64, 0, 576, 0, False), (38400, 512, 0, 1024, 0, False)]
-
-
-@pytest.mark.parametrize("rows,K1,K2,cout,py,xg", PERSIST_SHAPES)
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_persistent_lds_form_is_bit_identical_to_the_tile_per_workgroup_form(device, rows, K1, K2, cout, py, xg, dt):
-    """mlp_pm_lds_persist_kernel on the shapes of the benchmarked step: same bits as mlp_pm_lds_kernel (same products in the same
-    k order per accumulator), every tile written exactly once (the output starts as NaN)"""
-    g = torch.Generator().manual_seed(rows + cout)
-    B = 8
-    P = rows // B
-    M = 2 * P
-    src = torch.randn(B, M if xg else P, K1, generator=g).to(dt).to(device)
-    pick = torch.randint(0, M, (B, P), generator=g).to(device) if xg else None
-    x2 = torch.randn(B, P, K2, generator=g).to(dt).to(device) if K2 else None
-    w = (torch.randn(cout, K1 + K2, generator=g) / (K1 + K2) ** 0.5).to(dt).to(device)
-    bias = torch.randn(cout, generator=g).to(device)
-    gather = (torch.randn(B, py, cout, generator=g).to(dt).to(device), torch.randint(0, py, (B, P), generator=g).to(device)) if py else None
-    outs = []
-    for hint in (7, 8, 8 + (7 << 8)):
-        out = torch.full((B, P, cout), float("nan"), device=device, dtype=dt)
-        ops_pm.mlp(src, w, bias, 1, x2=x2, gather=gather, x1_gather=pick, out=out, tile_hint=hint)
-        outs.append(out)
-    assert not torch.isnan(outs[0]).any()
-    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
-
-
 def test_mlp_pm_rejects_what_it_cannot_do(device):
     from ffb6d_amd import _lib
     x = torch.randn(1, 10, 12, device=device)
@@ -137,7 +104,7 @@ def test_mlp_pm_operand_gather_and_log_softmax(device):
     bias = torch.randn(128, generator=g)
     picked = torch.gather(img, 1, choose.unsqueeze(2).expand(-1, -1, 64))
     want = _ref(picked, w, bias, 1, pts)
-    for dt, hint in ((torch.int64, 0), (torch.int32, 0), (torch.int64, 7), (torch.int64, 8), (torch.int32, 8 + (1 << 8))):     # 7, 8: the LDS-tiled forms' loaders gather too
+    for dt, hint in ((torch.int64, 0), (torch.int32, 0), (torch.int64, 7)):          # 7: the LDS-tiled form's loader gathers too
         got = ops_pm.mlp(img.to(device), w.to(device), bias.to(device), ops.ACT_RELU, x2=pts.to(device),
                          x1_gather=choose.to(device).to(dt), tile_hint=hint).cpu()
         torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)

@@ -39,8 +39,6 @@ CASES = [(2, 130, 24, 8, 37, 1, 13, h) for h in (1, 2, 3, 4, 5)]                
 CASES += [(1, 300, 64, 0, 64, 1, 0, 6), (2, 201, 24, 0, 16, 0, 0, 6), (1, 260, 32, 96, 100, 2, 70, 6), (1, 130, 128, 0, 128, 1, -1, 6),
           (2, 300, 64, 0, 64, 1, 37, 6), (3, 50, 32, 0, 24, 2, 9, 6)]  # stream form (the last two: Y rows fetched ahead of the tile prefetch)
 CASES += [(1, 300, 96, 0, 40, 0, 0, 7), (2, 140, 32, 32, 72, 2, 50, 7), (1, 257, 256, 0, 200, 1, -1, 7), (8, 24, 512, 256, 256, 2, 0, 7)]  # LDS-tiled form
-# persistent LDS-tiled form (hint 8; bits 8.. cap the workgroups per XCD so that one workgroup walks several tiles)
-CASES += [(1, 300, 96, 0, 40, 0, 0, 8), (2, 140, 32, 32, 72, 2, 50, 8 + (1 << 8)), (1, 257, 256, 0, 200, 1, -1, 8), (8, 24, 512, 256, 256, 2, 0, 8)]
 CASES += [(8, 48, 1024, 0, 64, 1, 0, 5), (1, 33, 8, 8, 5, 1, 0, 0), (1, 1, 8, 0, 8, 0, 0, 0), (2, 64, 128, 0, 22, 0, 0, 0)]      # K split, tiny, automatic choice
 
 
@@ -72,7 +70,7 @@ def test_log_softmax_epilogue_on_the_emulator(emu, hint):
     assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("hint", [1, 2, 7, 8, 8 + (1 << 8)])
+@pytest.mark.parametrize("hint", [1, 2, 7])
 @pytest.mark.parametrize("idt", [torch.int64, torch.int32])
 def test_operand_gather_on_the_emulator(emu, hint, idt):
     """`choose` (ffb6d.py:309-312): the gather of the picked pixel rows IS the operand load of the head GEMM"""
@@ -100,7 +98,7 @@ def test_kernel_forms_are_bit_identical_on_the_emulator(emu):
         assert torch.equal(o, outs[0])
 
 
-@pytest.mark.parametrize("hint", [1, 2, 5, 6, 7, 8])
+@pytest.mark.parametrize("hint", [1, 2, 5, 6, 7])
 def test_mlp_pm_bf16_on_the_emulator(emu, hint):
     """bf16 rows, fp32 accumulation (v_mfma_f32_32x32x16_bf16): against float64 on the bf16-rounded operands, bar = one bf16
     rounding of the output"""
@@ -131,37 +129,6 @@ def test_lds_tiled_bf16_prefetch_past_the_last_step(emu, K1, K2, cout, rows):
     got = ops_pm.mlp(x1, w, bias, 1, x2=x2, tile_hint=7)
     assert float((got.double() - want).abs().max()) <= 1e-2 * float(want.abs().max())
     assert torch.equal(got, ops_pm.mlp(x1, w, bias, 1, x2=x2, tile_hint=1))
-
-
-# (rows, K1, K2, cout, workgroups per XCD, gathered operand, gathered epilogue rows)
-PERSIST = [(1300, 32, 0, 300, 1, False, 0),        # 11 x 3 tiles on 8 workgroups: several tiles each, ragged rows and channels, one-step tiles
-           (2100, 64, 0, 132, 2, False, 40),       # 17 x 2 tiles, two steps, gathered epilogue rows
-           (1100, 32, 32, 128, 1, True, 0),        # `choose` operand gather fetched one tile ahead, two sources
-           (9 * 128, 96, 0, 1200, 3, False, 0)]    # 9 x 10 tiles: ragged blocks of the XCD walk (GC = 8, then 2 channel tiles)
-
-
-@pytest.mark.parametrize("rows,K1,K2,cout,spx,xg,py", PERSIST)
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_persistent_lds_form_walks_its_tile_lists(emu, rows, K1, K2, cout, spx, xg, py, dt):
-    """mlp_pm_lds_persist_kernel: a workgroup's operand stream runs across tile boundaries (three steps ahead, whichever tile they
-    belong to); every tile of the launch is produced exactly once and equals the one-tile-per-workgroup kernel bit for bit"""
-    g = torch.Generator().manual_seed(rows + cout)
-    if dt == torch.bfloat16:                   # rows of whole 128-byte segments
-        K1, K2 = 2 * K1, 2 * K2
-    B = 2 if rows % 2 == 0 else 1
-    P = rows // B
-    M = 3 * P + 5
-    src = torch.randn(B, M if xg else P, K1, generator=g).to(dt)
-    pick = torch.randint(0, M, (B, P), generator=g) if xg else None
-    x2 = torch.randn(B, P, K2, generator=g).to(dt) if K2 else None
-    w = (torch.randn(cout, K1 + K2, generator=g) / (K1 + K2) ** 0.5).to(dt)
-    bias = torch.randn(cout, generator=g)
-    gather = (torch.randn(B, py, cout, generator=g).to(dt), torch.randint(0, py, (B, P), generator=g)) if py else None
-    got = ops_pm.mlp(src, w, bias, 2, x2=x2, gather=gather, x1_gather=pick, tile_hint=8 + (spx << 8))
-    want = ops_pm.mlp(src, w, bias, 2, x2=x2, gather=gather, x1_gather=pick, tile_hint=7)
-    assert torch.equal(got, want)
-    ref = _ref(src, w, bias, 2, x2=x2, gather=gather, x1_gather=pick)
-    assert float((got.double() - ref).abs().max()) <= (1e-5 if dt == torch.float32 else 1e-2) * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("B,N,C1,C2,idt", [(2, 50, 16, 16, torch.int64), (1, 37, 32, 32, torch.int32), (1, 20, 64, 64, torch.int64),
@@ -228,10 +195,9 @@ def test_fused_lfa_persistent_loop_on_the_emulator(emu, monkeypatch, B, N, d, p_
     """the software pipeline over the point groups of a workgroup (indices two groups ahead, gathered rows one group ahead):
     one workgroup per XCD, so every workgroup walks several groups, the last ones ragged"""
     from oracle import ops_ref
-    monkeypatch.setenv("FFB6D_LFA_WG_PER_XCD", "1")
     a = _lfa_case(B, N, d, mode, torch.float32, torch.int64, seed=N + d)
     kw = dict(w2=a["w2"], b2=a["b2"], act2=2) if mode == 2 else {}
-    got = ops_pm.lfa_half(mode, a["xyz"], a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2, p_hint=p_hint, **kw)
+    got = ops_pm.lfa_half(mode, a["xyz"], a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2, p_hint=p_hint + (1 << 8), **kw)
     want = ops_ref.lfa_half(mode, a["xyz"], a["nei"], a["f"], a["w1"], a["b1"], 2, a["wfc"], a["wm"], a["bm"], 2, **kw)
     assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 

@@ -144,7 +144,7 @@ def test_pyramid_pooling_training_fold_on_the_device(device, monkeypatch):
     dev_type = "cuda" if torch.cuda.is_available() else "cpu"           # --emulate: CPU tensors, CPU autocast
 
     def run(fold, autocast):
-        monkeypatch.setenv("FFB6D_PSP_TRAIN_FOLD", fold)
+        monkeypatch.setattr(M.PyramidPooling, "fold_in_training", fold == "1")
         pp.zero_grad()
         xs = x.clone().requires_grad_(True)
         with torch.autocast(dev_type, dtype=torch.bfloat16, enabled=autocast):
