@@ -299,7 +299,16 @@ class _UpsampleAlign(torch.autograd.Function):
     def forward(ctx, x, size):
         ctx.in_shape = tuple(x.shape)
         # autocast lists the up-sampling kernels as float32 operators (a bf16 map would be cast up, interpolated and handed to the
-        # next convolution's cast down: three passes over the largest maps of the decoder); here it stays in the map's own dtype
+        # next convolution's cast down: three passes over the largest maps of the decoder); here it stays in the map's own dtype.
+        # On pixel-major rows (channels_last maps: what the convolutions of the training step read and write) the forward is the
+        # inference path's row kernel -- ATen's source index and blend order (bilinear_pm_kernel), 2.8-3.8 TB/s where ATen's NHWC
+        # bf16 kernel moves the decoder's largest map at 0.5 TB/s (646 us per call, profiles/r04_rocprofv3_kernel_stats_train_bf16.txt)
+        B, C, IH, IW = x.shape
+        vl = 8 if x.dtype == torch.bfloat16 else 4
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and C % vl == 0 and x.is_contiguous(memory_format=torch.channels_last):
+            from . import ops_pm
+            rows = ops_pm.bilinear_resize(x.permute(0, 2, 3, 1), size, True)       # [B,OH,OW,C]
+            return rows.permute(0, 3, 1, 2)                                         # channels_last [B,C,OH,OW]
         with torch.autocast("cuda", enabled=False):
             return torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=True)
 

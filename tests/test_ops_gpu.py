@@ -188,7 +188,8 @@ def _grad_pair(fn_ours, fn_ref, x, extra=()):
 
 @pytest.mark.parametrize("B,C,IH,IW,fmt", [(2, 8, 5, 7, "cl"), (1, 16, 2, 2, "cl"), (2, 8, 6, 4, "nchw"), (1, 24, 9, 3, "cl")])
 def test_upsample_align_gather_backward_matches_aten(device, B, C, IH, IW, fmt):
-    """pspnet.py:37-42: bilinear x2 with align_corners; forward = torch's, backward = ffb6d_bilinear_bwd_pm (a gather with ATen's
+    """pspnet.py:37-42: bilinear x2 with align_corners; forward = the row kernel of the inference path on channels_last maps (ATen's
+    source index and blend order: 1e-6 against torch), torch's own elsewhere; backward = ffb6d_bilinear_bwd_pm (a gather with ATen's
     source-index arithmetic) against ATen's own scatter backward"""
     F = torch.nn.functional
     g = torch.Generator().manual_seed(IH * IW + C)
@@ -197,7 +198,8 @@ def test_upsample_align_gather_backward_matches_aten(device, B, C, IH, IW, fmt):
         x = x.contiguous(memory_format=torch.channels_last)
     (y, gx, _), (yr, gr, _) = _grad_pair(lambda t: ops.upsample_align(t, (2 * IH, 2 * IW)),
                                           lambda t: F.interpolate(t, size=(2 * IH, 2 * IW), mode="bilinear", align_corners=True), x)
-    assert torch.equal(y, yr)
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last) == yr.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y, yr, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(gx, gr, rtol=1e-5, atol=1e-5)
 
 
