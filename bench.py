@@ -222,7 +222,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
 
-    from ffb6d_amd import _lib, distributed, model, ops, pyramid, synth
+    from ffb6d_amd import _lib, distributed, forward_pm, model, ops, pyramid, synth
     group = distributed.init_from_env(backend=args.dist_backend, device=dev)   # nccl == RCCL on ROCm
     rank, world = group.rank, group.world
     _lib.load()
@@ -298,7 +298,9 @@ def main():
         if train:
             opt.zero_grad(set_to_none=True)
             # --precision bf16: mixed precision as the reference trains (apex amp, train_lm.py:600) -- torch.autocast runs
-            # the convolutions / 1x1 layers in bfloat16 with fp32 master weights; the neighbour operators keep fp32
+            # the convolutions / 1x1 layers in bfloat16 with fp32 master weights; the neighbour operators (ops_cl), the decoder's
+            # LogSoftmax and the up-samplings work on rows in that activation dtype with fp32 arithmetic inside and round their outputs
+            # to it
             with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.precision == "bf16"):
                 out = ddp(inputs)
                 if targets is not None:        # the reference's objective (train_lm.py:245-259) on the synthetic targets
@@ -555,6 +557,11 @@ def main():
                                      if args.objective == "reference" else ", objective: mean of squared outputs (proxy)") if train else ""),
                        "baseline_config": args.config, "global_batch": args.batch * world, "n_points": args.n_points,
                        "index_dtype": args.index_dtype, "layout": "pm",
+                       # the forms a record was taken with (module attributes since round 4: no environment switches)
+                       "forms": {"lfa_fused": forward_pm.LFA_FUSED, "posenc_fused": forward_pm.POSENC_FUSED, "stem_fused": forward_pm.STEM_FUSED,
+                                 "upconv_fold": forward_pm.UPCONV_FOLD if isinstance(forward_pm.UPCONV_FOLD, str) else
+                                 (None if forward_pm.UPCONV_FOLD is None else sorted(forward_pm.UPCONV_FOLD)),
+                                 "psp_train_fold": model.PyramidPooling.fold_in_training},
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "
                                       f"{args.dist_backend if world > 1 else 'no'} process group)"},
             "breakdown_ms": ({"step": fwd_ms, "knn_pyramid_alone": pyr_alone_ms,

@@ -21,6 +21,9 @@ constexpr int BLK = 256;
 template <typename T> struct El;
 template <> struct El<float> {
     static constexpr int SZ = 4;
+    typedef float4 Raw4;                                    // four channels as they are loaded (converted where they are used)
+    static __device__ __forceinline__ Raw4 ld4raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ float4 cvt4(Raw4 r) { return r; }
     static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
     static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -28,12 +31,14 @@ template <> struct El<float> {
 };
 template <> struct El<__bf16> {
     static constexpr int SZ = 2;
-    static __device__ __forceinline__ float4 ld4(const __bf16* p)
+    typedef uint2 Raw4;
+    static __device__ __forceinline__ Raw4 ld4raw(const __bf16* p) { return *reinterpret_cast<const uint2*>(p); }
+    static __device__ __forceinline__ float4 cvt4(Raw4 u)
     {
-        const uint2 u = *reinterpret_cast<const uint2*>(p);
         return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                            __uint_as_float(u.y & 0xffff0000u));
     }
+    static __device__ __forceinline__ float4 ld4(const __bf16* p) { return cvt4(ld4raw(p)); }
     static __device__ __forceinline__ void st4(__bf16* p, float4 v)
     {
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

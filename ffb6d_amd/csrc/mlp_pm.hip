@@ -66,8 +66,11 @@ struct PmParams {
 
 // epilogue shared by the GEMM kernels: bias, gathered / added row of Y, activation or log-softmax, store
 // LSM = false compiles the log-softmax branch out (it needs all channels of a point live at once: 16 * TM more registers)
+// ypre (use_pre): the gathered / added rows of Y fetched ahead by the caller, [j][i][g]; an array REFERENCE with static indices and a flag
+// -- a pointer that may be null would put the array into scratch memory
 template <typename T, int TM, int TN, bool LSM = true>
-__device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM][TN], int c0, int r0, int wm, int wn, int l31, int kh)
+__device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM][TN], int c0, int r0, int wm, int wn, int l31, int kh,
+                                            const typename El<T>::Raw4 (&ypre)[TM * TN * 4], bool use_pre)
 {
     constexpr int SZ = El<T>::SZ;
     // epilogue: lane = one point, 4 groups of 4 consecutive channels per 32 x 32 tile
@@ -93,6 +96,50 @@ __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM]
             yrow = yb + yr * p.ldy;
         }
         T* orow = ob + (size_t)r * p.ldo;
+        if constexpr (SZ == 2) {
+            // bf16: a point's 8 consecutive channels sit in lanes l (channels 8g .. 8g+3) and l + 32 (8g+4 .. 8g+7): four 8-byte
+            // stores per 32 x 32 tile and lane.  The epilogue's time is per store INSTRUCTION (~100 cycles per CU each, whatever the
+            // width: profiles/r04_gemm_epilogue_probe_bf16.txt -- half of the bf16 GEMMs' time), so pairs of channel groups trade
+            // halves across the half-waves (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second) and
+            // every lane stores 16 bytes: the lower lane all 8 channels of group g, the upper lane all 8 of group g + 1.
+            const bool wide = vec && !(LSM && p.act == 3) && (p.cout & 15) == 0 && (p.ldo & 7) == 0 &&
+                              (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+            if (wide) {                               // wave-uniform: every lane takes part in the swaps, dead rows included
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        uint2 pk[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int g = 2 * gp + h;
+                            const int ch = c0 + (wm * TM + i) * 32 + 8 * g + 4 * kh;
+                            float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                            const bool on = ch < p.cout && live;
+                            if (p.bias && on) {
+                                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch);
+                                v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                            }
+                            if (yrow && on) {
+                                const float4 y4 = use_pre ? El<T>::cvt4(ypre[(j * TM + i) * 4 + g]) : El<T>::ld4(yrow + ch);
+                                v.x += y4.x; v.y += y4.y; v.z += y4.z; v.w += y4.w;
+                            }
+                            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                            const bf16x4 b = {(__bf16)activate(v.x, slope), (__bf16)activate(v.y, slope), (__bf16)activate(v.z, slope),
+                                              (__bf16)activate(v.w, slope)};
+                            pk[h] = __builtin_bit_cast(uint2, b);
+                        }
+                        const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                        // lower lane: [own group 2gp | upper's group 2gp]; upper lane: [lower's group 2gp+1 | own group 2gp+1]
+                        const int ch16 = c0 + (wm * TM + i) * 32 + 16 * gp + 8 * kh;
+                        if (ch16 < p.cout && live)
+                            *reinterpret_cast<uint4*>(orow + ch16) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                    }
+                }
+                continue;
+            }
+        }
         if (vec && !(LSM && p.act == 3)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -106,7 +153,7 @@ __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM]
                         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
                     }
                     if (yrow) {
-                        const float4 y4 = El<T>::ld4(yrow + ch);
+                        const float4 y4 = use_pre ? El<T>::cvt4(ypre[(j * TM + i) * 4 + g]) : El<T>::ld4(yrow + ch);
                         v.x += y4.x; v.y += y4.y; v.z += y4.z; v.w += y4.w;
                     }
                     El<T>::st4(orow + ch, make_float4(activate(v.x, slope), activate(v.y, slope), activate(v.z, slope),
@@ -176,6 +223,13 @@ __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM]
             }
         }
     }
+}
+
+template <typename T, int TM, int TN, bool LSM = true>
+__device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM][TN], int c0, int r0, int wm, int wn, int l31, int kh)
+{
+    typename El<T>::Raw4 none[TM * TN * 4];           // never read
+    pm_epilogue<T, TM, TN, LSM>(p, acc, c0, r0, wm, wn, l31, kh, none, false);
 }
 
 // TM x TN MFMA tiles of 32 (channels) x 32 (points) per wave; WM x WN waves per workgroup.
@@ -727,11 +781,12 @@ mlp_pm_lds_kernel(const PmParams p)
     // profiles/r02_mlp_pm_lds_ab.txt).  Two LDS stages, one barrier per step: step s + 1 is parked after step s was read.
 #define FFB6D_PIN() __builtin_amdgcn_sched_barrier(0)
 #define FFB6D_LDS_ITER(FILL, NEXT)                                   \
+    if (s + 1 >= nstage) break;         /* the last step is multiplied below, outside the loop */ \
     gload(s + 3, FILL);                 FFB6D_PIN();                 \
     multiply(s & 1);                    FFB6D_PIN();                 \
-    if (s + 1 < nstage) park(NEXT, (s + 1) & 1);                     \
+    park(NEXT, (s + 1) & 1);                                         \
     __syncthreads();                                                 \
-    if (++s >= nstage) break;
+    ++s;
     Step va, vb, vc;
     gload(0, va);
     gload(1, vb);
@@ -745,8 +800,38 @@ mlp_pm_lds_kernel(const PmParams p)
         FFB6D_LDS_ITER(vc, va)
     }
 #undef FFB6D_LDS_ITER
+    // The last step needs no operand registers any more (its images are in LDS, nothing is left to fetch): the three sets are free, and
+    // the rows of Y the epilogue adds -- gathered rows of the p2r fusion / decoder: an index load, then 16 row loads per lane -- are
+    // requested NOW and arrive under the last 64 MFMAs instead of after them (profiles/r04_gemm_*_probe: the epilogue is exposed in
+    // full, and the gathered rows were about half of it on the fusion GEMMs).  Same sums in the same order: identical results.
+    typename El<T>::Raw4 ypre[16];
+    const bool pre = p.y && (p.cout & 3) == 0 && (p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.y) & (4 * SZ - 1)) == 0 &&
+                     (p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & (4 * SZ - 1)) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+    if (pre) {
+        const T* yb = static_cast<const T*>(p.y);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = r0 + (wn * 2 + j) * 32 + l31;
+            long long yr = min(r, p.rows - 1);        // rows past the end: a valid row, fetched and never used
+            if (p.gidx) {
+                const long long gi = p.idx64 ? static_cast<const long long*>(p.gidx)[yr] : (long long)static_cast<const int*>(p.gidx)[yr];
+                yr = (yr / p.P) * p.py + gi;
+            }
+            const T* yrow = yb + yr * p.ldy;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = min(c0 + (wm * 2 + i) * 32 + 8 * g + 4 * kh, p.cout - 4);
+                    ypre[(j * 2 + i) * 4 + g] = El<T>::ld4raw(yrow + ch);
+                }
+        }
+    }
+    FFB6D_PIN();
+    multiply(s & 1);
+    FFB6D_PIN();
 #undef FFB6D_PIN
-    pm_epilogue<T, 2, 2, false>(p, acc, c0, r0, wm, wn, l31, kh);
+    pm_epilogue<T, 2, 2, false>(p, acc, c0, r0, wm, wn, l31, kh, ypre, pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

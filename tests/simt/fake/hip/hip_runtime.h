@@ -33,6 +33,7 @@ struct int2 { int x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 typedef simt::Dim3 dim3;
 #define threadIdx simt::g_thread
@@ -171,6 +172,18 @@ inline int shfl_up(int v, int d, int w)
 }
 inline float shfl(float v, int src, int w) { return __builtin_bit_cast(float, shfl(__builtin_bit_cast(int, v), src, w)); }
 inline unsigned shfl(unsigned v, int src, int w) { return (unsigned)shfl((int)v, src, w); }
+// v_permlane32_swap_b32 vdst, vsrc: lanes 32-63 of vdst trade places with lanes 0-31 of vsrc; returns {vdst', vsrc'}
+typedef unsigned u32x2_swap_t __attribute__((ext_vector_type(2)));
+inline u32x2_swap_t permlane32_swap(unsigned vdst, unsigned vsrc)
+{
+    const int l = lane();
+    const unsigned dst_up = shfl(vdst, (l + 32) & 63, 64);       // vdst of the lane 32 above (read by the lower half)
+    const unsigned src_lo = shfl(vsrc, (l + 32) & 63, 64);       // vsrc of the lane 32 below (read by the upper half)
+    u32x2_swap_t r;
+    r[0] = l < 32 ? vdst : src_lo;
+    r[1] = l < 32 ? dst_up : vsrc;
+    return r;
+}
 
 inline f32x16_t mfma_32x32x2_f32(float a, float b, f32x16_t c)
 {
@@ -251,6 +264,7 @@ typedef simt::Rsrc __amdgpu_buffer_rsrc_t;
 // scheduling hints and hardware-id reads: no functional effect on the emulator (workgroups run one after the other)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) simt::permlane32_swap(a, b)
 #define __builtin_amdgcn_s_getreg(reg_) ((((reg_) & 63) == 20) ? (unsigned)(blockIdx.x & 7u) : 0u)      /* HW_REG_XCC_ID: workgroup b on XCD b % 8 */
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
