@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <type_traits>
 
 namespace ffb6d {
 namespace {
@@ -55,6 +56,12 @@ constexpr int GRP = 8;      // candidates per unrolled group
 
 constexpr int CELL_BITS = 15;                 // coarse Z-curve cells (top bits of the 30-bit key)
 constexpr int CELL_SHIFT = 30 - CELL_BITS;
+// The sort that brings a set into Morton order sees only the top SORT_BITS of the 30-bit key (8 bits per axis: with at most 76 800 points
+// in 16 M cells nearly every point still has a cell of its own) under the (set, frame) segment number: 32-bit sort keys for up to 256
+// segments -- two thirds of the bytes a 64-bit key + 32-bit value sort moves (the sort was 0.45 ms of the step, profiles/r04_rocprofv3_
+// kernel_stats_steady_state.txt).  The order INSIDE a cell is the input order (stable sort); no search result depends on it.
+constexpr int SORT_BITS = 24;
+constexpr int SORT_DROP = 30 - SORT_BITS;
 constexpr int NCELL = 1 << CELL_BITS;
 
 constexpr int FAN = 16;                       // tiles per level-2 box
@@ -155,27 +162,29 @@ __device__ __forceinline__ uint32_t morton_key(float x, float y, float z, const 
 }
 
 // `seg` = the sort segment of frame b: keys of one segment stay together and in segment order
+template <typename KeyT>
 __device__ __forceinline__ void morton_body(const float* __restrict__ pts, int S, const float* __restrict__ frame,
-                                            unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals, int b, unsigned seg)
+                                            KeyT* __restrict__ keys, uint32_t* __restrict__ vals, int b, unsigned seg)
 {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= S) return;
     const float* p = pts + ((size_t)b * S + i) * 3;
     const uint32_t k = morton_key(p[0], p[1], p[2], frame + b * 8);
-    keys[(size_t)b * S + i] = ((unsigned long long)seg << 32) | k;
+    keys[(size_t)b * S + i] = ((KeyT)seg << SORT_BITS) | (KeyT)(k >> SORT_DROP);
     vals[(size_t)b * S + i] = (uint32_t)i;
 }
 
+template <typename KeyT>
 __global__ void __launch_bounds__(BLK)
-morton_kernel(const float* __restrict__ pts, int S, const float* __restrict__ frame,
-              unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+morton_kernel(const float* __restrict__ pts, int S, const float* __restrict__ frame, KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     morton_body(pts, S, frame, keys, vals, blockIdx.y, blockIdx.y);
 }
 
 // one wave per tile: gather the sorted points, build the tile box
+template <typename KeyT>
 __device__ __forceinline__ void gather_box_body(const float* __restrict__ pts, int S, int S_pad, int nt,
-                                                const unsigned long long* __restrict__ skeys, const uint32_t* __restrict__ perm,
+                                                const KeyT* __restrict__ skeys, const uint32_t* __restrict__ perm,
                                                 float4* __restrict__ out_pts, float4* __restrict__ boxes,
                                                 uint32_t* __restrict__ out_keys, int b)
 {
@@ -190,7 +199,7 @@ __device__ __forceinline__ void gather_box_body(const float* __restrict__ pts, i
         const uint32_t src = perm[(size_t)b * S + slot];
         const float* s = pts + ((size_t)b * S + src) * 3;
         p = make_float4(s[0], s[1], s[2], __uint_as_float(src));
-        key = (uint32_t)skeys[(size_t)b * S + slot];
+        key = ((uint32_t)skeys[(size_t)b * S + slot] & ((1u << SORT_BITS) - 1u)) << SORT_DROP;       // the sorted bits of the 30-bit key
         lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z;
     }
 #pragma unroll
@@ -209,9 +218,10 @@ __device__ __forceinline__ void gather_box_body(const float* __restrict__ pts, i
     }
 }
 
+template <typename KeyT>
 __global__ void __launch_bounds__(BLK)
 gather_box_kernel(const float* __restrict__ pts, int S, int S_pad, int nt,
-                  const unsigned long long* __restrict__ skeys, const uint32_t* __restrict__ perm,
+                  const KeyT* __restrict__ skeys, const uint32_t* __restrict__ perm,
                   float4* __restrict__ out_pts, float4* __restrict__ boxes, uint32_t* __restrict__ out_keys)
 {
     gather_box_body(pts, S, S_pad, nt, skeys, perm, out_pts, boxes, out_keys, blockIdx.y);
@@ -285,15 +295,17 @@ frame_multi_kernel(const MultiDesc m)
     frame_body(d.pts, d.S, d.frame, blockIdx.x);
 }
 
+template <typename KeyT>
 __global__ void __launch_bounds__(BLK)
-morton_multi_kernel(const MultiDesc m, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+morton_multi_kernel(const MultiDesc m, KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const SetDesc& d = m.s[blockIdx.z];
     morton_body(d.pts, d.S, d.frame, keys + d.pos0, vals + d.pos0, blockIdx.y, blockIdx.z * m.B + blockIdx.y);
 }
 
+template <typename KeyT>
 __global__ void __launch_bounds__(BLK)
-gather_box_multi_kernel(const MultiDesc m, const unsigned long long* __restrict__ skeys, const uint32_t* __restrict__ perm)
+gather_box_multi_kernel(const MultiDesc m, const KeyT* __restrict__ skeys, const uint32_t* __restrict__ perm)
 {
     const SetDesc& d = m.s[blockIdx.z];
     gather_box_body(d.pts, d.S, d.S_pad, d.nt, skeys + d.pos0, perm + d.pos0, d.out_pts, d.boxes, d.out_keys, blockIdx.y);
@@ -652,7 +664,7 @@ knn_row16_body(const float4* __restrict__ spts, const float4* __restrict__ boxes
     // 17-ary lower_bound over the sorted keys, 16 probes per step (one per lane of the row)
     int my_tile = 0;
     {
-        const uint32_t kq = morton_key(q.x, q.y, q.z, sframe + b * 8);
+        const uint32_t kq = morton_key(q.x, q.y, q.z, sframe + b * 8) & ~((1u << SORT_DROP) - 1u);      // the stored keys carry the sorted bits only
         const uint32_t* sk = skeys + (size_t)b * S_pad;
         int lo = 0, hi = live ? S : 0;
         while (__any(hi > lo)) {
@@ -808,6 +820,22 @@ struct PrepWs {
 PrepWs prep_ws_n(size_t n);
 PrepWs prep_ws(int64_t B, int64_t S) { return prep_ws_n((size_t)B * S); }
 
+// one stable sort of all (segment, truncated Morton key) pairs: `segments` = number of (set, frame) segments in the key's high bits
+constexpr int64_t MAX_SEG32 = 1LL << (32 - SORT_BITS);
+template <typename KeyT>
+int sort_segments(KeyT* keys_in, KeyT* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int64_t segments, void* temp,
+                  size_t temp_bytes, hipStream_t st, const char* who)
+{
+    unsigned end_bit = SORT_BITS;
+    while ((1LL << (end_bit - SORT_BITS)) < segments) ++end_bit;
+    size_t need = 0;
+    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
+    if (need > temp_bytes) return set_error(FFB6D_ERR_WORKSPACE, "%s: radix sort wants %zu temp bytes, reserved %zu", who, need, temp_bytes);
+    size_t have = temp_bytes;
+    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(temp, have, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
+    return FFB6D_OK;
+}
+
 PrepWs prep_ws_n(size_t n)
 {
     PrepWs w;
@@ -864,25 +892,20 @@ int ffb6d_knn_prepare(const float* pts, int64_t B, int64_t S, void* prepared, si
     float* frame = reinterpret_cast<float*>(pp + L.frame_off);
 
     hipLaunchKernelGGL(frame_kernel, dim3((unsigned)B), dim3(1024), 0, st, pts, (int)S, frame);
-    hipLaunchKernelGGL(morton_kernel, dim3((unsigned)ceil_div(S, BLK), (unsigned)B), dim3(BLK), 0, st, pts, (int)S,
-                       frame, keys_in, vals_in);
-    FFB6D_LAUNCH_CHECK();
-
     const size_t n = (size_t)B * S;
-    unsigned end_bit = 32;
-    while ((1LL << (end_bit - 32)) < B) ++end_bit;
-    size_t need = 0;
-    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
-    if (need > W.temp_bytes)
-        return set_error(FFB6D_ERR_WORKSPACE, "knn_prepare: radix sort wants %zu temp bytes, reserved %zu", need,
-                         W.temp_bytes);
-    size_t have = W.temp_bytes;
-    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(ws + W.temp, have, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
-
-    hipLaunchKernelGGL(gather_box_kernel, dim3((unsigned)ceil_div(L.nt, BLK / 64), (unsigned)B), dim3(BLK), 0, st, pts,
-                       (int)S, (int)L.S_pad, (int)L.nt, keys_out, vals_out,
-                       reinterpret_cast<float4*>(pp + L.pts_off), reinterpret_cast<float4*>(pp + L.box_off),
-                       reinterpret_cast<uint32_t*>(pp + L.key_off));
+    auto run = [&](auto* kin, auto* kout) -> int {
+        using KeyT = std::remove_pointer_t<decltype(kin)>;
+        hipLaunchKernelGGL((morton_kernel<KeyT>), dim3((unsigned)ceil_div(S, BLK), (unsigned)B), dim3(BLK), 0, st, pts, (int)S, frame, kin,
+                           vals_in);
+        FFB6D_LAUNCH_CHECK();
+        if (const int rc = sort_segments<KeyT>(kin, kout, vals_in, vals_out, n, B, ws + W.temp, W.temp_bytes, st, "knn_prepare")) return rc;
+        hipLaunchKernelGGL((gather_box_kernel<KeyT>), dim3((unsigned)ceil_div(L.nt, BLK / 64), (unsigned)B), dim3(BLK), 0, st, pts,
+                           (int)S, (int)L.S_pad, (int)L.nt, kout, vals_out, reinterpret_cast<float4*>(pp + L.pts_off),
+                           reinterpret_cast<float4*>(pp + L.box_off), reinterpret_cast<uint32_t*>(pp + L.key_off));
+        return FFB6D_OK;
+    };
+    const int rc = B <= MAX_SEG32 ? run(reinterpret_cast<uint32_t*>(keys_in), reinterpret_cast<uint32_t*>(keys_out)) : run(keys_in, keys_out);
+    if (rc) return rc;
     hipLaunchKernelGGL(box2_kernel, dim3((unsigned)ceil_div(L.nt2, BLK), (unsigned)B), dim3(BLK), 0, st,
                        reinterpret_cast<const float4*>(pp + L.box_off), (int)L.nt, (int)L.nt2,
                        reinterpret_cast<float4*>(pp + L.box2_off));
@@ -941,17 +964,19 @@ int ffb6d_knn_prepare_multi(int nsets, const float* const* pts, const int64_t* n
     auto* vals_out = reinterpret_cast<uint32_t*>(ws + W.vals_out);
     const unsigned ns = (unsigned)nsets, nb = (unsigned)B;
     hipLaunchKernelGGL(frame_multi_kernel, dim3(nb, ns), dim3(1024), 0, st, m);
-    hipLaunchKernelGGL(morton_multi_kernel, dim3((unsigned)ceil_div(S_max, BLK), nb, ns), dim3(BLK), 0, st, m, keys_in, vals_in);
-    FFB6D_LAUNCH_CHECK();
-    unsigned end_bit = 32;
-    while ((1LL << (end_bit - 32)) < B * nsets) ++end_bit;
-    size_t need = 0;
-    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
-    if (need > W.temp_bytes)
-        return set_error(FFB6D_ERR_WORKSPACE, "knn_prepare_multi: radix sort wants %zu temp bytes, reserved %zu", need, W.temp_bytes);
-    size_t have = W.temp_bytes;
-    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(ws + W.temp, have, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, st));
-    hipLaunchKernelGGL(gather_box_multi_kernel, dim3((unsigned)ceil_div(nt_max, BLK / 64), nb, ns), dim3(BLK), 0, st, m, keys_out, vals_out);
+    auto run = [&](auto* kin, auto* kout) -> int {
+        using KeyT = std::remove_pointer_t<decltype(kin)>;
+        hipLaunchKernelGGL((morton_multi_kernel<KeyT>), dim3((unsigned)ceil_div(S_max, BLK), nb, ns), dim3(BLK), 0, st, m, kin, vals_in);
+        FFB6D_LAUNCH_CHECK();
+        if (const int rc = sort_segments<KeyT>(kin, kout, vals_in, vals_out, n, B * nsets, ws + W.temp, W.temp_bytes, st, "knn_prepare_multi"))
+            return rc;
+        hipLaunchKernelGGL((gather_box_multi_kernel<KeyT>), dim3((unsigned)ceil_div(nt_max, BLK / 64), nb, ns), dim3(BLK), 0, st, m, kout,
+                           vals_out);
+        return FFB6D_OK;
+    };
+    const int rc = B * nsets <= MAX_SEG32 ? run(reinterpret_cast<uint32_t*>(keys_in), reinterpret_cast<uint32_t*>(keys_out))
+                                          : run(keys_in, keys_out);
+    if (rc) return rc;
     hipLaunchKernelGGL(box2_multi_kernel, dim3((unsigned)ceil_div(nt2_max, BLK), nb, ns), dim3(BLK), 0, st, m);
     hipLaunchKernelGGL(cell_table_multi_kernel, dim3(NCELL / BLK, nb, ns), dim3(BLK), 0, st, m);
     FFB6D_LAUNCH_CHECK();
