@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
+    ap.add_argument("--form", action="append", default=[], metavar="NAME=0|1",
+                    help="A/B runs: set a boolean form attribute of ffb6d_amd.forward_pm (HEADS_SHARE_FIRST=0 ...) before the model is "
+                         "built; the line's config.forms records what ran")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 16 if args.config == 5 else 8
@@ -223,6 +226,11 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
 
     from ffb6d_amd import _lib, distributed, forward_pm, model, ops, pyramid, synth
+    for item in args.form:
+        name, _, val = item.partition("=")
+        if not isinstance(getattr(forward_pm, name, None), bool) or val not in ("0", "1"):
+            raise SystemExit(f"--form {item}: not a boolean form attribute of ffb6d_amd.forward_pm")
+        setattr(forward_pm, name, val == "1")
     group = distributed.init_from_env(backend=args.dist_backend, device=dev)   # nccl == RCCL on ROCm
     rank, world = group.rank, group.world
     _lib.load()
@@ -559,6 +567,8 @@ def main():
                        "index_dtype": args.index_dtype, "layout": "pm",
                        # the forms a record was taken with (module attributes since round 4: no environment switches)
                        "forms": {"lfa_fused": forward_pm.LFA_FUSED, "posenc_fused": forward_pm.POSENC_FUSED, "stem_fused": forward_pm.STEM_FUSED,
+                                 "heads_share_first": forward_pm.HEADS_SHARE_FIRST, "heads_align_last": forward_pm.HEADS_ALIGN_LAST,
+                                 "heads_on_both_streams": forward_pm.HEADS_ON_BOTH_STREAMS,
                                  "upconv_fold": forward_pm.UPCONV_FOLD if isinstance(forward_pm.UPCONV_FOLD, str) else
                                  (None if forward_pm.UPCONV_FOLD is None else sorted(forward_pm.UPCONV_FOLD)),
                                  "psp_train_fold": model.PyramidPooling.fold_in_training},

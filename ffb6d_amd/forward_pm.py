@@ -79,6 +79,24 @@ def folded(m, pad_k=None, dt=F32):
     return cached(m, "folded%s%s" % (pad_k or "", dt), mlp_sources(m), build)
 
 
+def stacked(owner, ms, dt=F32):
+    """folded() of several SharedMLPs over the same input, stacked along the output channels: (W [sum Cout, Cin], b [sum Cout])"""
+    def build():
+        parts = [folded(m, dt=dt) for m in ms]
+        return torch.cat([w for w, _ in parts]).contiguous(), torch.cat([b for _, b in parts]).contiguous()
+    return cached(owner, "stacked%s%s" % ("_".join(str(id(m)) for m in ms), dt), [t for m in ms for t in mlp_sources(m)], build)
+
+
+def out_padded(m, cout_to, dt=F32):
+    """folded(m) with zero rows appended to the weight (and zeros to the bias) up to cout_to output channels"""
+    def build():
+        w, b = folded(m, dt=dt)
+        wp, bp = w.new_zeros(cout_to, w.shape[1]), b.new_zeros(cout_to)
+        wp[:w.shape[0]], bp[:b.shape[0]] = w, b
+        return wp, bp
+    return cached(m, "outpad%d%s" % (cout_to, dt), mlp_sources(m), build)
+
+
 def split(m, k1, dt=F32):
     """(W_a [Cout,k1], W_b [Cout,Cin-k1], b) for conv(cat(a, gather(b))) == W_a a + gather(W_b b)."""
     def build():
@@ -109,6 +127,12 @@ STEM_FUSED = True
 # One launch per half of the local feature aggregation (csrc/lfa_pm.hip): the per-pair tensors live in LDS only.
 # False: the round-2 chain posenc_mlp -> att_pool -> mlp (six launches, [B,N,16,d/2] through HBM).
 LFA_FUSED = True
+# The first layers of the three prediction heads (ffb6d.py:316-318: same input rows, same shape) as one GEMM over stacked weights.
+HEADS_SHARE_FIRST = True
+# ... and their last layers (22 / 24 / 3 channels) with the output rows padded to whole 16 bytes: the stream form instead of a 128-wide tile
+HEADS_ALIGN_LAST = True
+# ... and the keypoint head on the side stream while the other two run on main (only with two_streams)
+HEADS_ON_BOTH_STREAMS = True
 LFA_WIDTHS = (32, 64, 128, 256)
 
 
@@ -494,14 +518,40 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
     img = rgb_emb.view(B, H * W_, c)
     choose = inputs['choose'].reshape(B, -1)
 
-    def head(seq):
-        y = mlp(seq[0], img, x2=p_emb, x1_gather=choose)
-        for layer in list(seq)[1:]:
+    seqs = [net.rgbd_seg_layer, net.kp_ofst_layer, net.ctr_ofst_layer]
+    firsts = [seq[0] for seq in seqs]
+    if HEADS_SHARE_FIRST and len({(m.conv.weight.shape, m.act_code) for m in firsts}) == 1:
+        # the three first layers read the same rows (ffb6d.py:316-318): one GEMM over the stacked weights -- each output channel's
+        # dot product is the one the separate launch computes -- and the heads continue on channel slices of its output
+        w, b = stacked(net, firsts, img.dtype)
+        y0 = ops_pm.mlp(img, w, b, firsts[0].act_code, x2=p_emb, x1_gather=choose)
+        step = firsts[0].conv.weight.shape[0]
+        starts = [y0[..., h * step:(h + 1) * step] for h in range(3)]
+    else:
+        starts = [mlp(m, img, x2=p_emb, x1_gather=choose) for m in firsts]
+
+    def head(seq, y):
+        layers = list(seq)[1:]
+        for layer in layers[:-1]:
             y = mlp(layer, y)
-        return y
+        last, cout = layers[-1], layers[-1].conv.weight.shape[0]
+        mult = 16 // y.element_size()
+        if HEADS_ALIGN_LAST and cout % mult:
+            # 22 / 3 output channels: zero weight rows up to whole 16-byte output rows, which the stream form needs
+            # (ffb6d_mlp_pm_choice); the extra channels are never read
+            w, b = out_padded(last, -(-cout // mult) * mult, y.dtype)
+            return ops_pm.mlp(y, w, b, last.act_code)[..., :cout]
+        return mlp(last, y)
 
     n = p_emb.shape[1]
-    end_points['pred_rgbd_segs'] = head(net.rgbd_seg_layer).float().transpose(1, 2).contiguous()           # [B,n_cls,N]
-    end_points['pred_kp_ofs'] = head(net.kp_ofst_layer).float().view(B, n, net.n_kps, 3).permute(0, 2, 1, 3).contiguous()
-    end_points['pred_ctr_ofs'] = head(net.ctr_ofst_layer).float().view(B, n, 1, 3).permute(0, 2, 1, 3).contiguous()
+    # the three chains are independent and each leaves CUs idle (768 workgroups of short-K GEMMs): the keypoint head runs on the
+    # side stream, idle since the last decoder, under the other two
+    kp_on = side if HEADS_ON_BOTH_STREAMS else main
+    handover(starts[1], main, kp_on, "side waits for the heads' first layer")
+    with torch.cuda.stream(kp_on):
+        kp = head(seqs[1], starts[1]).float().reshape(B, n, net.n_kps, 3).permute(0, 2, 1, 3).contiguous()
+    end_points['pred_rgbd_segs'] = head(seqs[0], starts[0]).float().transpose(1, 2).contiguous()           # [B,n_cls,N]
+    ctr = head(seqs[2], starts[2]).float().reshape(B, n, 1, 3).permute(0, 2, 1, 3).contiguous()
+    end_points['pred_kp_ofs'] = handover(kp, kp_on, main, "main waits for the keypoint head")
+    end_points['pred_ctr_ofs'] = ctr
     return end_points

@@ -118,6 +118,39 @@ def test_mlp_pm_operand_gather_and_log_softmax(device):
             torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_stacked_head_gemm_equals_the_separate_launches(device, dt):
+    """forward_pm.HEADS_SHARE_FIRST: the first layers of the three heads (ffb6d.py:316-318, same gathered rows) as one GEMM over
+    stacked weights, the heads continuing on channel slices of its output -- every output channel is the dot product the separate
+    launch computes, in the same k order: equal bits, first layer and the layer after it (which reads a slice with a 3x row stride)"""
+    g = torch.Generator().manual_seed(11)
+    B, M, C = 2, 900, 128
+    P = 517 if torch.device(device).type == "cpu" else 20011        # on the GPU: enough rows for the LDS-tiled / stream forms
+    img = torch.randn(B, M, 64, generator=g).to(dt).to(device)
+    pts = torch.randn(B, P, 64, generator=g).to(dt).to(device)
+    choose = torch.randint(0, M, (B, P), generator=g).to(device)
+    ws = [(torch.randn(C, 128, generator=g) / 11).to(dt).to(device) for _ in range(3)]
+    bs = [torch.randn(C, generator=g).to(device) for _ in range(3)]
+    w2 = (torch.randn(C, C, generator=g) / 11).to(dt).to(device)
+    y0 = ops_pm.mlp(img, torch.cat(ws).contiguous(), torch.cat(bs).contiguous(), ops.ACT_RELU, x2=pts, x1_gather=choose)
+    assert y0.shape == (B, P, 3 * C)
+    for h in range(3):
+        sep = ops_pm.mlp(img, ws[h], bs[h], ops.ACT_RELU, x2=pts, x1_gather=choose)
+        part = y0[..., h * C:(h + 1) * C]
+        assert torch.equal(part, sep), h
+        assert torch.equal(ops_pm.mlp(part, w2, bs[0], ops.ACT_RELU), ops_pm.mlp(sep, w2, bs[0], ops.ACT_RELU)), h
+    # forward_pm.HEADS_ALIGN_LAST: 22 / 3 output channels as whole 16-byte rows (zero weight rows appended), the padding sliced away
+    mult = 16 // img.element_size()
+    for cout in (22, 3):
+        cp = -(-cout // mult) * mult
+        wl, bl = w2[:cout].contiguous(), bs[1][:cout].contiguous()
+        wp, bp = wl.new_zeros(cp, C), bl.new_zeros(cp)
+        wp[:cout], bp[:cout] = wl, bl
+        got = ops_pm.mlp(y0[..., :C], wp, bp, ops.ACT_NONE)
+        assert got.shape[-1] == cp and torch.equal(got[..., :cout], ops_pm.mlp(y0[..., :C], wl, bl, ops.ACT_NONE)), cout
+        assert not got[..., cout:].any()
+
+
 @pytest.mark.parametrize("B,M,C,Np,K,dt", [(2, 3072, 64, 768, 16, torch.int64), (1, 19200, 64, 3072, 16, torch.int32),
                                            (3, 192, 512, 48, 16, torch.int64), (2, 100, 8, 37, 5, torch.int64),
                                            (1, 4800, 1024, 48, 16, torch.int32)])

@@ -86,6 +86,13 @@ def test_operand_gather_on_the_emulator(emu, hint, idt):
     assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_stacked_head_gemm_on_the_emulator(emu, dt):
+    """forward_pm.HEADS_SHARE_FIRST: tests/test_pm_gpu.py's own check with CPU tensors"""
+    import test_pm_gpu as TPM
+    TPM.test_stacked_head_gemm_equals_the_separate_launches(torch.device("cpu"), dt)
+
+
 def test_kernel_forms_are_bit_identical_on_the_emulator(emu):
     """DESIGN 4a' / 4a'': stream form and LDS-tiled form feed every accumulator the same products in the same k order as the
     tile kernels -- equal bits (the emulated MFMA is deterministic, so any difference would be one of operand order)"""
