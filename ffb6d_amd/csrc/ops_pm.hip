@@ -275,6 +275,51 @@ bilinear_pm_kernel(const void* __restrict__ in, void* __restrict__ out, int IH, 
     v.store(out, (size_t)row * OW * q + t);
 }
 
+// The 3 x 3 patches of the bilinear (align_corners) up-sampling of `in` around picked pixels -- the operand rows of PSPUpsample's
+// convolution (pspnet.py:34-45) evaluated only where its output is read: the last colour stage feeds the heads through the `choose`
+// pick alone (ffb6d.py:302-312).  out[r, tap, :] = up(in)[b, Y + ky - 1, X + kx - 1, :] for idx[r] = Y * OW + X, tap = ky * 3 + kx,
+// zeros where the patch leaves the OH x OW map (the convolution's zero padding).  Element arithmetic as bilinear_pm_kernel: a patch
+// element IS the up-sampled map's element.  One thread per (row, tap, 16-byte unit); neighbouring taps share source pixels in L1.
+template <typename T, typename I>
+__global__ void __launch_bounds__(BLK)
+upsampled_patch_rows_pm_kernel(const void* __restrict__ in, const I* __restrict__ idx, void* __restrict__ out, int IH, int IW, int OH,
+                               int OW, int q, int P, size_t total, float rh, float rw)
+{
+    using U = Unit<T>;
+    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % (size_t)q);
+    const size_t rt = t / (size_t)q;
+    const int tap = (int)(rt % 9);
+    const size_t r = rt / 9;
+    const int b = (int)(r / (size_t)P);
+    long pix = (long)idx[r];
+    pix = pix < 0 ? 0 : (pix >= (long)OH * OW ? (long)OH * OW - 1 : pix);        // memory safety only: torch.gather would raise
+    const int oy = (int)(pix / OW), ox = (int)(pix - (long)oy * OW);
+    const int yy = oy + tap / 3 - 1, xx = ox + tap % 3 - 1;
+    U v;
+    if (yy < 0 || yy >= OH || xx < 0 || xx >= OW) {
+#pragma unroll
+        for (int e = 0; e < U::VL; ++e) v.v[e] = 0.f;
+    } else {
+        const float h1r = src_index(rh, yy, 1);
+        const int h1 = (int)h1r;
+        const int h1p = (h1 < IH - 1) ? 1 : 0;
+        const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+        const size_t r0 = ((size_t)b * IH + h1) * IW * q;
+        const size_t r1 = r0 + (size_t)h1p * IW * q;
+        const float w1r = src_index(rw, xx, 1);
+        const int w1 = (int)w1r;
+        const int w1p = (w1 < IW - 1) ? 1 : 0;
+        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        const int i0 = w1 * q + c, i1 = i0 + w1p * q;
+        const U a = U::load(in, r0 + i0), bq = U::load(in, r0 + i1), cc = U::load(in, r1 + i0), d = U::load(in, r1 + i1);
+#pragma unroll
+        for (int e = 0; e < U::VL; ++e) v.v[e] = h0l * (w0l * a.v[e] + w1l * bq.v[e]) + h1l * (w0l * cc.v[e] + w1l * d.v[e]);
+    }
+    v.store(out, t);
+}
+
 // ------------------------------------------------------------------------------------------------
 // pyramid pooling helpers (pspnet.py:7-31 rewritten as  W_x x + b + sum_i up_i((W_b,i W_i) pool_i(x)), forward_pm.py)
 //   psp_pool       all adaptive average pools of [B,H,W,C] -> fp32 [B, bins, C] (two passes through fp32 partial sums)
@@ -541,6 +586,36 @@ int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, in
     DISPATCH_DT(dtype, T, {
         hipLaunchKernelGGL((bilinear_pm_kernel<T>), dim3((unsigned)ceil_div(OW * (int64_t)q, BLK), (unsigned)(B * OH)), dim3(BLK), 0,
                            as_stream(stream), in, out, (int)IH, (int)IW, (int)OH, (int)OW, q, qshift, rh, rw, align_corners);
+    })
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}
+
+int ffb6d_upsampled_patch_rows_pm(int dtype, const void* in, const void* idx, int idx_bits, void* out, int64_t B, int64_t IH, int64_t IW,
+                                  int64_t OH, int64_t OW, int64_t C, int64_t P, ffb6d_stream_t stream)
+{
+    FFB6D_REQUIRE(dt_ok(dtype), "upsampled_patch_rows_pm: dtype must be 0 (f32) or 1 (bf16)");
+    FFB6D_REQUIRE(idx_bits == 32 || idx_bits == 64, "upsampled_patch_rows_pm: idx_bits must be 32 or 64");
+    const int VL = vl_of(dtype);
+    FFB6D_REQUIRE(B >= 0 && P >= 0 && IH >= 1 && IW >= 1 && OH >= 1 && OW >= 1 && C >= VL && C % VL == 0,
+                  "upsampled_patch_rows_pm: bad shape");
+    FFB6D_REQUIRE(IH < (1 << 24) && IW < (1 << 24) && OH < (1 << 24) && OW < (1 << 24) && P < (1LL << 31),
+                  "upsampled_patch_rows_pm: too large");
+    if (B == 0 || P == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(in && idx && out && al16(in) && al16(out), "upsampled_patch_rows_pm: null or unaligned pointer");
+    const float rh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;       // ATen area_pixel_compute_scale, align_corners
+    const float rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+    const int q = (int)(C / VL);
+    const size_t total = (size_t)B * P * 9 * q;
+    FFB6D_REQUIRE(ceil_div((int64_t)total, BLK) < (1LL << 31), "upsampled_patch_rows_pm: too many workgroups");
+    const dim3 grid((unsigned)ceil_div((int64_t)total, BLK));
+    DISPATCH_DT(dtype, T, {
+        if (idx_bits == 64)
+            hipLaunchKernelGGL((upsampled_patch_rows_pm_kernel<T, int64_t>), grid, dim3(BLK), 0, as_stream(stream), in,
+                               static_cast<const int64_t*>(idx), out, (int)IH, (int)IW, (int)OH, (int)OW, q, (int)P, total, rh, rw);
+        else
+            hipLaunchKernelGGL((upsampled_patch_rows_pm_kernel<T, int32_t>), grid, dim3(BLK), 0, as_stream(stream), in,
+                               static_cast<const int32_t*>(idx), out, (int)IH, (int)IW, (int)OH, (int)OW, q, (int)P, total, rh, rw);
     })
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;

@@ -50,7 +50,7 @@ struct CombineArgs {
     int q;                // 16-byte units per C channels
     float rh, rw;         // ATen's align_corners scales (IH-1)/(OH-1), (IW-1)/(OW-1)
     float slope;          // PReLU slope (one parameter)
-    int banded;           // 1: XCD-band workgroup order (default), 0: row-major (FFB6D_UPCONV_XCD=0, A/B)
+    int banded;           // 1: XCD-band workgroup order (default), 0: row-major (the A/B form of round 3)
     unsigned nbx, nby;    // logical launch: workgroups along the row of threads, output rows (or row pairs) of all frames
 };
 

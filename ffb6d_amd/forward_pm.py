@@ -300,6 +300,39 @@ def final_head(fh, x):
     return ops_pm.mlp(x, w, cv.bias.detach().float(), ops_pm.ACT_LOG_SOFTMAX, role="cnn")
 
 
+# The last colour stage (PSPUpsample 64 -> 64 to full resolution, then `final`) is read by the heads only through the `choose` pick
+# (ffb6d.py:302-312): evaluate it at the picked pixels -- 3x3 patches of the up-sampled map as operand rows of a K = 9*cin GEMM, then
+# BatchNorm + PReLU and `final` on [B,n,64] rows -- instead of on all 480 x 640 pixels of which 4 % are read.  Same arithmetic per
+# picked pixel (the patch elements ARE the up-sampled map's; the convolution's sum runs over the same 9*cin products), no full map.
+LAST_STAGE_AT_CHOSEN = True
+
+
+def last_stage_at_chosen(stage, x, choose):
+    """cnn_up_stages[-1] = Sequential(UpBlock, FinalHead) on x [B,h,w,cin] -> the rows [B,n,C] the heads' `choose` pick would read
+    from its [B,2h,2w,C] output; None when the stage is not of that form (the caller runs it densely)."""
+    from . import model
+    mods = [m for m in stage if not isinstance(m, torch.nn.Dropout2d)] if isinstance(stage, torch.nn.Sequential) else []
+    if len(mods) != 2 or not isinstance(mods[0], model.UpBlock) or not isinstance(mods[1], model.FinalHead):
+        return None
+    ub, fh = mods
+    cv, bn, prelu = ub.conv[1], ub.conv[2], ub.conv[3]
+    if not (cv.kernel_size == (3, 3) and cv.padding == (1, 1) and cv.stride == (1, 1) and cv.dilation == (1, 1) and cv.groups == 1) \
+            or prelu.weight.numel() != 1:
+        return None
+    B, h, w_, cin = x.shape
+    wk = cached(ub, "taps%s" % x.dtype, [cv.weight],
+                lambda: cv.weight.detach().permute(0, 2, 3, 1).reshape(cv.out_channels, 9 * cin).to(x.dtype).contiguous())
+    patches = ops_pm.upsampled_patch_rows(x, choose, (2 * h, 2 * w_))                        # [B,n,9*cin]
+    y = ops_pm.mlp(patches, wk, role="cnn")
+    slope = cached(ub, "slope", [prelu.weight], lambda: float(prelu.weight.detach().item()))
+    scale, shift = ops.bn_fold(bn)
+    if cv.bias is not None:
+        shift = cached(ub, "shift", [cv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var],
+                       lambda: (shift + scale * cv.bias.detach()).contiguous())
+    y = ops_pm.affine_act_(y, scale, shift, act=ops.ACT_LEAKY, slope=slope)
+    return final_head(fh, y)
+
+
 def cnn_stage(stage, x):
     """Run one entry of cnn_ds_stages / cnn_up_stages on a [B,H,W,C] map."""
     from . import model
@@ -508,15 +541,19 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
         if taps is not None:
             torch.cuda.synchronize(dev)
             taps['rgb_emb_up%d' % i], taps['p_emb_up%d' % i] = rgb_emb.permute(0, 3, 1, 2).float(), p_emb.transpose(1, 2).unsqueeze(3).float()
-    rgb_emb = cnn_stage(net.cnn_up_stages[n_up - 1], rgb_emb)
+    B = rgb_emb.shape[0]
+    choose = inputs['choose'].reshape(B, -1)
+    img = last_stage_at_chosen(net.cnn_up_stages[n_up - 1], rgb_emb, choose) if LAST_STAGE_AT_CHOSEN else None
+    if img is not None:
+        choose = None                                                               # img [B,n,c]: already the picked rows
+    else:
+        rgb_emb = cnn_stage(net.cnn_up_stages[n_up - 1], rgb_emb)
+        img = rgb_emb.view(B, -1, rgb_emb.shape[-1])
     with on_side():
         p_emb = decode(net.rndla_up_stages[n_up - 1], ds_emb[0], p_emb, inputs['cld_interp_idx0'])
     handover(p_emb, side, main, "main waits for the last decoder")                 # also the final join: main is behind all side work
 
     # ---- heads: conv(cat(rgb[choose], p_emb)) with the pick as the operand gather of the first GEMM ----
-    B, H, W_, c = rgb_emb.shape
-    img = rgb_emb.view(B, H * W_, c)
-    choose = inputs['choose'].reshape(B, -1)
 
     seqs = [net.rgbd_seg_layer, net.kp_ofst_layer, net.ctr_ofst_layer]
     firsts = [seq[0] for seq in seqs]

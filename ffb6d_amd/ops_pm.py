@@ -335,6 +335,29 @@ def bilinear_resize(x, size, align_corners):
     return out
 
 
+def upsampled_patch_rows(x, idx, size):
+    """x [B,IH,IW,C], idx [B,P] (flat pixel Y*OW + X of the up-sampled map) -> [B,P,9*C]: the 3x3 patches (tap-major) of the
+    align_corners bilinear up-sampling of x to `size` around the picked pixels, zeros outside the map -- PSPUpsample's convolution
+    (pspnet.py:34-45) as a K = 9*C GEMM over the picked pixels only (the `choose` pick, ffb6d.py:309-312, moved in front of it)."""
+    _need_gpu(x, idx)
+    lib = _lib.load()
+    xc = x.detach()
+    xc = xc if xc.is_contiguous() else xc.contiguous()
+    B, IH, IW, C = xc.shape
+    if idx.dim() != 2 or idx.shape[0] != B:
+        raise ValueError("idx must be [B,P]")
+    P = idx.shape[1]
+    ii, bits = _idx(idx.reshape(-1))
+    OH, OW = int(size[0]), int(size[1])
+    out = torch.empty((B, P, 9 * C), dtype=x.dtype, device=x.device)
+    nbytes = x.element_size() * B * C * (IH * IW + 9 * P) + B * P * (bits // 8)
+    with torch.cuda.device(x.device), _lib.traced("upsampled_patch_rows_pm", nbytes, (C, OH, OW, P)):
+        rc = lib.ffb6d_upsampled_patch_rows_pm(_dt(xc), xc.data_ptr(), ii.data_ptr(), bits, out.data_ptr(), B, IH, IW, OH, OW, C, P,
+                                               _stream(xc))
+    _lib.check(rc, "ffb6d_upsampled_patch_rows_pm")
+    return out
+
+
 def upconv_combine(z, shift, slope, size):
     """Second half of the folded PSPUpsample (pspnet.py:34-45; csrc/upconv.hip): z [B,IH,IW,9*C] = per-tap channel mixing
     at the low resolution (tap-major blocks of C channels), shift [C] float32, one PReLU slope -> [B,OH,OW,C]:

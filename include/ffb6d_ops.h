@@ -184,6 +184,12 @@ int ffb6d_affine_relu_maxpool_pm(int dtype, const void* x, const float* scale, c
 /* Bilinear resize [B,IH,IW,C] -> [B,OH,OW,C] (ATen upsample_bilinear2d arithmetic; pspnet.py:24-28,37-42). */
 int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
                              int64_t C, int align_corners, ffb6d_stream_t stream);
+/* PSPUpsample's convolution where its output is read (pspnet.py:34-45; the last colour stage feeds the heads only through the `choose`
+ * pick, ffb6d.py:302-312): out [B*P, 9, C] = the 3x3 patches of the align_corners bilinear up-sampling of in [B,IH,IW,C] to OH x OW
+ * around the picked pixels idx [B*P] (flat Y*OW + X within the frame; int32 / int64), tap-major, zeros outside the map -- the operand
+ * rows of a K = 9*C ffb6d_mlp_pm GEMM with the weight [Cout, (ky*3+kx)*C + ci].  Arithmetic as ffb6d_bilinear_resize_pm. */
+int ffb6d_upsampled_patch_rows_pm(int dtype, const void* in, const void* idx, int idx_bits, void* out, int64_t B, int64_t IH,
+                                  int64_t IW, int64_t OH, int64_t OW, int64_t C, int64_t P, ffb6d_stream_t stream);
 /* Relative position encoding fused with the first shared MLP of the local feature aggregation (Building_block.forward,
  * RandLANet.py:196-199: mlp1(relative_pos_encoding(xyz, neigh_idx)), encoding [dis, p-q, p, q] of RandLANet.py:216-223):
  *   out[b,n,k,:] = act(w[:, 0:10] . enc(b,n,k) + bias),   xyz [B,N,3] float32, idx [B,N,K], w [cout, ldw] float32 with

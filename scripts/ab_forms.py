@@ -1,4 +1,5 @@
-"""In-process A/B of forward_pm's boolean form attributes on the default workload (bs = 8, N = 12288, fp32, three streams):
+"""In-process A/B of forward_pm's boolean form attributes on the default workload (bs = 8, N = 12288, fp32, three streams; --precision bf16
+--batch 16 = BASELINE configuration 5):
 one model and one set of MIOpen solver choices, the forms toggled between blocks of steps.  `bench.py --form` runs each setting in
 its own process, where MIOpen's search alone moves the step by +-0.8 ms -- more than the forms compared here.
 
@@ -23,6 +24,8 @@ def main():
     ap.add_argument("groups", nargs="+", help="comma-separated attribute names; group i is switched on from setting i on")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--batch", type=int, default=8)
     args = ap.parse_args()
     groups = [g.split(",") for g in args.groups]
     for g in groups:
@@ -34,8 +37,8 @@ def main():
     net = model.FFB6D(n_classes=22, n_pts=12288)
     net.load_state_dict(bench.state_dict(22))
     net = net.to(dev).eval()
-    net.two_streams, net.precision, net.index_dtype = True, "fp32", torch.int64
-    frames = distributed.shard_frames(2, 8, 0, None, n_points=12288)
+    net.two_streams, net.precision, net.index_dtype = True, args.precision, torch.int64
+    frames = distributed.shard_frames(2, args.batch, 0, None, n_points=12288)
     fixed = {"rgb": torch.from_numpy(frames["rgb"]).to(dev).float(), "cld_rgb_nrm": torch.from_numpy(frames["cld_rgb_nrm"]).to(dev),
              "choose": torch.from_numpy(frames["choose"]).to(dev).long()}
     dpt_xyz = torch.from_numpy(frames["dpt_xyz"]).to(dev)
@@ -69,7 +72,7 @@ def main():
             b.record()
             torch.cuda.synchronize()
             ms[i].append(a.elapsed_time(b) / args.steps)
-    out = {"workload": "bs=8, N=12288, fp32, three streams, one process", "steps_per_block": args.steps, "rounds": args.rounds, "settings": []}
+    out = {"workload": f"bs={args.batch}, N=12288, {args.precision}, three streams, one process", "steps_per_block": args.steps, "rounds": args.rounds, "settings": []}
     for i in range(n_set):
         on = [n for g in groups[:i] for n in g]
         out["settings"].append({"on": on, "ms_per_step": [round(x, 4) for x in ms[i]], "mean_ms": round(sum(ms[i]) / len(ms[i]), 4),

@@ -15,6 +15,7 @@ KEYS = [("mlp_pm_kernel<2, 2, 1, 4, false>", "mlp_pm<64x256>", 2.0), ("mlp_pm_ke
         ("mlp_pm_kernel<2, 1, 2, 2, true>", "mlp_pm<64x32,ksplit>", 2.0), ("mlp_pm_lds_kernel", "mlp_pm<lds128x128>", 2.0),
         ("mlp_pm_stream_kernel", "mlp_pm<stream>", 2.0), ("att_pool_pm_kernel", "att_pool_pm", 2.0),
         ("affine_act_pm_kernel", "affine_act_pm", 2.0), ("bilinear_pm_kernel", "bilinear_resize_pm", 2.0),
+        ("upsampled_patch_rows_pm_kernel", "upsampled_patch_rows_pm", 2.0),
         ("random_sample_pm_kernel", "random_sample_pm", 2.0), ("rel_pos_enc_pm_kernel", "relative_pos_encoding_pm", 1.0),
         ("psp_rowsum_pm_kernel", "psp_pool_pm", 2.0), ("psp_binsum_pm_kernel", "psp_pool_pm", 2.0),
         ("psp_prior_sum_pm_kernel", "psp_prior_sum_pm", 2.0), ("knn_row16", "knn", 1.0), ("knn_pruned", "knn", 1.0),

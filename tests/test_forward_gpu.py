@@ -286,6 +286,37 @@ def test_forward_builds_the_index_pyramid_itself_when_it_is_missing(device, two_
         assert float((got[k] - want[k]).abs().max()) <= HOT_TOL * float(want[k].abs().max()), k
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_head_forms_equal_the_dense_last_stage(device, precision):
+    """forward_pm's forms around the prediction heads -- the last colour stage evaluated at the picked pixels only
+    (LAST_STAGE_AT_CHOSEN), first layers as one stacked GEMM, aligned last layers, keypoint head on the side stream -- against the
+    same network with all of them off (the full 480 x 640 map, then the `choose` pick; ffb6d.py:302-318).  fp32: the hot-path bar
+    (the K = 576 GEMM sums the convolution's products in another order than the dense path); bf16: the bf16 bar of the whole-forward parity tests (5e-2 of the range)."""
+    from ffb6d_amd import forward_pm
+    frames = synth.make_batch(11, 2, n_points=12288, height=480, width=640)
+    net = build(22, 12288, device)
+    net.precision = precision
+    inputs = pyramid.frames_to_device(frames, device)
+    names = ("LAST_STAGE_AT_CHOSEN", "HEADS_SHARE_FIRST", "HEADS_ALIGN_LAST", "HEADS_ON_BOTH_STREAMS")
+    keep = {n: getattr(forward_pm, n) for n in names}
+    try:
+        with torch.no_grad():
+            for n in names:
+                setattr(forward_pm, n, False)
+            want = {k: v.float().clone() for k, v in net(inputs).items()}
+            for n in names:
+                setattr(forward_pm, n, True)
+            got = {k: v.float() for k, v in net(inputs).items()}
+    finally:
+        for n, v in keep.items():
+            setattr(forward_pm, n, v)
+    for k in want:
+        scale = float(want[k].abs().max())
+        err = float((got[k] - want[k]).abs().max()) / scale
+        print(precision, k, "max err / range", err)
+        assert err <= (HOT_TOL if precision == "fp32" else 5e-2), (k, err)
+
+
 def test_batch_items_are_independent(device):
     """Every op on the path is per-sample in eval mode: a frame's result must not depend on its batch
     neighbours -- the property multi-GPU sharding relies on.  Two checks: (1) the same frame between DIFFERENT neighbours in batches

@@ -118,6 +118,33 @@ def test_mlp_pm_operand_gather_and_log_softmax(device):
             torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,h,w,C,P,idt", [(2, 6, 8, 8, 40, torch.int64), (1, 5, 7, 16, 70, torch.int32), (3, 1, 1, 8, 4, torch.int64),
+                                           (2, 12, 16, 64, 333, torch.int64)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_upsampled_patch_rows_are_the_unfolded_upsampled_map(device, B, h, w, C, P, idt, dt):
+    """forward_pm.LAST_STAGE_AT_CHOSEN: the 3x3 patches of the align_corners x2 up-sampling around picked pixels (corners and edges
+    among them: zero padding) == unfold(upsample(x)) at those pixels.  Against this package's own up-sampling kernel: equal bits;
+    against ATen's: 1e-6 (fp32)."""
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(h * w + C + P)
+    x = torch.randn(B, h, w, C, generator=g).to(dt)
+    OH, OW = 2 * h, 2 * w
+    idx = torch.randint(0, OH * OW, (B, P), generator=g)
+    idx[:, :4] = torch.tensor([0, OW - 1, (OH - 1) * OW, OH * OW - 1])             # the four corners
+    got = ops_pm.upsampled_patch_rows(x.to(device), idx.to(idt).to(device), (OH, OW)).cpu()
+    assert got.shape == (B, P, 9 * C) and got.dtype == dt
+
+    def patches(up):                                                                # up [B,OH,OW,C] -> [B,P,9*C], tap-major
+        cols = F.unfold(up.permute(0, 3, 1, 2).float(), 3, padding=1).view(B, C, 9, OH * OW)            # [B, C, tap, pixel]
+        pick = torch.gather(cols, 3, idx.view(B, 1, 1, P).expand(-1, C, 9, -1))                          # [B, C, 9, P]
+        return pick.permute(0, 3, 2, 1).reshape(B, P, 9 * C)
+    ours = ops_pm.bilinear_resize(x.to(device), (OH, OW), True).cpu()
+    assert torch.equal(got.float(), patches(ours))
+    aten = F.interpolate(x.float().permute(0, 3, 1, 2), size=(OH, OW), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    tol = 1e-6 if dt == torch.float32 else 1e-2
+    torch.testing.assert_close(got.float(), patches(aten), rtol=tol, atol=tol)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_stacked_head_gemm_equals_the_separate_launches(device, dt):
     """forward_pm.HEADS_SHARE_FIRST: the first layers of the three heads (ffb6d.py:316-318, same gathered rows) as one GEMM over

@@ -86,6 +86,14 @@ def test_operand_gather_on_the_emulator(emu, hint, idt):
     assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("B,h,w,C,P,idt", [(2, 6, 8, 8, 40, torch.int64), (1, 5, 7, 16, 70, torch.int32), (3, 1, 1, 8, 4, torch.int64)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_upsampled_patch_rows_on_the_emulator(emu, B, h, w, C, P, idt, dt):
+    """forward_pm.LAST_STAGE_AT_CHOSEN: tests/test_pm_gpu.py's own check with CPU tensors"""
+    import test_pm_gpu as TPM
+    TPM.test_upsampled_patch_rows_are_the_unfolded_upsampled_map(torch.device("cpu"), B, h, w, C, P, idt, dt)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_stacked_head_gemm_on_the_emulator(emu, dt):
     """forward_pm.HEADS_SHARE_FIRST: tests/test_pm_gpu.py's own check with CPU tensors"""
