@@ -1205,8 +1205,10 @@ extern "C" int ffb6d_mlp_pm_choice(int64_t rows, int64_t cout, int64_t k1, int64
     if (stream) return 6;
     // LDS-tiled form: rows of whole 128-byte segments (both sources), enough 128 x 128 tiles to fill the chip; bit-identical to
     // the tile kernels and faster on every such layer measured (profiles/r02_mlp_pm_lds_ab.txt: bf16 2.0-2.4x, fp32 0-10 %)
+    // (fp32 with cout <= 64: half of the 128-channel tile would be padding -- the 64 x 256 tile kernel is 1.45x faster there,
+    // profiles/r04_tail_gemm_probe.txt; in bf16 the LDS-tiled form still wins)
     const bool lds = act != 3 && row_bytes % 128 == 0 && (k1 * (bf16 ? 2 : 4)) % 128 == 0 &&
-                     ceil_div(rows, 128) * ceil_div(cout, 128) >= 256;
+                     ceil_div(rows, 128) * ceil_div(cout, 128) >= 256 && (bf16 || cout > 64);
     return lds ? 7 : ffb6d_mlp_pm_tile(rows, cout, K, act);
 }
 

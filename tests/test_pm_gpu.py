@@ -152,7 +152,7 @@ def test_stacked_head_gemm_equals_the_separate_launches(device, dt):
     launch computes, in the same k order: equal bits, first layer and the layer after it (which reads a slice with a 3x row stride)"""
     g = torch.Generator().manual_seed(11)
     B, M, C = 2, 900, 128
-    P = 517 if torch.device(device).type == "cpu" else 20011        # on the GPU: enough rows for the LDS-tiled / stream forms
+    P = 517 if torch.device(device).type == "cpu" else 33001        # on the GPU: enough rows for the LDS-tiled / stream / 32 x 256 forms
     img = torch.randn(B, M, 64, generator=g).to(dt).to(device)
     pts = torch.randn(B, P, 64, generator=g).to(dt).to(device)
     choose = torch.randint(0, M, (B, P), generator=g).to(device)
@@ -174,7 +174,11 @@ def test_stacked_head_gemm_equals_the_separate_launches(device, dt):
         wp, bp = wl.new_zeros(cp, C), bl.new_zeros(cp)
         wp[:cout], bp[:cout] = wl, bl
         got = ops_pm.mlp(y0[..., :C], wp, bp, ops.ACT_NONE)
-        assert got.shape[-1] == cp and torch.equal(got[..., :cout], ops_pm.mlp(y0[..., :C], wl, bl, ops.ACT_NONE)), cout
+        ref = ops_pm.mlp(y0[..., :C], wl, bl, ops.ACT_NONE)
+        # same products; equal bits whenever both shapes take kernels with the same k order (every form but the K-split tile, which
+        # ffb6d_mlp_pm_tile picks for few rows): asserted as 1e-6 of the range so that the kernel choice stays free
+        assert got.shape[-1] == cp and float((got[..., :cout].float() - ref.float()).abs().max()) <= 1e-6 * float(ref.float().abs().max()) \
+            + (0 if dt == torch.float32 else 8e-3 * float(ref.float().abs().max())), cout
         assert not got[..., cout:].any()
 
 
