@@ -279,45 +279,58 @@ bilinear_pm_kernel(const void* __restrict__ in, void* __restrict__ out, int IH, 
 // convolution (pspnet.py:34-45) evaluated only where its output is read: the last colour stage feeds the heads through the `choose`
 // pick alone (ffb6d.py:302-312).  out[r, tap, :] = up(in)[b, Y + ky - 1, X + kx - 1, :] for idx[r] = Y * OW + X, tap = ky * 3 + kx,
 // zeros where the patch leaves the OH x OW map (the convolution's zero padding).  Element arithmetic as bilinear_pm_kernel: a patch
-// element IS the up-sampled map's element.  One thread per (row, tap, 16-byte unit); neighbouring taps share source pixels in L1.
+// element IS the up-sampled map's element.  One thread per (row, filter row ky, 16-byte unit): its three taps' twelve source loads are
+// issued together (taps outside the map read a clamped address and are zeroed by a select), neighbouring taps share source pixels in L1.
 template <typename T, typename I>
 __global__ void __launch_bounds__(BLK)
 upsampled_patch_rows_pm_kernel(const void* __restrict__ in, const I* __restrict__ idx, void* __restrict__ out, int IH, int IW, int OH,
                                int OW, int q, int P, size_t total, float rh, float rw)
 {
     using U = Unit<T>;
-    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * BLK + threadIdx.x;          // (row, ky, unit)
     if (t >= total) return;
     const int c = (int)(t % (size_t)q);
     const size_t rt = t / (size_t)q;
-    const int tap = (int)(rt % 9);
-    const size_t r = rt / 9;
+    const int ky = (int)(rt % 3);
+    const size_t r = rt / 3;
     const int b = (int)(r / (size_t)P);
     long pix = (long)idx[r];
     pix = pix < 0 ? 0 : (pix >= (long)OH * OW ? (long)OH * OW - 1 : pix);        // memory safety only: torch.gather would raise
     const int oy = (int)(pix / OW), ox = (int)(pix - (long)oy * OW);
-    const int yy = oy + tap / 3 - 1, xx = ox + tap % 3 - 1;
-    U v;
-    if (yy < 0 || yy >= OH || xx < 0 || xx >= OW) {
+    const int yy = oy + ky - 1;
+    const bool y_in = yy >= 0 && yy < OH;
+    const float h1r = src_index(rh, y_in ? yy : oy, 1);
+    const int h1 = (int)h1r;
+    const int h1p = (h1 < IH - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const size_t r0 = ((size_t)b * IH + h1) * IW * q;
+    const size_t r1 = r0 + (size_t)h1p * IW * q;
+    U a[3], bq[3], cc[3], d[3];
+    float w0l[3], w1l[3];
+    bool inside[3];
 #pragma unroll
-        for (int e = 0; e < U::VL; ++e) v.v[e] = 0.f;
-    } else {
-        const float h1r = src_index(rh, yy, 1);
-        const int h1 = (int)h1r;
-        const int h1p = (h1 < IH - 1) ? 1 : 0;
-        const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
-        const size_t r0 = ((size_t)b * IH + h1) * IW * q;
-        const size_t r1 = r0 + (size_t)h1p * IW * q;
-        const float w1r = src_index(rw, xx, 1);
+    for (int kx = 0; kx < 3; ++kx) {
+        const int xx = ox + kx - 1;
+        const bool x_in = xx >= 0 && xx < OW;
+        inside[kx] = y_in && x_in;
+        const float w1r = src_index(rw, x_in ? xx : ox, 1);
         const int w1 = (int)w1r;
         const int w1p = (w1 < IW - 1) ? 1 : 0;
-        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        w1l[kx] = w1r - (float)w1;
+        w0l[kx] = 1.f - w1l[kx];
         const int i0 = w1 * q + c, i1 = i0 + w1p * q;
-        const U a = U::load(in, r0 + i0), bq = U::load(in, r0 + i1), cc = U::load(in, r1 + i0), d = U::load(in, r1 + i1);
-#pragma unroll
-        for (int e = 0; e < U::VL; ++e) v.v[e] = h0l * (w0l * a.v[e] + w1l * bq.v[e]) + h1l * (w0l * cc.v[e] + w1l * d.v[e]);
+        a[kx] = U::load(in, r0 + i0); bq[kx] = U::load(in, r0 + i1); cc[kx] = U::load(in, r1 + i0); d[kx] = U::load(in, r1 + i1);
     }
-    v.store(out, t);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        U v;
+#pragma unroll
+        for (int e = 0; e < U::VL; ++e) {
+            const float x = h0l * (w0l[kx] * a[kx].v[e] + w1l[kx] * bq[kx].v[e]) + h1l * (w0l[kx] * cc[kx].v[e] + w1l[kx] * d[kx].v[e]);
+            v.v[e] = inside[kx] ? x : 0.f;
+        }
+        v.store(out, ((r * 9 + (size_t)(ky * 3 + kx)) * (size_t)q) + (size_t)c);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -606,7 +619,7 @@ int ffb6d_upsampled_patch_rows_pm(int dtype, const void* in, const void* idx, in
     const float rh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;       // ATen area_pixel_compute_scale, align_corners
     const float rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
     const int q = (int)(C / VL);
-    const size_t total = (size_t)B * P * 9 * q;
+    const size_t total = (size_t)B * P * 3 * q;              // threads: (row, filter row, 16-byte unit)
     FFB6D_REQUIRE(ceil_div((int64_t)total, BLK) < (1LL << 31), "upsampled_patch_rows_pm: too many workgroups");
     const dim3 grid((unsigned)ceil_div((int64_t)total, BLK));
     DISPATCH_DT(dtype, T, {
