@@ -328,9 +328,9 @@ def test_whole_fused_forward_on_the_emulator_matches_the_plain_torch_restatement
 
 def test_head_forms_equal_the_dense_last_stage_on_the_emulator(emu):
     """DESIGN 4b': the last colour stage at the picked pixels + the heads' forms against the dense evaluation of the same network
-    (tests/test_forward_gpu.py's own check with CPU tensors; one ragged frame: 1100 points, 136 x 168 pixels -- two whole forwards)"""
+    (tests/test_forward_gpu.py's own check with CPU tensors; one ragged frame: 1100 points, 72 x 88 pixels -- two whole forwards)"""
     import test_forward_gpu as TF
-    TF.test_head_forms_equal_the_dense_last_stage(torch.device("cpu"), "fp32", n_pts=1100, height=136, width=168, n_frames=1)
+    TF.test_head_forms_equal_the_dense_last_stage(torch.device("cpu"), "fp32", n_pts=1100, height=72, width=88, n_frames=1)
 
 
 # ---------------------------------------------------------------------------------------------------------------
