@@ -568,7 +568,7 @@ def main():
                        # the forms a record was taken with (module attributes since round 4: no environment switches)
                        "forms": {"lfa_fused": forward_pm.LFA_FUSED, "posenc_fused": forward_pm.POSENC_FUSED, "stem_fused": forward_pm.STEM_FUSED,
                                  "last_stage_at_chosen": forward_pm.LAST_STAGE_AT_CHOSEN, "heads_share_first": forward_pm.HEADS_SHARE_FIRST, "heads_align_last": forward_pm.HEADS_ALIGN_LAST,
-                                 "heads_on_both_streams": forward_pm.HEADS_ON_BOTH_STREAMS,
+                                 "heads_on_both_streams": forward_pm.HEADS_ON_BOTH_STREAMS, "heads_chain_fused": forward_pm.HEADS_CHAIN_FUSED,
                                  "upconv_fold": forward_pm.UPCONV_FOLD if isinstance(forward_pm.UPCONV_FOLD, str) else
                                  (None if forward_pm.UPCONV_FOLD is None else sorted(forward_pm.UPCONV_FOLD)),
                                  "psp_train_fold": model.PyramidPooling.fold_in_training},

@@ -97,6 +97,14 @@ def out_padded(m, cout_to, dt=F32):
     return cached(m, "outpad%d%s" % (cout_to, dt), mlp_sources(m), build)
 
 
+def kc_padded(m, cout_to):
+    """out_padded(m, cout_to) in float32 with the weight k-chunked (ops_pm.k_chunked): the last layer of csrc/mlp_chain.hip"""
+    def build():
+        w, b = out_padded(m, cout_to, F32)
+        return ops_pm.k_chunked(w), b
+    return cached(m, "kcpad%d" % cout_to, mlp_sources(m), build)
+
+
 def split(m, k1, dt=F32):
     """(W_a [Cout,k1], W_b [Cout,Cin-k1], b) for conv(cat(a, gather(b))) == W_a a + gather(W_b b)."""
     def build():
@@ -133,6 +141,9 @@ HEADS_SHARE_FIRST = True
 HEADS_ALIGN_LAST = True
 # ... and the keypoint head on the side stream while the other two run on main (only with two_streams)
 HEADS_ON_BOTH_STREAMS = True
+# ... and the three layers after the first of each head (128 -> 128 -> 128 -> c) as one launch with the hidden activations in
+# registers (csrc/mlp_chain.hip; fp32 only)
+HEADS_CHAIN_FUSED = True
 LFA_WIDTHS = (32, 64, 128, 256)
 
 
@@ -569,6 +580,14 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
 
     def head(seq, y):
         layers = list(seq)[1:]
+        if HEADS_CHAIN_FUSED and y.dtype == torch.float32 and len(layers) == 3 and y.shape[-1] == 128 and \
+                [tuple(m.conv.weight.shape[:2]) for m in layers[:2]] == [(128, 128)] * 2 and layers[2].conv.weight.shape[1] == 128 \
+                and layers[2].conv.weight.shape[0] <= 32 and all(m.act_code in (0, 1, 2) for m in layers):
+            # the three remaining layers as one launch, hidden activations in registers (csrc/mlp_chain.hip)
+            cout = layers[2].conv.weight.shape[0]
+            cpad = -(-cout // 4) * 4
+            parts = [folded_kc(m, F32) + (m.act_code,) for m in layers[:2]] + [kc_padded(layers[2], 32) + (layers[2].act_code,)]
+            return ops_pm.mlp_chain3(y, parts[0], parts[1], parts[2], cpad)[..., :cout]
         for layer in layers[:-1]:
             y = mlp(layer, y)
         last, cout = layers[-1], layers[-1].conv.weight.shape[0]

@@ -223,6 +223,29 @@ def k_chunked(w):
     return w.detach().reshape(cout, d // vl, vl).permute(1, 0, 2).contiguous()
 
 
+def mlp_chain3(x, layer1, layer2, layer3, cout3):
+    """Three shared MLPs in a row as one launch (csrc/mlp_chain.hip; the layers after the first of a prediction head,
+    ffb6d.py:135-157): x [..., 128] float32 rows (a channel slice of a wider row buffer is fine); layer_i = (W k-chunked, bias, act)
+    with W1, W2 = k_chunked([128,128]), W3 = k_chunked([32,128]) (rows >= cout3 zero), biases float32 [128], [128], [32] -> [..., cout3]."""
+    _need_gpu(x)
+    lib = _lib.load()
+    a, ldx = rows_view(x.detach())
+    if x.dtype != torch.float32 or a.shape[1] != 128:
+        raise ValueError("mlp_chain3 takes float32 rows of 128 channels")
+    (w1, b1, a1), (w2, b2, a2), (w3, b3, a3) = layer1, layer2, layer3
+    for w, b, shape, n in ((w1, b1, (32, 128, 4), 128), (w2, b2, (32, 128, 4), 128), (w3, b3, (32, 32, 4), 32)):
+        if tuple(w.shape) != shape or w.dtype != torch.float32 or not w.is_contiguous() or b.dtype != torch.float32 or b.numel() != n:
+            raise ValueError(f"k-chunked float32 weight {shape} and float32 bias [{n}] expected, got {tuple(w.shape)} / {tuple(b.shape)}")
+    rows = a.shape[0]
+    out = torch.empty(tuple(x.shape[:-1]) + (int(cout3),), dtype=torch.float32, device=x.device)
+    nbytes = 4 * (rows * (128 + int(cout3)) + 2 * 128 * 128 + 32 * 128)
+    with torch.cuda.device(x.device), _lib.traced("mlp_chain3_pm", nbytes, (128, int(cout3), rows)):
+        rc = lib.ffb6d_mlp_chain3_pm_f32(a.data_ptr(), ldx, w1.data_ptr(), b1.data_ptr(), int(a1), w2.data_ptr(), b2.data_ptr(), int(a2),
+                                         w3.data_ptr(), b3.data_ptr(), int(a3), out.data_ptr(), int(cout3), rows, int(cout3), _stream(x))
+    _lib.check(rc, "ffb6d_mlp_chain3_pm_f32")
+    return out
+
+
 def lfa_half(mode, xyz, neigh_idx, f, w1, b1, act1, wfc, wm, bm, actm, w2=None, b2=None, act2=ACT_NONE, out=None, p_hint=0):
     """One half of Building_block.forward (RandLANet.py:196-214) in one launch (csrc/lfa_pm.hip): neighbour gather +
     relative_pos_encoding + mlp1 (+ mlp2 for mode 2) + Att_pooling (fc, softmax over the 16 neighbours, weighted sum, mlp).

@@ -184,6 +184,14 @@ int ffb6d_affine_relu_maxpool_pm(int dtype, const void* x, const float* scale, c
 /* Bilinear resize [B,IH,IW,C] -> [B,OH,OW,C] (ATen upsample_bilinear2d arithmetic; pspnet.py:24-28,37-42). */
 int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, int64_t IH, int64_t IW, int64_t OH, int64_t OW,
                              int64_t C, int align_corners, ffb6d_stream_t stream);
+/* Three shared MLPs in a row on [rows, 128] float32 rows as one launch (the layers after the first of a prediction head,
+ * ffb6d.py:135-157,316-318): out = act3(W3 act2(W2 act1(W1 x + b1) + b2) + b3), W1, W2 [128,128], W3 [cout3,128] with BatchNorm
+ * folded; the hidden activations stay in registers.  Weights k-chunked ([K/4][cout][4] floats: element (q, c, j) = W[c][4q + j]),
+ * W3 / b3 padded with zero rows to 32 output channels; cout3 (a multiple of 4, <= 32) channels of a row are written; act codes as
+ * ffb6d_mlp_pm (0 none, 1 ReLU, 2 LeakyReLU(0.2)).  Per output the k order of ffb6d_mlp_pm's tile kernels. */
+int ffb6d_mlp_chain3_pm_f32(const float* x, int64_t ldx, const float* w1k, const float* b1, int act1, const float* w2k, const float* b2,
+                            int act2, const float* w3k, const float* b3, int act3, float* out, int64_t ldo, int64_t rows, int64_t cout3,
+                            ffb6d_stream_t stream);
 /* PSPUpsample's convolution where its output is read (pspnet.py:34-45; the last colour stage feeds the heads only through the `choose`
  * pick, ffb6d.py:302-312): out [B*P, 9, C] = the 3x3 patches of the align_corners bilinear up-sampling of in [B,IH,IW,C] to OH x OW
  * around the picked pixels idx [B*P] (flat Y*OW + X within the frame; int32 / int64), tap-major, zeros outside the map -- the operand

@@ -41,3 +41,22 @@ for dt, bs in ((torch.float32, 8), (torch.bfloat16, 16)):
             base = y if base is None else base
             line.append(f"{hint}: {us:7.1f} us {2e-6 * rows * (k1 + k2) * cout / us:6.1f} TF/s{'' if torch.equal(y, base) else ' (bits differ)'}")
         print(f"{str(dt)[6:]:9s} K={k1}+{k2} cout={cout} rows={rows}   " + "   ".join(line))
+
+# a head's three layers after the first (128 -> 128 -> 128 -> c): three launches against csrc/mlp_chain.hip, fp32, bs = 8
+rows = 12288 * 8
+wide = torch.randn(rows, 384, device=dev)
+x = wide[:, 128:256]
+for cout in (22, 24, 3):
+    ws = [torch.randn(128, 128, device=dev) / 11, torch.randn(128, 128, device=dev) / 11, torch.randn(cout, 128, device=dev) / 11]
+    bs = [torch.randn(128, device=dev), torch.randn(128, device=dev), torch.randn(cout, device=dev)]
+    cpad = -(-cout // 4) * 4
+    wp, bp = torch.zeros(cpad, 128, device=dev), torch.zeros(cpad, device=dev)
+    wp[:cout], bp[:cout] = ws[2], bs[2]
+    w32, b32 = torch.zeros(32, 128, device=dev), torch.zeros(32, device=dev)
+    w32[:cout], b32[:cout] = ws[2], bs[2]
+    parts = [(ops_pm.k_chunked(ws[0]), bs[0], 1), (ops_pm.k_chunked(ws[1]), bs[1], 1), (ops_pm.k_chunked(w32), b32, 0)]
+    t3, y3 = run(lambda: ops_pm.mlp(ops_pm.mlp(ops_pm.mlp(x, ws[0], bs[0], 1), ws[1], bs[1], 1), wp, bp, 0))
+    t1, y1 = run(lambda: ops_pm.mlp_chain3(x, parts[0], parts[1], parts[2], cpad))
+    fl = 2e-6 * rows * (2 * 128 * 128 + 128 * cout)
+    print(f"head chain 128->128->128->{cout}: three launches {t3:7.1f} us   one launch {t1:7.1f} us {fl / t1:6.1f} TF/s   "
+          f"max |diff| / range {float((y1 - y3).abs().max() / y3.abs().max()):.1e}")

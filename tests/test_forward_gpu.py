@@ -289,7 +289,7 @@ def test_forward_builds_the_index_pyramid_itself_when_it_is_missing(device, two_
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_head_forms_equal_the_dense_last_stage(device, precision, n_pts=12288, height=480, width=640, n_frames=2):
     """forward_pm's forms around the prediction heads -- the last colour stage evaluated at the picked pixels only
-    (LAST_STAGE_AT_CHOSEN), first layers as one stacked GEMM, aligned last layers, keypoint head on the side stream -- against the
+    (LAST_STAGE_AT_CHOSEN), first layers as one stacked GEMM, the remaining layers of a head as one launch (fp32), keypoint head on the side stream -- against the
     same network with all of them off (the full 480 x 640 map, then the `choose` pick; ffb6d.py:302-318).  fp32: the hot-path bar
     (the K = 576 GEMM sums the convolution's products in another order than the dense path); bf16: the bf16 bar of the whole-forward parity tests (5e-2 of the range)."""
     from ffb6d_amd import forward_pm
@@ -297,8 +297,9 @@ def test_head_forms_equal_the_dense_last_stage(device, precision, n_pts=12288, h
     net = build(22, n_pts, device)
     net.precision = precision
     inputs = pyramid.frames_to_device(frames, device)
-    names = ("LAST_STAGE_AT_CHOSEN", "HEADS_SHARE_FIRST", "HEADS_ALIGN_LAST", "HEADS_ON_BOTH_STREAMS")
+    names = ("LAST_STAGE_AT_CHOSEN", "HEADS_SHARE_FIRST", "HEADS_ALIGN_LAST", "HEADS_ON_BOTH_STREAMS", "HEADS_CHAIN_FUSED")
     keep = {n: getattr(forward_pm, n) for n in names}
+    chain = forward_pm.ops_pm.mlp_chain3
     on_gpu = torch.device(device).type == "cuda"          # the emulator suite calls this with CPU tensors: one stream, the fused path directly
     run = (lambda: net(inputs)) if on_gpu else (lambda: forward_pm.forward(net, inputs, {}, two_streams=False))
     try:
@@ -308,8 +309,12 @@ def test_head_forms_equal_the_dense_last_stage(device, precision, n_pts=12288, h
             want = {k: v.float().clone() for k, v in run().items()}
             for n in names:
                 setattr(forward_pm, n, True)
+            calls, chain = [], forward_pm.ops_pm.mlp_chain3
+            forward_pm.ops_pm.mlp_chain3 = lambda *a, **k: (calls.append(1), chain(*a, **k))[1]
             got = {k: v.float() for k, v in run().items()}
+            assert len(calls) == (3 if precision == "fp32" else 0)          # the fused chain is an fp32 kernel
     finally:
+        forward_pm.ops_pm.mlp_chain3 = chain
         for n, v in keep.items():
             setattr(forward_pm, n, v)
     for k in want:

@@ -118,6 +118,35 @@ def test_mlp_pm_operand_gather_and_log_softmax(device):
             torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("rows,cout,acts,sliced", [(517, 22, (1, 1, 0), True), (128, 3, (1, 2, 0), False), (33, 24, (0, 1, 1), True),
+                                                    (100000, 22, (1, 1, 0), True)])
+def test_mlp_chain3_matches_the_separate_layers(device, rows, cout, acts, sliced):
+    """csrc/mlp_chain.hip (forward_pm.HEADS_CHAIN_FUSED): 128 -> 128 -> 128 -> c as one launch, hidden activations in registers,
+    against float64 (1e-5 of the range, the GEMM bar) and against three ffb6d_mlp_pm launches (1e-6: same products, same k order
+    wherever the separate launches take a tile kernel)."""
+    if rows > 1000 and torch.device(device).type == "cpu":
+        pytest.skip("the large case is for the device")
+    g = torch.Generator().manual_seed(rows + cout)
+    wide = torch.randn(rows, 384, generator=g)
+    x = (wide[:, 128:256] if sliced else wide[:, :128].contiguous()).to(device)           # a channel slice: row stride 384
+    ws = [torch.randn(128, 128, generator=g) / 11, torch.randn(128, 128, generator=g) / 11, torch.randn(cout, 128, generator=g) / 11]
+    bs = [torch.randn(128, generator=g), torch.randn(128, generator=g), torch.randn(cout, generator=g)]
+    cpad = -(-cout // 4) * 4
+    w3p, b3p = torch.zeros(32, 128), torch.zeros(32)
+    w3p[:cout], b3p[:cout] = ws[2], bs[2]
+    parts = [(ops_pm.k_chunked(w).to(device), b.to(device), a) for w, b, a in zip([ws[0], ws[1], w3p], [bs[0], bs[1], b3p], acts)]
+    got = ops_pm.mlp_chain3(x, parts[0], parts[1], parts[2], cpad)
+    assert got.shape == (rows, cpad) and not got[:, cout:].any()
+    y, y64 = x, x.double().cpu()
+    for w, b, a in zip(ws, bs, acts):
+        y = ops_pm.mlp(y, w.to(device), b.to(device), a)
+        y64 = y64 @ w.double().t() + b.double()
+        y64 = torch.relu(y64) if a == 1 else (torch.nn.functional.leaky_relu(y64, 0.2) if a == 2 else y64)
+    scale = float(y64.abs().max())
+    assert float((got[:, :cout].double().cpu() - y64).abs().max()) <= 1e-5 * scale
+    assert float((got[:, :cout] - y).abs().max()) <= 1e-6 * scale
+
+
 @pytest.mark.parametrize("B,h,w,C,P,idt", [(2, 6, 8, 8, 40, torch.int64), (1, 5, 7, 16, 70, torch.int32), (3, 1, 1, 8, 4, torch.int64),
                                            (2, 12, 16, 64, 333, torch.int64)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
