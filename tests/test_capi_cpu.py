@@ -106,6 +106,17 @@ def test_argument_errors_are_reported_without_a_gpu(native_lib):
     assert rc != 0 and "npts" in _lib.last_error()
     rc = native_lib.ffb6d_random_sample_f32(None, None, 16, None, None, 1, 1, 1, 1, 16, None)
     assert rc != 0 and "idx_bits" in _lib.last_error()
+    # round 4's entry points: shapes are checked before anything touches a device
+    rc = native_lib.ffb6d_mlp_chain3_pm_f32(None, 128, None, None, 1, None, None, 1, None, None, 0, None, 24, 100, 22, None)
+    assert rc != 0 and "cout3" in _lib.last_error()                                  # 22 is not a multiple of 4
+    rc = native_lib.ffb6d_mlp_chain3_pm_f32(None, 128, None, None, 1, None, None, 3, None, None, 0, None, 24, 100, 24, None)
+    assert rc != 0 and "act" in _lib.last_error()                                    # no log-softmax inside the chain
+    assert native_lib.ffb6d_mlp_chain3_pm_f32(None, 128, None, None, 1, None, None, 1, None, None, 0, None, 24, 0, 24, None) == 0      # no rows
+    rc = native_lib.ffb6d_upsampled_patch_rows_pm(0, None, None, 16, None, 1, 4, 4, 8, 8, 8, 10, None)
+    assert rc != 0 and "idx_bits" in _lib.last_error()
+    rc = native_lib.ffb6d_upsampled_patch_rows_pm(0, None, None, 64, None, 1, 4, 4, 8, 8, 6, 10, None)
+    assert rc != 0 and "bad shape" in _lib.last_error()                              # 6 channels: not whole 16-byte units
+    assert native_lib.ffb6d_upsampled_patch_rows_pm(0, None, None, 64, None, 1, 4, 4, 8, 8, 8, 0, None) == 0                           # no rows
 
 
 def test_ops_refuse_cpu_tensors():
