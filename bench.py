@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--trace-all", action="store_true", help="extra untimed pass: per-op table to stderr")
     ap.add_argument("--cudnn-benchmark", type=int, default=1,
                     help="torch.backends.cudnn.benchmark (MIOpen find mode for the colour branch's dense convs)")
+    ap.add_argument("--miopen-db", choices=["pinned", "fresh"], default="pinned",
+                    help="pinned (default): MIOpen reads the committed find-db of ONE search (ffb6d_amd/miopen_pin.py) instead of timing "
+                         "its near-tied solvers again on every machine -- the same convolution kernels on every run; fresh: MIOpen's own "
+                         "search on an empty user database (what rounds 1-4 measured: the step moves by +-0.4-0.8 ms with the draw)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer (default, the BASELINE metric): pyramid + forward, eval, no_grad.  train: BASELINE "
                          "config 3 shape -- pyramid + forward + backward + Adam step in train() mode, wrapped in "
@@ -109,8 +113,9 @@ MLP_KERNEL_NAMES = {"mlp_pm<128x128>": "mlp_pm_kernel<2, 2, 2, 2, false>", "mlp_
                     "mlp_pm<32x256>": "mlp_pm_kernel<1, 2, 1, 4, false>", "mlp_pm<64x64>": "mlp_pm_kernel<1, 1, 2, 2, false>",
                     "mlp_pm<64x32,ksplit>": "mlp_pm_kernel<2, 1, 2, 2, true>",
                     "mlp_pm<stream>": "mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>", "mlp_pm<lds128x128>": "mlp_pm_lds_kernel<T>",
+                    "mlp_pm<seq128x128>": "mlp_pm_seq_kernel<TWO>",
                     "att_pool_pm": "att_pool_pm_kernel<TM, TN>", "lfa_pm": "lfa_pm_kernel<T, D, MODE, P>"}
-PM_TILES = {1: "128x128", 2: "64x256", 3: "32x256", 4: "64x64", 5: "64x32,ksplit", 6: "stream", 7: "lds128x128"}
+PM_TILES = {1: "128x128", 2: "64x256", 3: "32x256", 4: "64x64", 5: "64x32,ksplit", 6: "stream", 7: "lds128x128", 8: "seq128x128"}
 
 
 def gemm_flops(name, rec_tag, batch):
@@ -206,6 +211,12 @@ def main():
     args = parse()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)            # never returns: a multi-GPU request is never silently run on one rank
+    miopen_db = "MIOpen's own search (fresh user find-db)"
+    if args.miopen_db == "pinned":
+        from ffb6d_amd import miopen_pin
+        miopen_db = miopen_pin.use(rank=local_rank)          # before the first convolution: a private copy per process
     if world_env > 1:
         # one MIOpen find-db / kernel cache per rank: N ranks tuning the same convolutions at the same
         # time would otherwise contend for the lock of one sqlite user database
@@ -213,8 +224,6 @@ def main():
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/ffb6d_miopen_cache_rank{local_rank}")
         for d in (os.environ["MIOPEN_USER_DB_PATH"], os.environ["MIOPEN_CUSTOM_CACHE_DIR"]):
             os.makedirs(d, exist_ok=True)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args)            # never returns: a multi-GPU request is never silently run on one rank
     if world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     if not torch.cuda.is_available():
@@ -569,6 +578,8 @@ def main():
                        "forms": {"lfa_fused": forward_pm.LFA_FUSED, "posenc_fused": forward_pm.POSENC_FUSED, "stem_fused": forward_pm.STEM_FUSED,
                                  "last_stage_at_chosen": forward_pm.LAST_STAGE_AT_CHOSEN, "heads_share_first": forward_pm.HEADS_SHARE_FIRST, "heads_align_last": forward_pm.HEADS_ALIGN_LAST,
                                  "heads_on_both_streams": forward_pm.HEADS_ON_BOTH_STREAMS, "heads_chain_fused": forward_pm.HEADS_CHAIN_FUSED,
+                                 "gemm_seq_form": forward_pm.GEMM_SEQ_FORM,
+                                 "miopen": ("find mode (cudnn.benchmark), " if args.cudnn_benchmark else "immediate mode, ") + miopen_db,
                                  "upconv_fold": forward_pm.UPCONV_FOLD if isinstance(forward_pm.UPCONV_FOLD, str) else
                                  (None if forward_pm.UPCONV_FOLD is None else sorted(forward_pm.UPCONV_FOLD)),
                                  "psp_train_fold": model.PyramidPooling.fold_in_training},

@@ -32,6 +32,7 @@
 // every row, i.e. 8 k and four MFMAs in fp32, 16 k and ONE MFMA (16x the rate) in bf16.  Bias and all epilogue
 // arithmetic stay fp32; stores round to nearest even (v_cvt_pk_bf16_f32).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "ffb6d_ops.h"
@@ -62,6 +63,10 @@ struct PmParams {
     int P, py, px;        // output rows per frame (for the gathers), rows of Y / of X1 per frame
     int act, idx64;
     int n_pt, n_ct;       // point tiles, channel tiles
+    // tile-sequence form: three regions of point tiles with decreasing sequence lengths (guided schedule: the last workgroups the
+    // dispatcher hands out are short ones).  Region A = point tiles [0, pt_b): tpg tiles per workgroup; B = [pt_b, pt_c): tpg_b;
+    // C = [pt_c, n_pt): one tile per workgroup.  wg_b / wg_c = first workgroup of regions B / C.
+    int tpg, tpg_b, pt_b, pt_c, wg_b, wg_c;
 };
 
 // epilogue shared by the GEMM kernels: bias, gathered / added row of Y, activation or log-softmax, store
@@ -835,6 +840,260 @@ mlp_pm_lds_kernel(const PmParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Tile-SEQUENCE form of the LDS-tiled GEMM (round 5): the answer to what round 4 measured -- the tile boundary's cost is the epilogue
+// (output bytes / ~5 TB/s per launch, ~100 cycles per store instruction and CU, hidden by nothing: 10-13 % of the fp32 launches, a quarter
+// of the K = 128 / 256 ones), and a wave cannot multiply while it waits in its own in-order vector-memory queue.  Here a workgroup owns
+// `tpg` consecutive channel tiles of ONE point tile (same X rows, W rows change) and
+//   * the operand stream runs across the tile boundaries (the loader is two steps ahead of the multiply whatever tile that step is in);
+//   * the finished tile's accumulators move to a SECOND register set and its epilogue is cut into 16 pieces (one 4-channel group of one
+//     32 x 32 MFMA tile: 4 VALU adds, activation, ONE 16-byte store per lane) that ride inside the first four steps of the NEXT tile,
+//     one piece per 16 MFMAs -- the stores trickle out between multiplies instead of as a 64-instruction train in front of the
+//     workgroup's exit; the rows of Y a piece adds (gathered rows of the p2r fusion / decoder) are requested one step ahead,
+//     BEFORE the operand loads of that step, so waiting for them never waits for the operand stream;
+//   * register budget for two accumulator sets: ONE staging register set instead of three (a step is 64 fp32 MFMAs per wave = ~4 k
+//     cycles of matrix pipe, longer than the memory latency: the loads of step g + 2 are issued at the top of step g and parked into
+//     LDS at the top of step g + 1) -- 2 x 64 accumulators + 32 staging + 32 fragments; the bias of the group's channels sits in LDS.
+//   Only the LAST tile of a sequence keeps an exposed epilogue; the grid still has >= ~1000 workgroups on every layer the chooser
+//   sends here (the persistent forms of round 4 lost inside the three-stream step because 512 resident workgroups cannot be
+//   rebalanced; here the hardware dispatcher still hands out several rounds of workgroups).
+// Same products in the same k order per accumulator, same epilogue arithmetic -> bit-identical to mlp_pm_lds_kernel / the tile kernels.
+// fp32 only (a bf16 step is ~0.5 k cycles: one staging set cannot hide the memory latency there).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool TWO>
+__global__ void __launch_bounds__(BLK, 2)
+mlp_pm_seq_kernel(const PmParams p)
+{
+    typedef float T;
+    constexpr int SZ = 4;
+    constexpr int CB = 128;                           // bytes of every row per step
+    constexpr int RS = CB + 16;                       // image row stride
+    constexpr int IMG = 128 * RS;                     // one operand image
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [2 stages][W image | X image], bias of the group [tpg * 128] fp32
+
+    int t = blockIdx.x, tpg = p.tpg, pt_lo = 0, pt_hi = p.pt_b;
+    if (t >= p.wg_c) { t -= p.wg_c; tpg = 1; pt_lo = p.pt_c; pt_hi = p.n_pt; }
+    else if (t >= p.wg_b) { t -= p.wg_b; tpg = p.tpg_b; pt_lo = p.pt_b; pt_hi = p.pt_c; }
+    const int n_grp = (p.n_ct + tpg - 1) / tpg;
+    const int xcd = t & 7, sl = t >> 3;
+    const int pt = pt_lo + (sl / n_grp) * 8 + xcd;
+    const int grp = sl % n_grp;
+    if (pt >= pt_hi) return;
+    const int ct0 = grp * tpg;
+    const int ntile = min(tpg, p.n_ct - ct0);
+    const int r0 = pt * 128;
+
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int K = p.k1 + p.k2;
+    const int kb1 = p.k1 * SZ, kbt = K * SZ;
+    const int nstage = kbt / CB;                      // >= 4 (launcher)
+    const int total = ntile * nstage;                 // steps of this workgroup
+
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, (unsigned)p.cout * (unsigned)kbt);
+    const unsigned x1_rows = p.xidx ? (unsigned)(p.rows / p.P) * (unsigned)p.px : (unsigned)p.rows;
+    const __amdgpu_buffer_rsrc_t rs_x1 = make_rsrc(p.x1, span_bytes(x1_rows, p.ld1, p.k1, SZ));
+    const __amdgpu_buffer_rsrc_t rs_x2 = make_rsrc(TWO ? p.x2 : p.x1, TWO ? span_bytes((unsigned)p.rows, p.ld2, p.k2, SZ) : 0u);
+    const unsigned y_rows = p.gidx ? (unsigned)(p.rows / p.P) * (unsigned)p.py : (unsigned)p.rows;
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.y ? p.y : p.out, p.y ? span_bytes(y_rows, p.ldy, p.cout, SZ) : 0u);
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, span_bytes((unsigned)p.rows, p.ldo, p.cout, SZ));
+
+    // bias of the group's channels -> LDS (-0.0f where there is none: x + (-0.0f) == x for every x, the sign of a zero included)
+    float* bias_lds = reinterpret_cast<float*>(lds + 4 * IMG);
+    for (int c = threadIdx.x; c < ntile * 128; c += BLK) {
+        const int ch = ct0 * 128 + c;
+        bias_lds[c] = (p.bias && ch < p.cout) ? p.bias[ch] : -0.0f;
+    }
+
+    // loader: thread -> 16-byte chunk lchunk of the 128-byte segment of rows lrow + 32 i (i < 4), for W and for X
+    const int lchunk = threadIdx.x & 7, lrow = threadIdx.x >> 3;
+    int w_off[4], x1_off[4], x2_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + lrow + 32 * i;
+        x1_off[i] = OOB;
+        x2_off[i] = OOB;
+        if (r < p.rows) {
+            int xr = r;
+            if (p.xidx)
+                xr = (r / p.P) * p.px + (p.idx64 ? (int)static_cast<const long long*>(p.xidx)[r] : static_cast<const int*>(p.xidx)[r]);
+            x1_off[i] = xr * p.ld1 * SZ + lchunk * 16;
+            x2_off[i] = r * p.ld2 * SZ + lchunk * 16;
+        }
+    }
+    auto set_w = [&](int ct) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = ct * 128 + lrow + 32 * i;
+            w_off[i] = ch < p.cout ? ch * kbt + lchunk * 16 : OOB;
+        }
+    };
+    struct Step { u32x4 w[4], x[4]; };
+    Step v;
+    int l_s = 0, l_ct = ct0;                          // the loader's position: step of channel tile l_ct
+    // Branch-free (descriptor and offsets selected; past the last step: out-of-range offsets, nothing is fetched): hipcc counts
+    // outstanding loads exactly only through straight-line code, and the epilogue pieces below wait for THEIR loads by count.
+    // (max(off, dead): every offset is in [0, OOB], dead is 0 or OOB -- a select on a wave-uniform condition becomes a branch.)
+    auto gload = [&](int dead) {                      // the loader's step -> v; then on to the next step (of the next tile after the last step)
+        const int seg = l_s * CB;
+        const bool first = !TWO || seg < kb1;
+        const __amdgpu_buffer_rsrc_t rx = first ? rs_x1 : rs_x2;
+        const int xseg = first ? seg : seg - kb1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, max(w_off[i], dead), seg, 0);
+            v.x[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, max(first ? x1_off[i] : x2_off[i], dead), xseg, 0);
+        }
+        if (++l_s == nstage) {
+            l_s = 0;
+            ++l_ct;
+            set_w(l_ct);                              // past the last tile: never used
+        }
+    };
+    auto park = [&](int stage) {
+        unsigned char* wi = lds + stage * 2 * IMG;
+        unsigned char* xi = wi + IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(wi + (lrow + 32 * i) * RS + lchunk * 16) = v.w[i];
+            *reinterpret_cast<u32x4*>(xi + (lrow + 32 * i) * RS + lchunk * 16) = v.x[i];
+        }
+    };
+
+    // epilogue geometry of this lane: two output rows (j), their Y rows, as byte offsets into the buffers
+    int o_off[2], y_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = r0 + (wn * 2 + j) * 32 + l31;
+        o_off[j] = OOB;
+        y_off[j] = OOB;
+        if (r < p.rows) {
+            o_off[j] = r * p.ldo * SZ;
+            if (p.y) {
+                int yr = r;
+                if (p.gidx)
+                    yr = (r / p.P) * p.py + (p.idx64 ? (int)static_cast<const long long*>(p.gidx)[r] : static_cast<const int*>(p.gidx)[r]);
+                y_off[j] = yr * p.ldy * SZ;
+            }
+        }
+    }
+    const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
+    const float y_on = p.y ? 1.f : 0.f;               // (no Y: the registers hold the zeros of an out-of-range load; x + (-0.0f) == x)
+
+    f32x16 acc[2][2], prev[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // piece q of a finished tile (channel base pc0): MFMA tile (i, j), 4-channel group gq
+    //   q = 4 * ph + ks  ->  j = q >> 3, i = (q >> 2) & 1, gq = q & 3
+    u32x4 yreg[4];                                    // Y rows of the four pieces of the coming drain step
+    int pc0 = 0;                                      // channel base of the tile in `prev`
+    auto piece_off = [&](int q, int c0t, const int (&row_off)[2]) {          // byte offset of piece q's 16 bytes in a row buffer, OOB if dead
+        const int j = q >> 3, i = (q >> 2) & 1, gq = q & 3;
+        const int ch = c0t + (wm * 2 + i) * 32 + 8 * gq + 4 * kh;
+        return ch < p.cout ? max(row_off[j], row_off[j] + ch * SZ) : OOB;  // (a dead row: OOB + ch * SZ wraps negative, max keeps OOB)
+    };
+    auto yload = [&](int ph, int c0t) {               // pieces 4 ph .. 4 ph + 3 of the tile at c0t
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) yreg[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, piece_off(4 * ph + ks, c0t, y_off), 0, 0);
+    };
+    auto piece = [&](int ph, int ks) {
+        const int q = 4 * ph + ks;
+        const int j = q >> 3, i = (q >> 2) & 1, gq = q & 3;
+        const int ch = pc0 + (wm * 2 + i) * 32 + 8 * gq + 4 * kh;
+        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + (ch - ct0 * 128));
+        u32x4 ou;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float u = prev[i][j][4 * gq + c] + (c == 0 ? b4.x : c == 1 ? b4.y : c == 2 ? b4.z : b4.w);
+            const float yv = __uint_as_float(yreg[ks][c]);
+            u += y_on != 0.f ? yv : -0.0f;
+            ou[c] = __float_as_uint(activate(u, slope));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(ou, rs_o, piece_off(q, pc0, o_off), 0, 0);
+    };
+
+    int g = 0;                                        // step of the workgroup's sequence being multiplied
+    // one step: park the loads of step g + 1, request step g + 2, multiply step g (PH >= 0: with four epilogue pieces of the tile before,
+    // each after the first half of its sub-step's MFMAs: its wait for the Y rows and its VALU work sit under the second half)
+    auto step = [&](auto ph_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
+        park((g + 1) & 1);                            // (after the last step: into a stage nobody reads any more)
+        gload(g + 2 < total ? 0 : OOB);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* wi = lds + (g & 1) * 2 * IMG + (wm * 64 + l31) * RS + kh * 16;
+        const unsigned char* xi = lds + (g & 1) * 2 * IMG + IMG + (wn * 64 + l31) * RS + kh * 16;
+        u32x4 wa[2][2], xb[2][2];
+        auto frags = [&](int ks, u32x4 (&a)[2], u32x4 (&b)[2]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const u32x4*>(wi + i * 32 * RS + ks * 32);
+                b[i] = *reinterpret_cast<const u32x4*>(xi + i * 32 * RS + ks * 32);
+            }
+        };
+        auto half = [&](int ks, int h) {              // two of the four (k, k + 4) pairs of sub-step ks: 8 MFMAs
+#pragma unroll
+            for (int tt = 2 * h; tt < 2 * h + 2; ++tt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wa[ks & 1][i][tt]), __uint_as_float(xb[ks & 1][j][tt]),
+                                                                         acc[i][j], 0, 0, 0);
+        };
+        frags(0, wa[0], xb[0]);
+#pragma unroll
+        for (int ks = 0; ks < CB / 32; ++ks) {
+            if (ks + 1 < CB / 32) frags(ks + 1, wa[(ks + 1) & 1], xb[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            half(ks, 0);
+            if constexpr (PH >= 0) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PH >= 0) piece(PH, ks);
+            half(ks, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // Y rows of the next drain step -- issued after this step's pieces have used the registers and before the next step's operand loads
+        if constexpr (PH >= 0 && PH < 3) yload(PH + 1, pc0);
+        __syncthreads();
+        ++g;
+    };
+
+    set_w(ct0);
+    gload(0);
+    park(0);
+    gload(0);                                         // total >= nstage >= 4
+    __syncthreads();
+    int c0 = ct0 * 128;
+    for (int s = 0; s < nstage; ++s) step(std::integral_constant<int, -1>{});        // first tile: nothing to drain
+    for (int ti = 1; ti < ntile; ++ti) {
+        // hand the finished tile to the second register set; its epilogue rides in this tile's first four steps
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                prev[i][j] = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+        pc0 = c0;
+        c0 += 128;
+        yload(0, pc0);
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        for (int s = 4; s < nstage; ++s) step(std::integral_constant<int, -1>{});
+    }
+    pm_epilogue<T, 2, 2, false>(p, acc, c0, r0, wm, wn, l31, kh);     // the last tile's epilogue: the only exposed one
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Attentive pooling with the score GEMM fused in (Att_pooling.forward up to the pooled tensor, RandLANet.py:243-248):
 //     S[(n,k), :] = [ F[nei[n,k], :] | G[(n,k), :] ]           feature set: gathered point rows | per-pair rows
 //     A = S * W_fc^T                                           scores, never written
@@ -1004,6 +1263,49 @@ bool launch_lds(PmParams& p, hipStream_t st)
     return true;
 }
 
+template <bool TWO>
+bool launch_seq(PmParams& p, int plan, hipStream_t st)
+{
+    p.n_ct = (int)ceil_div(p.cout, 128);
+    p.n_pt = (int)ceil_div(p.rows, 128);
+    // plan: bits 0-3 tiles per workgroup in region A, 4-7 in region B, 8-15 tiles of region B / 16, 16-22 tiles of region C / 16
+    p.tpg = std::max(1, std::min(plan & 15, std::min(p.n_ct, 8)));
+    p.tpg_b = std::max(1, std::min((plan >> 4) & 15, p.tpg));
+    const int64_t tiles_b = (int64_t)((plan >> 8) & 255) * 16, tiles_c = (int64_t)((plan >> 16) & 127) * 16;
+    // regions are whole multiples of 8 point tiles (one per XCD), taken from the end of the point-tile range
+    const int pts_c = (int)std::min<int64_t>(p.n_pt, ceil_div(ceil_div(tiles_c, p.n_ct), 8) * 8);
+    const int pts_b = (int)std::min<int64_t>(p.n_pt - pts_c, ceil_div(ceil_div(tiles_b, p.n_ct), 8) * 8);
+    p.pt_c = p.n_pt - pts_c;
+    p.pt_b = p.pt_c - pts_b;
+    if (p.pt_b % 8) p.pt_b -= p.pt_b % 8;                                   // region A ends on a multiple of 8 (B takes the rest)
+    if (p.pt_c % 8 && p.pt_c > p.pt_b) p.pt_c -= p.pt_c % 8;                // so does B
+    if (p.pt_c < p.pt_b) p.pt_c = p.pt_b;
+    const int64_t grp_a = ceil_div(p.n_ct, p.tpg), grp_b = ceil_div(p.n_ct, p.tpg_b);
+    p.wg_b = (int)(p.pt_b / 8 * grp_a * 8);
+    p.wg_c = p.wg_b + (int)((p.pt_c - p.pt_b) / 8 * grp_b * 8);
+    const int64_t grid = p.wg_c + ceil_div(p.n_pt - p.pt_c, 8) * p.n_ct * 8;
+    const size_t lds = 2 * 2 * 128 * (128 + 16) + (size_t)p.tpg * 128 * sizeof(float);
+    static int attr_set[kMaxDevices];                                      // per device (common.h: device_slot)
+    int& done = attr_set[device_slot()];
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pm_seq_kernel<TWO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * 2 * 128 * (128 + 16) + 8 * 128 * (int)sizeof(float)) != hipSuccess)
+            return false;
+        done = 1;
+    }
+    hipLaunchKernelGGL((mlp_pm_seq_kernel<TWO>), dim3((unsigned)grid), dim3(BLK), lds, st, p);
+    return true;
+}
+
+// what the tile-sequence form needs beyond the LDS-tiled form's conditions: fp32, >= 4 steps per tile, the vector epilogue
+// (whole 16-byte channel groups), rows of Y and of the output inside the 2 GiB range of a buffer descriptor
+inline bool seq_form_ok(const PmParams& p, int64_t K, int64_t y_rows)
+{
+    return p.act != 3 && (K * 4) % 128 == 0 && (p.k1 * 4) % 128 == 0 && K * 4 / 128 >= 4 && (p.cout & 3) == 0 && (p.ldo & 3) == 0 &&
+           (!p.y || (p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.y)) & 15) == 0 &&
+           ((int64_t)p.rows + 256) * p.ldo * 4 < (1LL << 31) && (!p.y || (y_rows + 256) * p.ldy * 4 < (1LL << 31));
+}
+
 template <typename T, int TM, int NS, bool LSM, bool TWO, bool HASY = false>
 void launch_stream(PmParams& p, hipStream_t st)
 {
@@ -1089,11 +1391,18 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
     p.px = (int)x1_rows_per_frame; p.act = act;
     p.idx64 = idx_bits == 64;
     hipStream_t st = as_stream(stream);
-    int choice = tile_hint;
-    if (choice <= 0) {
+    int choice = tile_hint & 255, tpg = tile_hint >> 8;
+    if (tile_hint <= 0) {
         choice = ffb6d_mlp_pm_choice(rows, cout, k1, k2, act, SZ == 2, x1_idx != nullptr);
+        tpg = choice >> 8;
+        choice &= 255;
         if (choice == 6 && !stream_form_ok<T>(p, K)) choice = ffb6d_mlp_pm_tile(rows, cout, K, act);      // misaligned rows
+        if (choice == 8) {
+            const int64_t y_rows = y ? (y_idx ? rows / rows_per_frame * y_rows_per_frame : rows) : 0;
+            if (SZ != 4 || !seq_form_ok(p, K, y_rows)) choice = 7;                                        // misaligned rows / huge buffers
+        }
     }
+    if (choice == 8 && tpg <= 0) tpg = ffb6d_mlp_pm_seq_plan(rows, cout);
     switch (choice) {
         case 1: launch_pm<T, 2, 2, 2, 2, false>(p, st); break;      // 128 ch x 128 pt
         case 2: launch_pm<T, 2, 2, 1, 4, false>(p, st); break;      // 64 ch x 256 pt
@@ -1138,6 +1447,18 @@ int mlp_pm_impl(const void* w, const float* bias, const void* x1, int64_t k1, in
                           "mlp_pm: the LDS-tiled form has no log_softmax epilogue and needs k1 * %d and K * %d to be multiples of 128", SZ, SZ);
             if (!launch_lds<T>(p, st)) return set_error(FFB6D_ERR_HIP, "mlp_pm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
             break;
+        case 8: {                                                   // tile-sequence form (fp32): tile_hint = 8 + 256 * tiles per workgroup
+            if constexpr (SZ == 4) {
+                const int64_t y_rows = y ? (y_idx ? rows / rows_per_frame * y_rows_per_frame : rows) : 0;
+                FFB6D_REQUIRE(seq_form_ok(p, K, y_rows), "mlp_pm: the tile-sequence form needs fp32 rows of whole 128-byte segments, K >= 128, "
+                              "cout %% 4 == 0, 16-byte aligned output / Y rows and no log_softmax");
+                const bool ok = k2 > 0 ? launch_seq<true>(p, tpg, st) : launch_seq<false>(p, tpg, st);
+                if (!ok) return set_error(FFB6D_ERR_HIP, "mlp_pm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+            } else {
+                return set_error(FFB6D_ERR_ARG, "mlp_pm: the tile-sequence form (tile_hint 8) is fp32 only");
+            }
+            break;
+        }
         default: return set_error(FFB6D_ERR_ARG, "mlp_pm: unknown tile_hint %d", tile_hint);
     }
     FFB6D_LAUNCH_CHECK();
@@ -1209,7 +1530,33 @@ extern "C" int ffb6d_mlp_pm_choice(int64_t rows, int64_t cout, int64_t k1, int64
     // profiles/r04_tail_gemm_probe.txt; in bf16 the LDS-tiled form still wins)
     const bool lds = act != 3 && row_bytes % 128 == 0 && (k1 * (bf16 ? 2 : 4)) % 128 == 0 &&
                      ceil_div(rows, 128) * ceil_div(cout, 128) >= 256 && (bf16 || cout > 64);
-    return lds ? 7 : ffb6d_mlp_pm_tile(rows, cout, K, act);
+    if (!lds) return ffb6d_mlp_pm_tile(rows, cout, K, act);
+    // tile-sequence form (fp32, >= 4 steps of 128 bytes per tile, at least two channel tiles to put in a sequence): 8 + 256 * tiles per workgroup
+    const int plan = ffb6d_mlp_pm_seq_plan(rows, cout);
+    if (!bf16 && row_bytes >= 512 && (cout & 3) == 0 && (plan & 15) >= 2) return 8 + 256 * plan;
+    return 7;
+}
+
+// Schedule of the tile-sequence form (see launch_seq for the bit fields): sequence length T of region A, T / 2 in region B, single tiles in
+// region C -- the workgroups the dispatcher hands out last are short, so the 512 slots of the chip drain together.
+extern "C" int ffb6d_mlp_pm_seq_plan(int64_t rows, int64_t cout)
+{
+    // Measured on the long-row launches of the bench step (profiles/r05_seq_gemm_sweep.txt; sweep over T, the regions' sizes):
+    //   * T ~ half the number of rounds the tiles make over the chip's 512 workgroup slots, at least 2, at most the channel tiles, nudged
+    //     to a divisor of the channel-tile count (a ragged last group is a short workgroup in the MIDDLE of the dispatch order);
+    //   * from T = 4 on, ~512 tiles in sequences of 2 before the tail; ~512 single tiles as the tail once a point tile has >= 4 channel
+    //     tiles (with 2-3 channel tiles per point tile the tail of single tiles measured slower than none).
+    const int64_t n_pt = ceil_div(rows, 128), n_ct = ceil_div(cout, 128), tiles = n_pt * n_ct;
+    if (n_ct < 2 || tiles < 1024) return 1;
+    const int64_t cap = std::min<int64_t>(n_ct, 8);
+    int64_t ta = std::min<int64_t>(cap, std::max<int64_t>(2, tiles / 1024));
+    if (n_ct % ta != 0) {
+        if (ta + 1 <= cap && n_ct % (ta + 1) == 0) ta += 1;
+        else if (ta > 2 && n_ct % (ta - 1) == 0) ta -= 1;
+    }
+    const int64_t tb = ta >= 4 ? 2 : 1;
+    const int64_t b_tiles = tb > 1 ? 512 : 0, c_tiles = n_ct >= 4 ? 512 : 0;
+    return (int)(ta | tb << 4 | (b_tiles / 16) << 8 | (c_tiles / 16) << 16);
 }
 
 #define FFB6D_MLP_PM_ARGS                                                                                                    \

@@ -144,6 +144,10 @@ HEADS_ON_BOTH_STREAMS = True
 # ... and the three layers after the first of each head (128 -> 128 -> 128 -> c) as one launch with the hidden activations in
 # registers (csrc/mlp_chain.hip; fp32 only)
 HEADS_CHAIN_FUSED = True
+# The long-row fp32 GEMMs (p2r fusion, PSP bottleneck, z GEMMs, the heads' stacked first layer) in the tile-sequence form
+# (csrc/mlp_pm.hip: mlp_pm_seq_kernel -- a finished tile's epilogue rides between the MFMAs of the next tile of the same workgroup);
+# False: the LDS-tiled form (one tile per workgroup) for those launches.  Equal bits.
+GEMM_SEQ_FORM = True
 LFA_WIDTHS = (32, 64, 128, 256)
 
 
@@ -444,6 +448,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
     `rgb_emb_up{i}`, `p_emb_up{i}`), converted to the reference layout -- diagnostics / stage-level parity tests."""
     dev = inputs['rgb'].device
     dt = torch.bfloat16 if getattr(net, "precision", "fp32") == "bf16" else torch.float32
+    ops_pm.MLP_SEQ_FORM = GEMM_SEQ_FORM
     main = torch.cuda.current_stream(dev)
     side = net._side_stream(dev) if two_streams else main
     if two_streams:

@@ -28,6 +28,9 @@ def rows_view(x):
 
 
 ACT_LOG_SOFTMAX = 3
+# the tile-sequence form of the long-row fp32 GEMMs (csrc/mlp_pm.hip: mlp_pm_seq_kernel, round 5); False = the LDS-tiled form everywhere
+# (bit-identical results; forward_pm.GEMM_SEQ_FORM sets it per forward for in-process A/B)
+MLP_SEQ_FORM = True
 
 
 def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gather=None, out=None, tile_hint=0, role="path"):
@@ -97,8 +100,11 @@ def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gathe
         raise ValueError("out must be row-regular (a channel slice of a contiguous row buffer is fine)")
     nbytes = esz * ((K1 + K2) * Cout + rows * (K1 + K2) + rows * Cout) + rows * (bits // 8) * ((gi is not None) + (xi is not None)) + \
         (esz * (y.shape[0] if gi is None else rows) * Cout if y is not None else 0)
-    if _lib.TRACER is not None:      # tag = the kernel instantiation a profile lists this launch under
-        tile = int(tile_hint) if tile_hint > 0 else lib.ffb6d_mlp_pm_choice(rows, Cout, K1, K2, int(act), int(dt), int(xi is not None))
+    if tile_hint == 0 and not MLP_SEQ_FORM and not dt and \
+            (lib.ffb6d_mlp_pm_choice(rows, Cout, K1, K2, int(act), 0, int(xi is not None)) & 255) == 8:
+        tile_hint = 7                # A/B: the LDS-tiled form where the automatic choice is the tile-sequence form
+    if _lib.TRACER is not None:      # tag = the kernel instantiation a profile lists this launch under (8 = the tile-sequence form, any plan)
+        tile = (int(tile_hint) if tile_hint > 0 else lib.ffb6d_mlp_pm_choice(rows, Cout, K1, K2, int(act), int(dt), int(xi is not None))) & 255
     else:
         tile = 0
     with torch.cuda.device(x1.device), _lib.traced("mlp_pm", nbytes, (K1 + K2, Cout, rows, tile, dt, role)):

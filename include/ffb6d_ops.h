@@ -140,6 +140,13 @@ int ffb6d_mlp_pm_tile(int64_t rows, int64_t cout, int64_t K, int act);
  * (mlp_pm_lds_kernel: 128 x 128 tiles, 128-byte row segments staged through LDS) for the big long-row layers, else
  * ffb6d_mlp_pm_tile's tile.  All forms give identical results. */
 int ffb6d_mlp_pm_choice(int64_t rows, int64_t cout, int64_t k1, int64_t k2, int act, int bf16, int x1_gathered);
+/* 8 + 256 * T (round 5, fp32): the tile-SEQUENCE form of the LDS-tiled kernel (mlp_pm_seq_kernel) -- a workgroup multiplies T
+ * consecutive channel tiles of one point tile and the epilogue of each finished tile (second accumulator set) rides between the
+ * MFMAs of the next one; ffb6d_mlp_pm_choice returns it for the long-row fp32 layers with at least two channel tiles per sequence,
+ * tile_hint = 8 + 256 * plan selects it explicitly (plan 0: ffb6d_mlp_pm_seq_plan).  plan: bits 0-3 = T of the first region of point
+ * tiles, bits 4-7 = T of the second region, bits 8-15 / 16-22 = tiles (in units of 16) of the second region / of the last region, whose
+ * workgroups take one tile each -- a guided schedule: the workgroups handed out last are short.  Identical results. */
+int ffb6d_mlp_pm_seq_plan(int64_t rows, int64_t cout);
 
 /* Att_pooling.forward up to the pooled tensor (RandLANet.py:243-248) with the neighbour gather fused in:
  * S[(n,k),:] = [ f[nei[n,k],:] | g[(n,k),:] ], out[n,m] = sum_k S[(n,k),m] * softmax_k((S w_fc^T)[(n,k),m]).

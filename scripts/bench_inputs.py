@@ -1,0 +1,50 @@
+"""Timing of the on-device input pipeline on the GPU box: depth -> cloud, valid-pixel sampling + shuffle, input assembly
+(inputs.assemble_inputs without / with the index pyramid), HIP events.   python scripts/bench_inputs.py [--batch 8]"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ffb6d_amd import inputs, synth, _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--n-points", type=int, default=12288)
+ap.add_argument("--iters", type=int, default=20)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+fr = synth.make_batch(2, a.batch, n_points=a.n_points)
+H, W = fr["dpt_xyz"].shape[-2:]
+depth = torch.from_numpy(np.ascontiguousarray(fr["dpt_xyz"][:, 2])).to(dev)          # metres, zeros where invalid
+rgb = torch.from_numpy(fr["rgb"]).to(dev)
+nrm = torch.randn(a.batch, 3, H, W, device=dev)
+K = synth.LINEMOD_K
+
+
+def timed(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / a.iters
+
+
+out = {"batch": a.batch, "n_points": a.n_points, "frame": [H, W]}
+xyz = inputs.depth_to_cloud(depth, K)
+out["depth_to_cloud_us"] = timed(lambda: inputs.depth_to_cloud(depth, K))
+out["sample_points_us"] = timed(lambda: inputs.sample_points(depth, a.n_points, xyz, rgb, nrm, seed=7))
+out["assemble_inputs_us"] = timed(lambda: inputs.assemble_inputs(rgb, depth, nrm, K, a.n_points, seed=7))
+# algorithmic bytes: depth in, xyz out (depth_to_cloud); depth + xyz + rgb + normals read at the N picked pixels, [B,9,N] + choose + cld written
+b_d2c = a.batch * H * W * 4 * (1 + 3)
+out["depth_to_cloud_GBps"] = b_d2c / out["depth_to_cloud_us"] / 1e3
+tr = _lib.Tracer()
+_lib.TRACER = tr
+for _ in range(5):
+    inputs.assemble_inputs(rgb, depth, nrm, K, a.n_points, seed=7)
+torch.cuda.synchronize()
+_lib.TRACER = None
+out["kernels_us_per_call"] = {k: v["total_ms"] * 1e3 / 5 for k, v in tr.summary().items()}
+print(json.dumps(out))

@@ -42,6 +42,15 @@ CASES += [(1, 300, 96, 0, 40, 0, 0, 7), (2, 140, 32, 32, 72, 2, 50, 7), (1, 257,
 CASES += [(8, 48, 1024, 0, 64, 1, 0, 5), (1, 33, 8, 8, 5, 1, 0, 0), (1, 1, 8, 0, 8, 0, 0, 0), (2, 64, 128, 0, 22, 0, 0, 0)]      # K split, tiny, automatic choice
 
 
+# tile-sequence form (hint 8 + 256 * tiles per workgroup): 2 / 3 / 5 tiles in a sequence, ragged last group, ragged rows and channels,
+# exactly four steps per tile (K = 128) and more, two sources, gathered / added / no epilogue rows, every activation
+SEQ = lambda t: 8 + 256 * t                                                             # noqa: E731
+CASES += [(1, 300, 128, 0, 200, 1, 0, SEQ(2)), (2, 140, 64, 64, 384, 2, 50, SEQ(3)), (1, 257, 160, 0, 520, 1, -1, SEQ(2)),
+          (1, 130, 256, 0, 520, 0, 33, SEQ(3)), (3, 70, 128, 32, 600, 1, 0, SEQ(5)), (1, 129, 128, 0, 264, 2, -1, SEQ(8)),
+          # guided schedule: 29 point tiles x 3 channel tiles = regions of 8 (T = 3), 8 (T = 2) and 13 point tiles (single tiles)
+          (1, 3650, 128, 0, 300, 1, 17, SEQ(3 | 2 << 4 | 1 << 8 | 1 << 16))]
+
+
 @pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", CASES)
 def test_mlp_pm_fp32_on_the_emulator_matches_fp64(emu, B, P, K1, K2, Cout, act, py, hint):
     g = torch.Generator().manual_seed(K1 + Cout + P)
@@ -118,6 +127,18 @@ def test_kernel_forms_are_bit_identical_on_the_emulator(emu):
     outs = [ops_pm.mlp(x, w, bias, 1, tile_hint=h) for h in (1, 2, 4, 6, 7)]
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+    # the tile-sequence form (round 5): deferred epilogue pieces, same sums -- with gathered rows, without a bias, identity activation
+    # (negative zeros must survive the additions of "nothing")
+    x = torch.randn(2, 150, 160, generator=g)
+    w = torch.randn(392, 160, generator=g) / 12
+    bias = torch.randn(392, generator=g)
+    Y, idx = torch.randn(2, 40, 392, generator=g), torch.randint(0, 40, (2, 150), generator=g)
+    for kw in ({"gather": (Y, idx)}, {"add": Y[:, idx[0]]}, {}):
+        for b, act in ((bias, 2), (None, 0)):
+            want = ops_pm.mlp(x, w, b, act, tile_hint=7, **kw)
+            for t in (2, 3, 4):
+                got = ops_pm.mlp(x, w, b, act, tile_hint=8 + 256 * t, **kw)
+                assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (list(kw), act, t)
 
 
 @pytest.mark.parametrize("hint", [1, 2, 5, 6, 7])
