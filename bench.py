@@ -216,7 +216,8 @@ def main():
     miopen_db = "MIOpen's own search (fresh user find-db)"
     if args.miopen_db == "pinned":
         from ffb6d_amd import miopen_pin
-        miopen_db = miopen_pin.use(rank=local_rank)          # before the first convolution: a private copy per process
+        # before the first convolution: a private copy per process; the fp32 forward-only run also pins the solver
+        miopen_db = miopen_pin.use(rank=local_rank, only_solver=miopen_pin.FWD_SOLVER if (args.mode == "infer" and args.precision == "fp32") else None)
     if world_env > 1:
         # one MIOpen find-db / kernel cache per rank: N ranks tuning the same convolutions at the same
         # time would otherwise contend for the lock of one sqlite user database

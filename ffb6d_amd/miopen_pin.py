@@ -17,8 +17,16 @@ PIN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_pin")
 TAG = "r05 search on MI355X (gfx950, 256 CUs), MIOpen 3.5.0: fp32 NHWC forward problems of the bs = 8, 480 x 640 colour branch"
 
 
-def use(rank=0):
-    """Call before the first convolution of the process.  Returns a short description for bench records."""
+FWD_SOLVER = "ConvAsmImplicitGemmGTCDynamicFwdXdlopsNHWC"
+
+
+def use(rank=0, only_solver=None):
+    """Call before the first convolution of the process.  Returns a short description for bench records.
+    only_solver: restrict MIOpen's search to one solver (MIOPEN_DEBUG_FIND_ONLY_SOLVER) -- forward-only processes; a fresh machine has no
+    compiled kernels in its cache, so MIOpen discards the pinned find-db records and searches again: the ranking between near-tied
+    solvers is then redrawn, while the pinned perf-db still fixes each solver's kernel variant."""
+    if only_solver and not os.environ.get("MIOPEN_DEBUG_FIND_ONLY_SOLVER"):
+        os.environ["MIOPEN_DEBUG_FIND_ONLY_SOLVER"] = only_solver
     if os.environ.get("MIOPEN_USER_DB_PATH"):
         return "MIOPEN_USER_DB_PATH set by the caller: " + os.environ["MIOPEN_USER_DB_PATH"]
     dst = os.path.join(tempfile.gettempdir(), f"ffb6d_miopen_pin_{os.getpid()}_{rank}")
@@ -29,4 +37,4 @@ def use(rank=0):
             shutil.copy(os.path.join(PIN_DIR, f), os.path.join(dst, f))
             n += 1
     os.environ["MIOPEN_USER_DB_PATH"] = dst
-    return f"pinned user find-db ({n} files of ffb6d_amd/miopen_pin: {TAG})"
+    return f"pinned user find-db / perf-db ({n} files of ffb6d_amd/miopen_pin: {TAG})" + (f", solver {only_solver} only" if only_solver else "")
