@@ -23,14 +23,20 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Kernel attributes (dynamic LDS limit) and occupancy answers belong to a DEVICE: a process that drives several GPUs must set /
 // query them once per device, not once per process.  Slot of the calling thread's current device in a per-call-site cache
-// (`static int cache[kMaxDevices]`, 0 = not initialised yet; racing initialisers write the same value).
+// (`static int cache[kMaxDevices + 1]`, 0 = not initialised yet; racing initialisers write the same value).  A device the cache has no
+// slot for (ordinal >= kMaxDevices, or hipGetDevice failing) gets the slot kNoDeviceSlot, which call sites NEVER mark as initialised:
+// they then set the attribute / ask the occupancy on every call instead of borrowing device 0's answer.
 constexpr int kMaxDevices = 64;
+constexpr int kNoDeviceSlot = kMaxDevices;
 inline int device_slot()
 {
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return kNoDeviceSlot;
     return d;
 }
+// caches at the call sites: `static int flag[kMaxDevices + 1]`; cache_get / cache_set leave the overflow slot alone
+inline int cache_get(const int* cache, int slot) { return slot == kNoDeviceSlot ? 0 : __atomic_load_n(&cache[slot], __ATOMIC_RELAXED); }
+inline void cache_set(int* cache, int slot, int v) { if (slot != kNoDeviceSlot) __atomic_store_n(&cache[slot], v, __ATOMIC_RELAXED); }
 
 }  // namespace ffb6d
 

@@ -435,8 +435,11 @@ extern "C" int ffb6d_knn_search_multi(int n, const ffb6d_knn_search_t* s, int64_
             FFB6D_REQUIRE(s[i].support && s[i].query, "knn_search_multi: search %d runs the scan kernel and needs the raw arrays", i);
         }
     }
-    int rc = knn_search_multi_prepared(s, pruned, np, B, st);
-    if (rc != FFB6D_OK) return rc;
+    // (Round 5 measured the four kernels of a batch on library-owned side streams, forked from and joined into the caller's stream: the
+    // K = 16 scans of a pyramid are 32 workgroups, 91 us with 224 CUs idle.  Alone the pyramid went from 923 to 901 us -- the two big
+    // kernels share the chip either way -- and the bench step from 20.4 to 28.1 ms: six streams on the runtime's four hardware queues
+    // put the colour branch and the point branch behind one another.  No hidden streams.)
+    int rc = FFB6D_OK;
     const int kps[6] = {1, 2, 4, 8, 16, 32};
     for (int kp : kps) {
         MultiScan m;
@@ -445,19 +448,20 @@ extern "C" int ffb6d_knn_search_multi(int n, const ffb6d_knn_search_t* s, int64_
         auto flush = [&]() -> int {
             if (m.n == 0) return FFB6D_OK;
             int r = FFB6D_OK;
+            hipStream_t ls = st;
             switch (kp) {
-                case 1: r = launch_scan_multi<1>(m, blocks, st); break;
-                case 2: r = launch_scan_multi<2>(m, blocks, st); break;
-                case 4: r = launch_scan_multi<4>(m, blocks, st); break;
-                case 8: r = launch_scan_multi<8>(m, blocks, st); break;
-                case 16: r = launch_scan_multi<16>(m, blocks, st); break;
-                default: r = launch_scan_multi<32>(m, blocks, st); break;
+                case 1: r = launch_scan_multi<1>(m, blocks, ls); break;
+                case 2: r = launch_scan_multi<2>(m, blocks, ls); break;
+                case 4: r = launch_scan_multi<4>(m, blocks, ls); break;
+                case 8: r = launch_scan_multi<8>(m, blocks, ls); break;
+                case 16: r = launch_scan_multi<16>(m, blocks, ls); break;
+                default: r = launch_scan_multi<32>(m, blocks, ls); break;
             }
             m.n = 0;
             blocks = 0;
             return r;
         };
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < n && rc == FFB6D_OK; ++i) {
             if (ffb6d_knn_uses_pruning(B, s[i].S, s[i].Q, s[i].K) || pad_k(s[i].K) != kp) continue;
             ScanArgs& a = m.a[m.n];
             a.support = s[i].support; a.query = s[i].query; a.idx64 = s[i].idx64; a.idx32 = s[i].idx32; a.dist = s[i].dist;
@@ -465,11 +469,13 @@ extern "C" int ffb6d_knn_search_multi(int n, const ffb6d_knn_search_t* s, int64_
             a.gx = (int)ceil_div(s[i].Q, (int64_t)KNN_BLOCK * qpt_for(kp));
             a.blk0 = blocks;
             blocks += a.gx * (int)B;
-            if (++m.n == MAX_SCANS && (rc = flush()) != FFB6D_OK) return rc;
+            if (++m.n == MAX_SCANS) rc = flush();
         }
-        if ((rc = flush()) != FFB6D_OK) return rc;
+        if (rc == FFB6D_OK) rc = flush();
+        if (rc != FFB6D_OK) break;
     }
-    return FFB6D_OK;
+    if (rc == FFB6D_OK) rc = knn_search_multi_prepared(s, pruned, np, B, st);
+    return rc;
 }
 
 extern "C" {

@@ -24,7 +24,9 @@
 // visiting order cannot change which neighbour wins a tie.
 #include "common.h"
 
-#include <rocprim/rocprim.hpp>
+#include <rocprim/rocprim.hpp>      // 64-bit sort keys only (more than 256 (set, frame) segments in one call)
+
+#include "seg_sort.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -103,13 +105,23 @@ __device__ __forceinline__ void frame_body(const float* __restrict__ pts, int S,
     __shared__ float red[6][16];
     const float* p = pts + (size_t)b * S * 3;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = threadIdx.x; i < S; i += 1024) {
+    // four points per thread and trip, their twelve loads issued together: one block walks a whole frame (76 800 points for the
+    // stride-2 image grid) and a trip is one memory round trip -- 27.6 us per call with one point per trip (profiles/r05_knn_pmc.txt)
+    for (int i0 = threadIdx.x; i0 < S; i0 += 4 * 1024) {
+        float v[4][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v = p[(size_t)i * 3 + c];
-            lo[c] = fminf(lo[c], v);
-            hi[c] = fmaxf(hi[c], v);
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * 1024, S - 1);         // past the end: the last point again
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[u][c] = p[(size_t)i * 3 + c];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                lo[c] = fminf(lo[c], v[u][c]);
+                hi[c] = fmaxf(hi[c], v[u][c]);
+            }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -807,24 +819,38 @@ int pad_k(int K)
     return p;
 }
 
-size_t sort_temp_bound(size_t n)
+size_t sort_temp_bound(size_t n, size_t sort_blocks)
 {
-    // rocPRIM onesweep radix sort: two alternate key/value buffers + histograms/look-back state
-    return n * (sizeof(unsigned long long) + sizeof(uint32_t)) + (size_t)(4u << 20);
+    // the hand-written segmented sort (csrc/seg_sort.hip): one 256-bin histogram per workgroup; rocPRIM (64-bit keys only): two
+    // alternate key/value buffers + histograms/look-back state
+    return std::max(n * (sizeof(unsigned long long) + sizeof(uint32_t)) + (size_t)(4u << 20), sort_blocks * 256 * sizeof(uint32_t));
 }
 
 struct PrepWs {
     size_t keys_in, keys_out, vals_in, vals_out, bbox, temp, temp_bytes, total;
 };
 
-PrepWs prep_ws_n(size_t n);
-PrepWs prep_ws(int64_t B, int64_t S) { return prep_ws_n((size_t)B * S); }
+PrepWs prep_ws_n(size_t n, size_t sort_blocks);
+PrepWs prep_ws(int64_t B, int64_t S) { return prep_ws_n((size_t)B * S, (size_t)B * (size_t)ceil_div(S, segsort::CHUNK)); }
 
-// one stable sort of all (segment, truncated Morton key) pairs: `segments` = number of (set, frame) segments in the key's high bits
+// One stable sort of all (segment, truncated Morton key) pairs; `plan` = the (set, frame) segments as ranges of the key array.
+// 32-bit keys: the segmented radix sort of csrc/seg_sort.hip on the SORT_BITS key bits (segments never mix: the segment number in the
+// key's high bits is carried along, not sorted on) -- 6 launches; round 4 called rocprim::radix_sort_pairs here, which ran its merge
+// sort for these sizes: 20 launches, 0.13 ms alone, 0.40 ms inside the bench step.  64-bit keys (more than 256 segments): rocPRIM.
 constexpr int64_t MAX_SEG32 = 1LL << (32 - SORT_BITS);
-template <typename KeyT>
-int sort_segments(KeyT* keys_in, KeyT* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int64_t segments, void* temp,
-                  size_t temp_bytes, hipStream_t st, const char* who)
+int sort_segments(uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t, int64_t, segsort::Plan& plan,
+                  void* temp, size_t temp_bytes, hipStream_t st, const char* who)
+{
+    bool in_alt = false;
+    const hipError_t e = segsort::sort_pairs(plan, keys_in, vals_in, keys_out, vals_out, SORT_BITS, temp, temp_bytes, st, &in_alt);
+    if (e != hipSuccess) return set_error(e == hipErrorInvalidValue ? FFB6D_ERR_WORKSPACE : FFB6D_ERR_HIP, "%s: segmented sort failed: %s", who,
+                                          hipGetErrorString(e));
+    static_assert((SORT_BITS + 7) / 8 % 2 == 1, "an odd number of passes leaves the result in keys_out / vals_out");
+    return in_alt ? FFB6D_OK : set_error(FFB6D_ERR_HIP, "%s: segmented sort left its result in the wrong buffer", who);
+}
+
+int sort_segments(unsigned long long* keys_in, unsigned long long* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int64_t segments,
+                  segsort::Plan&, void* temp, size_t temp_bytes, hipStream_t st, const char* who)
 {
     unsigned end_bit = SORT_BITS;
     while ((1LL << (end_bit - SORT_BITS)) < segments) ++end_bit;
@@ -836,7 +862,7 @@ int sort_segments(KeyT* keys_in, KeyT* keys_out, uint32_t* vals_in, uint32_t* va
     return FFB6D_OK;
 }
 
-PrepWs prep_ws_n(size_t n)
+PrepWs prep_ws_n(size_t n, size_t sort_blocks)
 {
     PrepWs w;
     size_t o = 0;
@@ -846,7 +872,7 @@ PrepWs prep_ws_n(size_t n)
     w.vals_in = take(n * 4);
     w.vals_out = take(n * 4);
     w.bbox = take(4096);                       /* unused (frames live in the prepared blob) */
-    w.temp_bytes = sort_temp_bound(n);
+    w.temp_bytes = sort_temp_bound(n, sort_blocks);
     w.temp = take(w.temp_bytes);
     w.total = o;
     return w;
@@ -898,7 +924,9 @@ int ffb6d_knn_prepare(const float* pts, int64_t B, int64_t S, void* prepared, si
         hipLaunchKernelGGL((morton_kernel<KeyT>), dim3((unsigned)ceil_div(S, BLK), (unsigned)B), dim3(BLK), 0, st, pts, (int)S, frame, kin,
                            vals_in);
         FFB6D_LAUNCH_CHECK();
-        if (const int rc = sort_segments<KeyT>(kin, kout, vals_in, vals_out, n, B, ws + W.temp, W.temp_bytes, st, "knn_prepare")) return rc;
+        segsort::Plan plan;
+        plan.ngroups = 1; plan.B = (int)B; plan.g[0].pos0 = 0; plan.g[0].S = (int)S;
+        if (const int rc = sort_segments(kin, kout, vals_in, vals_out, n, B, plan, ws + W.temp, W.temp_bytes, st, "knn_prepare")) return rc;
         hipLaunchKernelGGL((gather_box_kernel<KeyT>), dim3((unsigned)ceil_div(L.nt, BLK / 64), (unsigned)B), dim3(BLK), 0, st, pts,
                            (int)S, (int)L.S_pad, (int)L.nt, kout, vals_out, reinterpret_cast<float4*>(pp + L.pts_off),
                            reinterpret_cast<float4*>(pp + L.box_off), reinterpret_cast<uint32_t*>(pp + L.key_off));
@@ -919,9 +947,13 @@ int ffb6d_knn_prepare(const float* pts, int64_t B, int64_t S, void* prepared, si
 size_t ffb6d_knn_prepare_multi_workspace_bytes(int nsets, const int64_t* npts, int64_t B)
 {
     if (nsets <= 0 || !npts || B <= 0) return 0;
-    size_t n = 0;
-    for (int i = 0; i < nsets; ++i) n += (size_t)B * (size_t)(npts[i] > 0 ? npts[i] : 0);
-    return prep_ws_n(n).total;
+    size_t n = 0, blocks = 0;
+    for (int i = 0; i < nsets; ++i) {
+        const size_t s = (size_t)(npts[i] > 0 ? npts[i] : 0);
+        n += (size_t)B * s;
+        blocks += (size_t)B * (size_t)ceil_div((int64_t)s, segsort::CHUNK);
+    }
+    return prep_ws_n(n, blocks).total;
 }
 
 int ffb6d_knn_prepare_multi(int nsets, const float* const* pts, const int64_t* npts, int64_t B, void* const* prepared,
@@ -953,7 +985,14 @@ int ffb6d_knn_prepare_multi(int nsets, const float* const* pts, const int64_t* n
         n += (size_t)B * (size_t)npts[i];
         S_max = std::max<int64_t>(S_max, npts[i]); nt_max = std::max<int64_t>(nt_max, L.nt); nt2_max = std::max<int64_t>(nt2_max, L.nt2);
     }
-    const PrepWs W = prep_ws_n(n);
+    segsort::Plan plan;
+    plan.ngroups = nsets; plan.B = (int)B;
+    size_t sort_blocks = 0;
+    for (int i = 0; i < nsets; ++i) {
+        plan.g[i].pos0 = m.s[i].pos0; plan.g[i].S = m.s[i].S;
+        sort_blocks += (size_t)B * (size_t)ceil_div(npts[i], segsort::CHUNK);
+    }
+    const PrepWs W = prep_ws_n(n, sort_blocks);
     if (workspace_bytes < W.total)
         return set_error(FFB6D_ERR_WORKSPACE, "knn_prepare_multi: need %zu workspace bytes, got %zu", W.total, workspace_bytes);
     hipStream_t st = as_stream(stream);
@@ -968,7 +1007,7 @@ int ffb6d_knn_prepare_multi(int nsets, const float* const* pts, const int64_t* n
         using KeyT = std::remove_pointer_t<decltype(kin)>;
         hipLaunchKernelGGL((morton_multi_kernel<KeyT>), dim3((unsigned)ceil_div(S_max, BLK), nb, ns), dim3(BLK), 0, st, m, kin, vals_in);
         FFB6D_LAUNCH_CHECK();
-        if (const int rc = sort_segments<KeyT>(kin, kout, vals_in, vals_out, n, B * nsets, ws + W.temp, W.temp_bytes, st, "knn_prepare_multi"))
+        if (const int rc = sort_segments(kin, kout, vals_in, vals_out, n, B * nsets, plan, ws + W.temp, W.temp_bytes, st, "knn_prepare_multi"))
             return rc;
         hipLaunchKernelGGL((gather_box_multi_kernel<KeyT>), dim3((unsigned)ceil_div(nt_max, BLK / 64), nb, ns), dim3(BLK), 0, st, m, kout,
                            vals_out);

@@ -533,14 +533,16 @@ void launch_lfa(LfaParams& p, hipStream_t st, int wg_cap)
     p.n_grp = (int)ceil_div(p.npts, P);
     const void* fn = reinterpret_cast<const void*>(&lfa_pm_kernel<T, D, MODE, P, WLDS, NW>);
     // persistent workgroups: as many as are resident at once (registers + LDS), each walks its share of the point groups
-    static int per_cu_of[kMaxDevices];                                     // per device (common.h: device_slot)
-    int& per_cu = per_cu_of[device_slot()];
+    static int per_cu_of[kMaxDevices + 1];                                     // per device (common.h: device_slot)
+    const int slot = device_slot();
+    int per_cu = cache_get(per_cu_of, slot);
     if (per_cu == 0) {
         int n = 0;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64 * NW, G::LDS) != hipSuccess || n < 1)
             n = 1;
         per_cu = n;
+        cache_set(per_cu_of, slot, n);
     }
     const int64_t per_xcd = ceil_div(p.n_grp, 8);                          // groups of one XCD
     // wg_cap (p_hint bits 8..15): cap on the workgroups per XCD (the tests use 1 to make every workgroup walk several groups)

@@ -190,13 +190,13 @@ extern "C" int ffb6d_mlp_chain3_pm_f32(const float* x, int64_t ldx, const float*
     p.s1 = slope_of(act1); p.s2 = slope_of(act2); p.s3 = slope_of(act3);
     p.out = out; p.ldx = (int)ldx; p.ldo = (int)ldo; p.cout3 = (int)cout3; p.rows = (int)rows;
     p.n_tiles = (int)ceil_div(rows, 128);
-    static int attr_set[kMaxDevices];                                      // per device (common.h: device_slot)
-    int& done = attr_set[device_slot()];
-    if (!done) {
+    static int attr_set[kMaxDevices + 1];                                      // per device (common.h: device_slot)
+    const int slot = device_slot();
+    if (!cache_get(attr_set, slot)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)CHAIN_LDS) != hipSuccess)
             return set_error(FFB6D_ERR_HIP, "mlp_chain3_pm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-        done = 1;
+        cache_set(attr_set, slot, 1);
     }
     const unsigned grid = (unsigned)std::min<int64_t>(p.n_tiles, 256);      // 144 KB of LDS: one workgroup per CU
     hipLaunchKernelGGL(mlp_chain3_kernel, dim3(grid), dim3(BLK), CHAIN_LDS, as_stream(stream), p);

@@ -1250,13 +1250,13 @@ bool launch_lds(PmParams& p, hipStream_t st)
     p.n_ct = (int)ceil_div(p.cout, 128);
     p.n_pt = (int)ceil_div(p.rows, 128);
     constexpr size_t lds = 2 * 2 * 128 * (128 + 16);
-    static int attr_set[kMaxDevices];                                      // per device (common.h: device_slot)
-    int& done = attr_set[device_slot()];
-    if (!done) {
+    static int attr_set[kMaxDevices + 1];                                      // per device (common.h: device_slot)
+    const int slot = device_slot();
+    if (!cache_get(attr_set, slot)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pm_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
             return false;
-        done = 1;
+        cache_set(attr_set, slot, 1);
     }
     const unsigned grid = (unsigned)(ceil_div(p.n_pt, 8) * p.n_ct * 8);
     hipLaunchKernelGGL((mlp_pm_lds_kernel<T>), dim3(grid), dim3(BLK), lds, st, p);
@@ -1285,13 +1285,13 @@ bool launch_seq(PmParams& p, int plan, hipStream_t st)
     p.wg_c = p.wg_b + (int)((p.pt_c - p.pt_b) / 8 * grp_b * 8);
     const int64_t grid = p.wg_c + ceil_div(p.n_pt - p.pt_c, 8) * p.n_ct * 8;
     const size_t lds = 2 * 2 * 128 * (128 + 16) + (size_t)p.tpg * 128 * sizeof(float);
-    static int attr_set[kMaxDevices];                                      // per device (common.h: device_slot)
-    int& done = attr_set[device_slot()];
-    if (!done) {
+    static int attr_set[kMaxDevices + 1];                                      // per device (common.h: device_slot)
+    const int slot = device_slot();
+    if (!cache_get(attr_set, slot)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pm_seq_kernel<TWO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * 2 * 128 * (128 + 16) + 8 * 128 * (int)sizeof(float)) != hipSuccess)
             return false;
-        done = 1;
+        cache_set(attr_set, slot, 1);
     }
     hipLaunchKernelGGL((mlp_pm_seq_kernel<TWO>), dim3((unsigned)grid), dim3(BLK), lds, st, p);
     return true;
@@ -1316,14 +1316,16 @@ void launch_stream(PmParams& p, hipStream_t st)
     constexpr size_t lds = 4 * IMG + (size_t)32 * TM * XS + (size_t)32 * TM * 4;                        // + the bias
     const void* fn = reinterpret_cast<const void*>(&mlp_pm_stream_kernel<T, TM, NS, LSM, TWO, HASY>);
     // resident workgroups per CU: registers (the X sets in flight + accumulators) and LDS (four wave images + the W copy)
-    static int per_cu_of[kMaxDevices];                                     // per device (common.h: device_slot)
-    int& per_cu = per_cu_of[device_slot()];
+    static int per_cu_of[kMaxDevices + 1];                                     // per device (common.h: device_slot)
+    const int slot = device_slot();
+    int per_cu = cache_get(per_cu_of, slot);
     if (per_cu == 0) {
         int n = 0;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, BLK, lds) != hipSuccess || n < 1)
             n = 1;
         per_cu = n;
+        cache_set(per_cu_of, slot, n);
     }
     const unsigned grid = (unsigned)std::min<int64_t>(p.n_pt, (int64_t)256 * per_cu);
     hipLaunchKernelGGL((mlp_pm_stream_kernel<T, TM, NS, LSM, TWO, HASY>), dim3(grid), dim3(BLK), lds, st, p);

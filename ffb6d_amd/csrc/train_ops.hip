@@ -160,24 +160,24 @@ bool nearest_interp_bwd_lds(const float* grad_out, const void* idx, int idx_bits
     const size_t lds = (size_t)CG * M * 4;
     const dim3 grid((unsigned)ceil_div(C, CG), (unsigned)B);
     if (idx_bits == 64) {
-        static int attr_set[kMaxDevices];                                  // per device (common.h: device_slot)
-        int& done = attr_set[device_slot()];
-        if (!done) {
+        static int attr_set[kMaxDevices + 1];                                  // per device (common.h: device_slot)
+        const int slot = device_slot();
+        if (!cache_get(attr_set, slot)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nearest_interp_bwd_lds_kernel<int64_t>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10) != hipSuccess)
                 return false;                                                  // the caller falls back to the atomic form
-            done = 1;
+            cache_set(attr_set, slot, 1);
         }
         hipLaunchKernelGGL((nearest_interp_bwd_lds_kernel<int64_t>), grid, dim3(BLK), lds, st, grad_out, static_cast<const int64_t*>(idx),
                            grad_feat, (int)C, (int)M, (int)U, (int)CG);
     } else {
-        static int attr_set[kMaxDevices];                                  // per device (common.h: device_slot)
-        int& done = attr_set[device_slot()];
-        if (!done) {
+        static int attr_set[kMaxDevices + 1];                                  // per device (common.h: device_slot)
+        const int slot = device_slot();
+        if (!cache_get(attr_set, slot)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nearest_interp_bwd_lds_kernel<int32_t>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10) != hipSuccess)
                 return false;                                                  // the caller falls back to the atomic form
-            done = 1;
+            cache_set(attr_set, slot, 1);
         }
         hipLaunchKernelGGL((nearest_interp_bwd_lds_kernel<int32_t>), grid, dim3(BLK), lds, st, grad_out, static_cast<const int32_t*>(idx),
                            grad_feat, (int)C, (int)M, (int)U, (int)CG);

@@ -43,7 +43,7 @@ typedef simt::Dim3 dim3;
 
 typedef void* hipStream_t;
 typedef int hipError_t;
-enum { hipSuccess = 0 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "simt"; }
