@@ -15,6 +15,7 @@
 //     a no-op for that set) and clears slot (t+1)%3.
 // fp32 throughout like the reference; results differ from it by summation order and exp rounding
 // only (tests/test_pose_gpu.py states the tolerance).
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -53,12 +54,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // instruction); the tile is kept as three planes in LDS so a lane fetches two neighbours per b64 read.
 __global__ __launch_bounds__(kBlock) void mean_shift_round_kernel(
     float4* __restrict__ buf0, float4* __restrict__ buf1, const int* __restrict__ counts, int sets_per_count,
-    int64_t stride, float k2, float thresh, unsigned* __restrict__ shift, int* __restrict__ rounds, int t, int G) {
+    int64_t stride, float k2, float thresh, unsigned* __restrict__ shift, int* __restrict__ rounds, int t, int G, int min_cnt) {
 #pragma clang fp contract(fast)
     __shared__ __attribute__((aligned(16))) float tx[kTile], ty[kTile], tz[kTile];
     __shared__ float wmax[kBlock / 64];
     const int g = blockIdx.y;
     const int cnt = counts[g / sets_per_count];
+    if (cnt <= min_cnt) return;                 // fitted by mean_shift_fit_kernel
     bool done = false;
     if (t > 0) done = __uint_as_float(shift[((t + 2) % 3) * G + g]) < thresh;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -127,17 +129,256 @@ __global__ __launch_bounds__(kBlock) void mean_shift_round_kernel(
     }
 }
 
+// ---- the whole fit of one vote set in ONE workgroup (round 5) ---------------------------------------------------
+// What the round-by-round kernels above cost on a batch of 8 frames x 5 objects (profiles/r05_pose_start.json): 903 launches, 80 ms,
+// 2.5e11 weighted pairs -- the sets need 220-260 rounds to meet the reference's stopping rule (largest move < bandwidth / 1000), and every
+// round is M^2 pairs.  But blurring mean shift COLLAPSES: after three rounds 1672 votes of a keypoint occupy 191 distinct fp32 positions,
+// after eight rounds 68, and the remaining ~200 rounds move a few stragglers between those clusters.  Points at bit-identical positions
+// move identically for ever (same sums in the same order), so they can be carried as ONE point with a multiplicity:
+//     new_c_i = sum_u m_u w(c_i, c_u) c_u / sum_u m_u w(c_i, c_u)        over the distinct positions u
+// is the reference's update (meanshift_pytorch.py:38-46) with equal terms collected -- the same iteration, not an approximation
+// (the fp32 sums group differently: 1e-7-level differences, tests/test_pose_gpu.py keeps its 5e-4 m bar).
+// One workgroup of 1024 threads owns a set of up to kCap points in LDS and makes ALL rounds without leaving the CU:
+//   * pair loop as above (4 lanes per point, packed fp32, one v_exp_f32 per pair), weights multiplied by the multiplicity;
+//   * the same loop notices d^2 == 0: the lowest index at a point's position is its representative, the multiplicities there add up;
+//   * after a round with duplicates a block-wide scan compacts the representatives (order preserved) and re-targets the map
+//     original point -> distinct position; the round's cost falls with the square of the collapse;
+//   * stopping test, the ball count of the winner (multiplicity-weighted; ties to the lowest ORIGINAL index, :50-53), labels of the
+//     original points and the centre are finished in the same launch: no host polling, no per-round launch.
+// Sets larger than kCap points are left to the round-by-round path (ffb6d_mean_shift_f32 runs it for those sets only).
+constexpr int kCap = 4096;
+constexpr int kBT = 1024;
+constexpr int kFitLds = (3 * 2 + 2) * kCap * (int)sizeof(float) + 3 * kCap * (int)sizeof(unsigned short) + 512;
+
+__global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
+    const float4* __restrict__ sets, const int* __restrict__ counts, int sets_per_count, int64_t stride, float k2, float thresh,
+    float bandwidth, int max_iter, float* __restrict__ centers, unsigned char* __restrict__ labels, int* __restrict__ n_inside,
+    int* __restrict__ iters, int* __restrict__ rounds_ws, int* __restrict__ n_large) {
+#pragma clang fp contract(fast)
+    extern __shared__ __attribute__((aligned(16))) unsigned char fit_lds[];
+    float* px = reinterpret_cast<float*>(fit_lds);              // [2][kCap] each: positions of the distinct points, ping-pong
+    float* py = px + 2 * kCap;
+    float* pz = py + 2 * kCap;
+    float* pm = pz + 2 * kCap;                                  // [kCap] multiplicity
+    float* pmn = pm + kCap;                                     // [kCap] multiplicity after merging (valid at representatives)
+    unsigned short* rep = reinterpret_cast<unsigned short*>(pmn + kCap);   // [kCap] lowest index at the same position
+    unsigned short* nidx = rep + kCap;                          // [kCap] index after compaction
+    unsigned short* owner = nidx + kCap;                        // [kCap] original point -> distinct position
+    float* red = reinterpret_cast<float*>(owner + kCap);        // [16 + 16 + ...] block reductions
+    unsigned long long* red64 = reinterpret_cast<unsigned long long*>(red + 32);
+
+    const int g = blockIdx.x;
+    const int M = counts[g / sets_per_count];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (M > kCap) {                                             // the round-by-round path takes this set
+        if (tid == 0) atomicAdd(n_large, 1);
+        return;
+    }
+    if (M <= 0) {
+        if (tid == 0) {
+            centers[3 * g] = centers[3 * g + 1] = centers[3 * g + 2] = 0.f;
+            if (n_inside) n_inside[g] = 0;
+            if (iters) iters[g] = 0;
+            rounds_ws[g] = 0;
+        }
+        if (labels)
+            for (int64_t j = tid; j < stride; j += kBT) labels[g * stride + j] = 0;
+        return;
+    }
+    const float4* src = sets + g * stride;
+    for (int j = tid; j < kCap; j += kBT) {
+        const float4 p = j < M ? src[j] : make_float4(kFar, kFar, kFar, 0.f);
+        px[j] = p.x; py[j] = p.y; pz[j] = p.z;
+        px[kCap + j] = kFar; py[kCap + j] = kFar; pz[kCap + j] = kFar;      // the other buffer: far points wherever a round does not write
+        pm[j] = j < M ? 1.f : 0.f;
+        owner[j] = (unsigned short)j;
+    }
+    int U = M, cur = 0, made = 0;
+    const int sub = tid & 3;
+    const v2f kk = {k2, k2};
+    __syncthreads();
+
+    for (int t = 0; t <= max_iter; ++t) {                       // `it > max_iter` stops after max_iter + 1 rounds (:47)
+        const float *cx_ = px + cur * kCap, *cy_ = py + cur * kCap, *cz_ = pz + cur * kCap;
+        float *nx_ = px + (cur ^ 1) * kCap, *ny_ = py + (cur ^ 1) * kCap, *nz_ = pz + (cur ^ 1) * kCap;
+        const int n = (U + 7) & ~7;                             // (slots U .. n hold far points of multiplicity 0)
+        float move = 0.f;
+        int dups = 0;
+        for (int i0 = 0; i0 < U; i0 += kBT / 4) {
+            const int q = i0 + (tid >> 2);
+            const int qc = min(q, U - 1);
+            const float ccx = cx_[qc], ccy = cy_[qc], ccz = cz_[qc];
+            const v2f cx = {ccx, ccx}, cy = {ccy, ccy}, cz = {ccz, ccz};
+            v2f sw = {0.f, 0.f}, sx = {0.f, 0.f}, sy = {0.f, 0.f}, sz = {0.f, 0.f}, mult = {0.f, 0.f};
+            int r0 = kCap, r1 = kCap;
+#pragma unroll 2
+            for (int x = 2 * sub; x < n; x += 8) {
+                const v2f ax = *reinterpret_cast<const v2f*>(&cx_[x]);
+                const v2f ay = *reinterpret_cast<const v2f*>(&cy_[x]);
+                const v2f az = *reinterpret_cast<const v2f*>(&cz_[x]);
+                const v2f am = *reinterpret_cast<const v2f*>(&pm[x]);
+                const v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
+                const v2f d2 = dx * dx + dy * dy + dz * dz;
+                const v2f e = d2 * kk;
+                v2f w;
+                w.x = __builtin_amdgcn_exp2f(e.x);
+                w.y = __builtin_amdgcn_exp2f(e.y);
+                w *= am;
+                sw += w;
+                sx += w * ax;
+                sy += w * ay;
+                sz += w * az;
+                const bool h0 = d2.x == 0.f, h1 = d2.y == 0.f;   // the same position (a far padding point never is)
+                mult.x += h0 ? am.x : 0.f;
+                mult.y += h1 ? am.y : 0.f;
+                r0 = h0 ? min(r0, x) : r0;
+                r1 = h1 ? min(r1, x + 1) : r1;
+            }
+            float aw = sw.x + sw.y, ax = sx.x + sx.y, ay = sy.x + sy.y, az = sz.x + sz.y, am = mult.x + mult.y;
+            int r = min(r0, r1);
+#pragma unroll
+            for (int o = 1; o < 4; o <<= 1) {
+                aw += __shfl_xor(aw, o);
+                ax += __shfl_xor(ax, o);
+                ay += __shfl_xor(ay, o);
+                az += __shfl_xor(az, o);
+                am += __shfl_xor(am, o);
+                r = min(r, __shfl_xor(r, o));
+            }
+            if (q < U && sub == 0) {
+                const float nx = ax / aw, ny = ay / aw, nz = az / aw;
+                nx_[q] = nx; ny_[q] = ny; nz_[q] = nz;
+                pmn[q] = am;
+                rep[q] = (unsigned short)r;
+                dups += r != q;
+                const float ex = nx - ccx, ey = ny - ccy, ez = nz - ccz;
+                float mv = sqrtf(ex * ex + ey * ey + ez * ez);
+                if (!(mv == mv)) mv = __uint_as_float(0x7f800000u);     // NaN never counts as converged
+                move = fmaxf(move, mv);
+            }
+        }
+        // block-wide: largest move, number of duplicates
+        move = wave_max(move);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dups += __shfl_xor(dups, o);
+        if (lane == 0) { red[wave] = move; red[16 + wave] = __int_as_float(dups); }
+        __syncthreads();
+        float bmove = red[0];
+        int bdups = __float_as_int(red[16]);
+        for (int i = 1; i < kBT / 64; ++i) { bmove = fmaxf(bmove, red[i]); bdups += __float_as_int(red[16 + i]); }
+        made = t + 1;
+        if (bdups == 0) {
+            cur ^= 1;                                           // (slots U .. n of the other buffer: far points since the start or the last compaction)
+        } else {
+            // compact the representatives in index order: thread -> 4 consecutive slots
+            int f[4], loc = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * tid + u;
+                f[u] = i < U && rep[i] == i;
+                loc += f[u];
+            }
+            int incl = loc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            __syncthreads();                                    // (red[] of the reductions above has been read by everyone)
+            if (lane == 63) red[wave] = __int_as_float(incl);
+            __syncthreads();
+            int pre = 0, total = 0;
+            for (int i = 0; i < kBT / 64; ++i) {
+                const int c = __float_as_int(red[i]);
+                pre += i < wave ? c : 0;
+                total += c;
+            }
+            int k = pre + incl - loc;
+            float *ox = px + cur * kCap, *oy = py + cur * kCap, *oz = pz + cur * kCap;      // the old positions are dead: compact into them
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * tid + u;
+                if (i < U) nidx[i] = (unsigned short)k;         // (of a duplicate: overwritten below through its representative)
+                if (f[u]) {
+                    ox[k] = nx_[i]; oy[k] = ny_[i]; oz[k] = nz_[i];
+                    pm[k] = pmn[i];                             // pm[k], k <= i: read only in the pair loop, which is over
+                    ++k;
+                }
+            }
+            __syncthreads();
+            for (int j = tid; j < M; j += kBT) owner[j] = nidx[rep[owner[j]]];
+            const int Un = total, nn = (Un + 7) & ~7;
+            for (int j = Un + tid; j < max(nn, min(n, kCap)); j += kBT) {      // far points behind the new end, in both buffers
+                ox[j] = kFar; oy[j] = kFar; oz[j] = kFar;
+                nx_[j] = kFar; ny_[j] = kFar; nz_[j] = kFar;
+                pm[j] = 0.f;
+            }
+            U = Un;
+        }
+        __syncthreads();
+        if (bmove < thresh) break;
+    }
+
+    // ball sizes (multiplicity-weighted), winner = largest ball, ties to the lowest index = lowest original index (:50-53)
+    const float *cx_ = px + cur * kCap, *cy_ = py + cur * kCap, *cz_ = pz + cur * kCap;
+    const int n = (U + 7) & ~7;
+    unsigned long long key = 0ull;
+    for (int i0 = 0; i0 < U; i0 += kBT / 4) {
+        const int q = i0 + (tid >> 2);
+        const int qc = min(q, U - 1);
+        const float ccx = cx_[qc], ccy = cy_[qc], ccz = cz_[qc];
+        float inside = 0.f;
+        for (int x = sub; x < n; x += 4) {
+            const float dx = ccx - cx_[x], dy = ccy - cy_[x], dz = ccz - cz_[x];
+            inside += sqrtf(dx * dx + dy * dy + dz * dz) < bandwidth ? pm[x] : 0.f;
+        }
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) inside += __shfl_xor(inside, o);
+        if (q < U) {
+            const unsigned long long mine = (static_cast<unsigned long long>((unsigned)inside) << 32) | (0xffffffffu - static_cast<unsigned>(q));
+            key = mine > key ? mine : key;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if (lane == 0) red64[wave] = key;
+    __syncthreads();
+    for (int i = 0; i < kBT / 64; ++i) key = red64[i] > key ? red64[i] : key;
+    const int win = static_cast<int>(0xffffffffu - static_cast<unsigned>(key & 0xffffffffull));
+    const float wx = cx_[win], wy = cy_[win], wz = cz_[win];
+    if (tid == 0) {
+        centers[3 * g] = wx; centers[3 * g + 1] = wy; centers[3 * g + 2] = wz;
+        if (n_inside) n_inside[g] = static_cast<int>(key >> 32);
+        if (iters) iters[g] = made;
+        rounds_ws[g] = made;
+    }
+    if (labels) {
+        for (int64_t j = tid; j < stride; j += kBT) {
+            unsigned char lab = 0;
+            if (j < M) {
+                const int u = owner[j];
+                const float dx = wx - cx_[u], dy = wy - cy_[u], dz = wz - cz_[u];
+                lab = sqrtf(dx * dx + dy * dy + dz * dz) < bandwidth;
+            }
+            labels[g * stride + j] = lab;
+        }
+    }
+}
+
 // ball size of every converged point, arg-max with ties to the lowest index (:50-53)
 __global__ __launch_bounds__(kBlock) void ball_count_kernel(
     const float4* __restrict__ buf0, const float4* __restrict__ buf1, const int* __restrict__ counts,
     int sets_per_count, int64_t stride, float bandwidth, const int* __restrict__ rounds,
-    unsigned long long* __restrict__ best) {
+    unsigned long long* __restrict__ best, int min_cnt) {
     __shared__ float4 tile[kTile];
     __shared__ unsigned long long wbest[kBlock / 64];
     const int g = blockIdx.y;
     const int cnt = counts[g / sets_per_count];
     const int q0 = blockIdx.x * kPointsPerBlock;
-    if (q0 >= cnt) return;
+    if (q0 >= cnt || cnt <= min_cnt) return;
     const float4* src = ((rounds[g] & 1) ? buf1 : buf0) + g * stride;
     const int sub = threadIdx.x & (kLanesPerPoint - 1);
     const int q = q0 + (threadIdx.x >> 2);
@@ -177,9 +418,10 @@ __global__ __launch_bounds__(kBlock) void ball_labels_kernel(
     const float4* __restrict__ buf0, const float4* __restrict__ buf1, const int* __restrict__ counts,
     int sets_per_count, int64_t stride, float bandwidth, const int* __restrict__ rounds,
     const unsigned long long* __restrict__ best, float* __restrict__ centers, unsigned char* __restrict__ labels,
-    int* __restrict__ n_inside, int* __restrict__ iters) {
+    int* __restrict__ n_inside, int* __restrict__ iters, int min_cnt) {
     const int g = blockIdx.y;
     const int cnt = counts[g / sets_per_count];
+    if (cnt <= min_cnt) return;                 // results written by mean_shift_fit_kernel
     const int j = blockIdx.x * kBlock + threadIdx.x;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && iters) iters[g] = rounds[g];
@@ -469,36 +711,66 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
     unsigned long long* best =
         reinterpret_cast<unsigned long long*>(tail + align256(3 * sizeof(unsigned) * G) + align256(sizeof(int) * G));
     FFB6D_HIP_TRY(hipMemsetAsync(tail, 0, need - 2 * buf_bytes, st));
-    FFB6D_HIP_TRY(hipMemcpyAsync(buf0, sets, static_cast<size_t>(G) * set_stride * sizeof(float4),
-                                 hipMemcpyDeviceToDevice, st));
 
     const double inv_bw2 = 1.0 / (static_cast<double>(bandwidth) * static_cast<double>(bandwidth));
     const float k2 = static_cast<float>(-0.5 * 1.4426950408889634 * inv_bw2);
     const float thresh = static_cast<float>(static_cast<double>(bandwidth) * 1e-3);   // stop_thresh (:30)
-    // blocks beyond a set's count exit at once, but 12288-wide grids over 1700-point sets are mostly
-    // such blocks: the caller's bound on the counts sizes the grid
-    const int64_t span = max_count > 0 ? max_count : set_stride;
+
+    // Sets of up to kCap points: the whole fit in one workgroup each, one launch for all of them (duplicate merging, no polling).
+    // `best` doubles as the counter of the sets that are larger (one int at its start; cleared above, cleared again before the
+    // round-by-round path uses the array).
+    int* n_large = reinterpret_cast<int*>(best);
+    {
+        static int attr_set[ffb6d::kMaxDevices + 1];
+        const int slot = ffb6d::device_slot();
+        if (!ffb6d::cache_get(attr_set, slot)) {
+            FFB6D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mean_shift_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              kFitLds));
+            ffb6d::cache_set(attr_set, slot, 1);
+        }
+    }
+    mean_shift_fit_kernel<<<static_cast<unsigned>(G), kBT, kFitLds, st>>>(
+        reinterpret_cast<const float4*>(sets), counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels,
+        n_inside, iters, rounds, n_large);
+    FFB6D_LAUNCH_CHECK();
+    if (set_stride <= kCap) return 0;                          // no set can be larger
+    int large = 0;                                             // one read-back per call (the old path polled every `check_every` rounds)
+    FFB6D_HIP_TRY(hipMemcpyAsync(&large, n_large, sizeof(int), hipMemcpyDeviceToHost, st));
+    FFB6D_HIP_TRY(hipStreamSynchronize(st));
+    if (large == 0) return 0;
+
+    // ---- sets of more than kCap points: one launch per round for all of them (round-1 path) ----
+    FFB6D_HIP_TRY(hipMemsetAsync(best, 0, sizeof(unsigned long long) * G, st));
+    FFB6D_HIP_TRY(hipMemcpyAsync(buf0, sets, static_cast<size_t>(G) * set_stride * sizeof(float4),
+                                 hipMemcpyDeviceToDevice, st));
+    // blocks beyond a set's count exit at once: the largest count sizes the grid
+    std::vector<int> host_counts(G / sets_per_count);
+    FFB6D_HIP_TRY(hipMemcpyAsync(host_counts.data(), counts, sizeof(int) * host_counts.size(), hipMemcpyDeviceToHost, st));
+    FFB6D_HIP_TRY(hipStreamSynchronize(st));
+    int64_t span = 1;
+    for (int c : host_counts) span = std::max<int64_t>(span, std::min<int64_t>(c, set_stride));
+    (void)max_count;
     const dim3 grid(static_cast<unsigned>(ceil_div(span, kPointsPerBlock)), static_cast<unsigned>(G));
     std::vector<float> host_shift;
     if (check_every > 0) host_shift.resize(G);
     for (int t = 0; t <= max_iter; ++t) {       // `it > max_iter` stops after max_iter+1 rounds (:47)
         mean_shift_round_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, k2, thresh,
-                                                         shift, rounds, t, G);
+                                                         shift, rounds, t, G, kCap);
         FFB6D_LAUNCH_CHECK();
         if (check_every > 0 && (t + 1) % check_every == 0 && t < max_iter) {
             FFB6D_HIP_TRY(hipMemcpyAsync(host_shift.data(), shift + (t % 3) * G, sizeof(float) * G,
                                          hipMemcpyDeviceToHost, st));
             FFB6D_HIP_TRY(hipStreamSynchronize(st));
             bool all_done = true;
-            for (int g = 0; g < G && all_done; ++g) all_done = host_shift[g] < thresh;
+            for (int g = 0; g < G && all_done; ++g) all_done = host_counts[g / sets_per_count] <= kCap || host_shift[g] < thresh;
             if (all_done) break;
         }
     }
-    ball_count_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best);
+    ball_count_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best, kCap);
     FFB6D_LAUNCH_CHECK();
     const dim3 lgrid(static_cast<unsigned>(labels ? ceil_div(set_stride, kBlock) : 1), static_cast<unsigned>(G));
     ball_labels_kernel<<<lgrid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best,
-                                                 centers, labels, n_inside, iters);
+                                                 centers, labels, n_inside, iters, kCap);
     FFB6D_LAUNCH_CHECK();
     return 0;
 }

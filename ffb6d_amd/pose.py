@@ -68,7 +68,7 @@ def mean_shift(sets, counts, bandwidth, max_iter=300, sets_per_count=1, want_lab
     rounds = torch.empty((G,), dtype=torch.int32, device=dev)
     lib = _lib.load()
     if max_count is None:
-        max_count = int(counts.max().item()) if (check_every > 0 and counts.numel()) else 0
+        max_count = 0            # (round 5: the library sizes its grids itself; no read-back of the counts here)
     wbytes = lib.ffb6d_mean_shift_workspace_bytes(G, M)
     ws = torch.empty((max(wbytes, 1),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev), _lib.traced("mean_shift", 16 * G * M, (G, M)):

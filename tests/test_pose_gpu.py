@@ -70,6 +70,20 @@ def test_mean_shift_batch_equals_single_fits(device):
         assert torch.equal(ctr, centers[g]) and torch.equal(lab, labels[g])
 
 
+def test_mean_shift_sets_beyond_the_one_workgroup_limit(device):
+    """Round 5: sets of up to 4096 points are fitted by one workgroup each (duplicate merging, csrc/pose.hip mean_shift_fit_kernel), larger
+    ones by the round-by-round kernels -- both in one call here, each against the oracle's restatement of MeanShiftTorch.fit."""
+    from oracle import pose_ref
+    sizes = (4200, 300, 4096)
+    clouds = [gen.ms_votes(520 + k, n) for k, n in enumerate(sizes)]
+    centers, labels = pose.MeanShiftTorch(bandwidth=0.05).fit_batch([torch.from_numpy(c).to(device) for c in clouds])
+    for g, c in enumerate(clouds):
+        want_c, want_l, _ = pose_ref.mean_shift_fit(torch.from_numpy(c), 0.05)
+        assert np.abs(centers[g].cpu().numpy() - np.asarray(want_c)).max() <= CTR_TOL, sizes[g]
+        flips = int((labels[g].cpu().numpy() != np.asarray(want_l)).sum())
+        assert flips <= max(1, int(LABEL_FLIP * sizes[g])), (sizes[g], flips)
+
+
 def test_mean_shift_round_limit_and_polling(device):
     """max_iter bounds the rounds (it > max_iter after max_iter+1 rounds, meanshift_pytorch.py:47);
     polling the stop flag every k rounds must not change the result."""
