@@ -352,40 +352,89 @@ def test_batch_items_are_independent(device):
         torch.backends.cudnn.benchmark = keep
 
 
-@pytest.mark.parametrize("n_pts,height,width", [(1024, 120, 160), (1100, 136, 168)])      # the second: ragged against every tile size
-def test_training_step_gradients_match_plain_torch(device, n_pts, height, width):
-    """Config-3 path (DDP training) on one rank: gradients through the custom operators' backward
-    kernels (inverted-index row sums / arg-max / softmax backward) inside the whole network must equal the
-    gradients plain torch autograd produces for the same forward (oracle/forward_ref.py)."""
+def _step_gradients(device, n_pts, height, width, batch, autocast):
+    """gradients of every parameter for one training forward / backward: ours (stock modules + the row operators of ops_cl, backward
+    through csrc/train_rows.hip / train_ops.hip), plain torch autograd of oracle/forward_ref.py in fp32, and -- with autocast -- plain
+    torch under the same bf16 autocast"""
     from oracle import forward_ref
-    frames = synth.make_batch(7, 2, n_points=n_pts, height=height, width=width)
+    frames = synth.make_batch(7, batch, n_points=n_pts, height=height, width=width)
     net = build(5, n_pts, device)         # eval(): BatchNorm uses running statistics in both paths
     inputs = pyramid.frames_to_device(frames, device)
-    names = ["rndla_ds_stages.0.lfa.mlp1.conv.weight", "rndla_ds_stages.2.lfa.att_pooling_1.fc.weight",
-             "ds_fuse_r2p_pre_layers.1.conv.weight", "ds_fuse_p2r_pre_layers.0.conv.weight",
-             "rndla_up_stages.1.conv.weight", "cnn_ds_stages.0.0.conv1.weight", "rndla_pre_stages.conv.weight"]
     params = dict(net.named_parameters())
 
     def loss_of(ep):
         return sum((v.float() ** 2).mean() for v in ep.values())
 
+    def ref_run(cast):
+        # one leaf per TENSOR: `final` is shared by two decoder stages (ffb6d.py:86-87), its weight appears under two state_dict keys
+        leaves, sd = {}, {}
+        for k, v in net.state_dict().items():
+            key = (v.data_ptr(), tuple(v.shape))
+            if key not in leaves:
+                leaves[key] = v.detach().clone().requires_grad_(k in params)
+            sd[k] = leaves[key]
+        with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=cast):
+            ref_loss = loss_of(forward_ref.ffb6d_forward(sd, inputs))
+        ref_loss.backward()
+        return float(ref_loss), {k: sd[k].grad for k in params}
+
     net.zero_grad()
-    with torch.enable_grad():
+    with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
         loss = loss_of(net(inputs))
     loss.backward()
-    ours = {n: params[n].grad.detach().clone() for n in names}
+    ours = {n: p.grad.detach().clone() if p.grad is not None else None for n, p in params.items()}
+    ref_loss, ref = ref_run(False)
+    plain = ref_run(True) if autocast else None
+    return float(loss), ours, ref_loss, ref, plain
 
-    sd = {k: v.detach().clone().requires_grad_(k in params) for k, v in net.state_dict().items()}
-    with torch.enable_grad():
-        ref_loss = loss_of(forward_ref.ffb6d_forward(sd, inputs))
-    ref_loss.backward()
-    assert abs(float(loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss))
-    for n in names:
-        g, r = ours[n], sd[n].grad
+
+@pytest.mark.parametrize("n_pts,height,width,batch", [(1024, 120, 160, 2), (1100, 136, 168, 2),      # the second: ragged against every tile size
+                                                      (12288, 480, 640, 1)])                         # the benchmarked geometry
+def test_training_step_gradients_match_plain_torch(device, n_pts, height, width, batch):
+    """Config-3 path (DDP training) on one rank: gradients through the custom operators' backward
+    kernels (inverted-index row sums / arg-max / softmax backward) inside the whole network must equal the
+    gradients plain torch autograd produces for the same forward (oracle/forward_ref.py) -- for EVERY parameter."""
+    loss, ours, ref_loss, ref, _ = _step_gradients(device, n_pts, height, width, batch, False)
+    assert abs(loss - ref_loss) <= 1e-3 * abs(ref_loss)
+    worst, checked = ("", 0.0), 0
+    for n, r in ref.items():
+        g = ours[n]
+        if r is None:                                  # a parameter the forward does not reach (none today)
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        assert g is not None, n
         scale = float(r.abs().max())
-        assert scale > 0, n
+        if scale == 0.0:
+            assert float(g.abs().max()) == 0.0, n
+            continue
         err = float((g - r).abs().max()) / scale
-        print(n, "grad max rel err", err)
-        # measured 5e-6 .. 3e-4 run to run: MIOpen's backward-data/weight algorithms and the float
-        # atomics of the scatter-add kernels are not bit-reproducible
-        assert err <= 5e-3, (n, err)
+        checked += 1
+        if err > worst[1]:
+            worst = (n, err)
+        # measured 5e-6 .. 3e-4 on most parameters, up to 7e-3 on a handful run to run: MIOpen's backward-data/weight algorithms and the
+        # float atomics of the scatter-add kernels are not bit-reproducible (the largest element of a gradient is the yardstick)
+        assert err <= 1e-2, (n, err)
+    print("parameters checked:", checked, "worst:", worst)
+    assert checked >= 300
+
+
+def test_training_step_gradients_under_bf16_autocast(device):
+    """the same step as the reference trains it (apex amp ~ torch.autocast(bfloat16), train_lm.py:600): our gradients may be as far from
+    the fp32 gradients as plain torch's gradients under the same autocast are -- twice that plus a floor, per parameter, measured in the
+    Frobenius norm (bf16 rounding is noise on every element; the largest element is not a stable yardstick)."""
+    loss, ours, ref_loss, ref, (plain_loss, plain) = _step_gradients(device, 1100, 136, 168, 2, True)
+    # (the objective itself -- sum of the mean squares of the three outputs -- moves by ~10 % under bf16 autocast on these weights, ours as plain torch's)
+    assert abs(loss - ref_loss) <= 2.0 * abs(plain_loss - ref_loss) + 1e-2 * abs(ref_loss), (loss, plain_loss, ref_loss)
+    worst, checked = ("", 0.0, 0.0), 0
+    for n, r in ref.items():
+        if r is None or float(r.abs().max()) == 0.0:
+            continue
+        nr = float(r.double().norm())
+        e_ours = float((ours[n].double() - r.double()).norm()) / nr
+        e_plain = float((plain[n].double() - r.double()).norm()) / nr
+        checked += 1
+        if e_ours - 2 * e_plain > worst[1] - 2 * worst[2]:
+            worst = (n, e_ours, e_plain)
+        assert e_ours <= 2.0 * e_plain + 2e-2, (n, e_ours, e_plain)
+    print("parameters checked:", checked, "worst (name, ours, plain torch):", worst)
+    assert checked >= 300
