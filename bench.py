@@ -583,7 +583,8 @@ def main():
                                  "miopen": ("find mode (cudnn.benchmark), " if args.cudnn_benchmark else "immediate mode, ") + miopen_db,
                                  "upconv_fold": forward_pm.UPCONV_FOLD if isinstance(forward_pm.UPCONV_FOLD, str) else
                                  (None if forward_pm.UPCONV_FOLD is None else sorted(forward_pm.UPCONV_FOLD)),
-                                 "psp_train_fold": model.PyramidPooling.fold_in_training},
+                                 "psp_train_fold": model.PyramidPooling.fold_in_training,
+                                 "final_rows_log_softmax": model.FinalHead.rows_log_softmax, "upsample_rows": ops.UPSAMPLE_ROWS},
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "
                                       f"{args.dist_backend if world > 1 else 'no'} process group)"},
             "breakdown_ms": ({"step": fwd_ms, "knn_pyramid_alone": pyr_alone_ms,

@@ -77,7 +77,7 @@ mlp_chain3_kernel(const ChainParams p)
         b1s[threadIdx.x] = p.b1[threadIdx.x];
         b2s[threadIdx.x] = p.b2[threadIdx.x];
     }
-    if (threadIdx.x < 32) b3s[threadIdx.x] = p.b3[threadIdx.x];
+    if (threadIdx.x < 32) b3s[threadIdx.x] = threadIdx.x < p.cout3 ? p.b3[threadIdx.x] : 0.f;     // cout3 entries are read, not 32
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, kh = lane >> 5;
@@ -179,6 +179,8 @@ extern "C" int ffb6d_mlp_chain3_pm_f32(const float* x, int64_t ldx, const float*
     FFB6D_REQUIRE(rows >= 0 && rows < (1LL << 31) - 256 && ldx >= D && ldx % 4 == 0 && cout3 >= 4 && cout3 <= 32 && cout3 % 4 == 0 &&
                       ldo >= cout3 && ldo % 4 == 0,
                   "mlp_chain3_pm: rows of 128 channels (ldx a multiple of 4), 4 <= cout3 <= 32 a multiple of 4, ldo a multiple of 4");
+    FFB6D_REQUIRE(ldx < (1LL << 31) && ldo < (1LL << 31), "mlp_chain3_pm: row strides must fit 31 bits (got %lld, %lld)", (long long)ldx,
+                  (long long)ldo);
     FFB6D_REQUIRE(act1 >= 0 && act1 <= 2 && act2 >= 0 && act2 <= 2 && act3 >= 0 && act3 <= 2, "mlp_chain3_pm: act must be 0, 1 or 2");
     if (rows == 0) return FFB6D_OK;
     FFB6D_REQUIRE(x && w1k && b1 && w2k && b2 && w3k && b3 && out, "mlp_chain3_pm: null pointer");
@@ -198,7 +200,15 @@ extern "C" int ffb6d_mlp_chain3_pm_f32(const float* x, int64_t ldx, const float*
             return set_error(FFB6D_ERR_HIP, "mlp_chain3_pm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         cache_set(attr_set, slot, 1);
     }
-    const unsigned grid = (unsigned)std::min<int64_t>(p.n_tiles, 256);      // 144 KB of LDS: one workgroup per CU
+    static int cu_count[kMaxDevices + 1];                                   // 144 KB of LDS: one workgroup per CU of THIS device
+    int cus = cache_get(cu_count, slot);
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        cache_set(cu_count, slot, cus);
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>(p.n_tiles, cus);
     hipLaunchKernelGGL(mlp_chain3_kernel, dim3(grid), dim3(BLK), CHAIN_LDS, as_stream(stream), p);
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;

@@ -25,7 +25,7 @@ Dense 3x3 / 7x7 convolutions stay on MIOpen, fed cha
 import torch
 import torch.nn.functional as F
 
-from . import ops, ops_pm, pyramid
+from . import _lib, ops, ops_pm, pyramid
 
 
 def cached(mod, name, sources, build):
@@ -583,36 +583,52 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
     else:
         starts = [mlp(m, img, x2=p_emb, x1_gather=choose) for m in firsts]
 
-    def head(seq, y):
+    def head_plan(seq, y):
+        """the derived weights of a head's remaining layers (folded / k-chunked / padded: cached on the modules) -- built HERE, on the
+        main stream, so that cached tensors always belong to main's allocator pool even when the head itself runs on the side stream"""
         layers = list(seq)[1:]
         if HEADS_CHAIN_FUSED and y.dtype == torch.float32 and len(layers) == 3 and y.shape[-1] == 128 and \
                 [tuple(m.conv.weight.shape[:2]) for m in layers[:2]] == [(128, 128)] * 2 and layers[2].conv.weight.shape[1] == 128 \
                 and layers[2].conv.weight.shape[0] <= 32 and all(m.act_code in (0, 1, 2) for m in layers):
             # the three remaining layers as one launch, hidden activations in registers (csrc/mlp_chain.hip)
             cout = layers[2].conv.weight.shape[0]
-            cpad = -(-cout // 4) * 4
             parts = [folded_kc(m, F32) + (m.act_code,) for m in layers[:2]] + [kc_padded(layers[2], 32) + (layers[2].act_code,)]
-            return ops_pm.mlp_chain3(y, parts[0], parts[1], parts[2], cpad)[..., :cout]
-        for layer in layers[:-1]:
-            y = mlp(layer, y)
+            return ("chain", layers, parts, cout)
         last, cout = layers[-1], layers[-1].conv.weight.shape[0]
         mult = 16 // y.element_size()
+        plain = [(m, folded(m, None, y.dtype)) for m in layers[:-1]]
         if HEADS_ALIGN_LAST and cout % mult:
             # 22 / 3 output channels: zero weight rows up to whole 16-byte output rows, which the stream form needs
             # (ffb6d_mlp_pm_choice); the extra channels are never read
-            w, b = out_padded(last, -(-cout // mult) * mult, y.dtype)
-            return ops_pm.mlp(y, w, b, last.act_code)[..., :cout]
-        return mlp(last, y)
+            return ("layers", plain, last, out_padded(last, -(-cout // mult) * mult, y.dtype), cout)
+        return ("layers", plain, last, folded(last, None, y.dtype), cout)
 
+    def head(plan, y):
+        if plan[0] == "chain":
+            _, layers, parts, cout = plan
+            try:
+                return ops_pm.mlp_chain3(y, parts[0], parts[1], parts[2], -(-cout // 4) * 4)[..., :cout]
+            except _lib.FFB6DNativeError as e:           # e.g. a device that refuses 145 KB of dynamic LDS: the three launches below
+                if "hipFuncSetAttribute" not in str(e):
+                    raise
+            for layer in layers:
+                y = mlp(layer, y)
+            return y
+        _, plain, last, (w, b), cout = plan
+        for layer, (wl, bl) in plain:
+            y = ops_pm.mlp(y, wl, bl, layer.act_code)
+        return ops_pm.mlp(y, w, b, last.act_code)[..., :cout]
+
+    plans = [head_plan(seq, y) for seq, y in zip(seqs, starts)]
     n = p_emb.shape[1]
     # the three chains are independent and each leaves CUs idle (768 workgroups of short-K GEMMs): the keypoint head runs on the
     # side stream, idle since the last decoder, under the other two
     kp_on = side if HEADS_ON_BOTH_STREAMS else main
     handover(starts[1], main, kp_on, "side waits for the heads' first layer")
     with torch.cuda.stream(kp_on):
-        kp = head(seqs[1], starts[1]).float().reshape(B, n, net.n_kps, 3).permute(0, 2, 1, 3).contiguous()
-    end_points['pred_rgbd_segs'] = head(seqs[0], starts[0]).float().transpose(1, 2).contiguous()           # [B,n_cls,N]
-    ctr = head(seqs[2], starts[2]).float().reshape(B, n, 1, 3).permute(0, 2, 1, 3).contiguous()
+        kp = head(plans[1], starts[1]).float().reshape(B, n, net.n_kps, 3).permute(0, 2, 1, 3).contiguous()
+    end_points['pred_rgbd_segs'] = head(plans[0], starts[0]).float().transpose(1, 2).contiguous()           # [B,n_cls,N]
+    ctr = head(plans[2], starts[2]).float().reshape(B, n, 1, 3).permute(0, 2, 1, 3).contiguous()
     end_points['pred_kp_ofs'] = handover(kp, kp_on, main, "main waits for the keypoint head")
     end_points['pred_ctr_ofs'] = ctr
     return end_points

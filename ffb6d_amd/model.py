@@ -301,12 +301,17 @@ class FinalHead(nn.Sequential):
     """pspnet.py:108-112 `final`: Conv2d(64,64,1) + LogSoftmax (implicit dim = 1 on a 4-d map); the fused inference path runs it
     as one GEMM with a log-softmax epilogue (forward_pm.final_head)."""
 
+    # True: the LogSoftmax runs on rows in the map's own dtype (under bf16 autocast the output is rounded to bf16; every consumer is a
+    # convolution that rounds its input to bf16, a row gather or a max over gathered rows, all of which commute with that rounding).
+    # False: ATen's operator, which autocast runs and stores in float32 as apex amp does for the reference.  bench.py records it.
+    rows_log_softmax = True
+
     def __init__(self, ch=64):
         super().__init__(nn.Conv2d(ch, ch, 1), nn.LogSoftmax(dim=1))
 
     def forward(self, x):
         y = self[0](x)
-        if y.is_cuda:
+        if y.is_cuda and self.rows_log_softmax:
             # the same operator on rows, in the map's own dtype: under autocast ATen's log_softmax is an fp32 operator that writes the two
             # largest maps of the decoder as fp32 (DESIGN.md section 6; measured with the multi-lane gather backward: 61.2 -> 54.0 ms
             # per bf16 training step, profiles/r04_start_bench_train_bf16_{default,optin}.json)
@@ -466,8 +471,13 @@ class FFB6D(nn.Module):
     def forward(self, inputs, end_points=None, scale=1, taps=None):
         if not end_points:
             end_points = {}
-        if os.environ.get("FFB6D_CHECK_INDICES") == "1" and inputs['rgb'].is_cuda and 'cld_nei_idx0' in inputs:
-            self.check_indices(inputs)
+        if os.environ.get("FFB6D_CHECK_INDICES") == "1" and inputs['rgb'].is_cuda:
+            if 'cld_nei_idx0' in inputs:
+                self.check_indices(inputs)
+            else:        # the forward builds the pyramid itself: `choose` is the one index tensor that still comes from the caller
+                bad = ops.check_index_range(inputs['choose'], inputs['rgb'].shape[2] * inputs['rgb'].shape[3])
+                if bad:  # (the patch-row kernel of the last colour stage would clamp it silently: forward_pm.last_stage_at_chosen)
+                    raise IndexError(f"choose: {bad} entries outside the {inputs['rgb'].shape[2]} x {inputs['rgb'].shape[3]} image")
         rgb = inputs['rgb']
         fused = not _autograd_path(rgb, self)
         if 'cld_nei_idx0' not in inputs:

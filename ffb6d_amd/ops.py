@@ -290,6 +290,11 @@ def _rows_dt(t):
     return {torch.float32: 0, torch.bfloat16: 1}.get(t.dtype)
 
 
+# the forward of upsample_align on channels_last maps: the inference path's row kernel (True) or ATen's interpolate (False: A/B, and the
+# operator autocast would run in float32); bench.py records it
+UPSAMPLE_ROWS = True
+
+
 class _UpsampleAlign(torch.autograd.Function):
     """F.interpolate(x, size, mode='bilinear', align_corners=True) whose backward is a gather (ffb6d_bilinear_bwd_pm) instead
     of ATen's atomic scatter."""
@@ -305,7 +310,8 @@ class _UpsampleAlign(torch.autograd.Function):
         # bf16 kernel moves the decoder's largest map at 0.5 TB/s (646 us per call, profiles/r04_rocprofv3_kernel_stats_train_bf16.txt)
         B, C, IH, IW = x.shape
         vl = 8 if x.dtype == torch.bfloat16 else 4
-        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and C % vl == 0 and x.is_contiguous(memory_format=torch.channels_last):
+        if UPSAMPLE_ROWS and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and C % vl == 0 and \
+                x.is_contiguous(memory_format=torch.channels_last):
             from . import ops_pm
             rows = ops_pm.bilinear_resize(x.permute(0, 2, 3, 1), size, True)       # [B,OH,OW,C]
             return rows.permute(0, 3, 1, 2)                                         # channels_last [B,C,OH,OW]

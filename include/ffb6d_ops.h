@@ -194,7 +194,8 @@ int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, in
 /* Three shared MLPs in a row on [rows, 128] float32 rows as one launch (the layers after the first of a prediction head,
  * ffb6d.py:135-157,316-318): out = act3(W3 act2(W2 act1(W1 x + b1) + b2) + b3), W1, W2 [128,128], W3 [cout3,128] with BatchNorm
  * folded; the hidden activations stay in registers.  Weights k-chunked ([K/4][cout][4] floats: element (q, c, j) = W[c][4q + j]),
- * W3 / b3 padded with zero rows to 32 output channels; cout3 (a multiple of 4, <= 32) channels of a row are written; act codes as
+ * W3 padded with zero rows to 32 output channels (its k-chunked image is [32][32][4] whatever cout3 is; of b3 only the first cout3
+ * entries are read); cout3 (a multiple of 4, <= 32) channels of a row are written; act codes as
  * ffb6d_mlp_pm (0 none, 1 ReLU, 2 LeakyReLU(0.2)).  Per output the k order of ffb6d_mlp_pm's tile kernels. */
 int ffb6d_mlp_chain3_pm_f32(const float* x, int64_t ldx, const float* w1k, const float* b1, int act1, const float* w2k, const float* b2,
                             int act2, const float* w3k, const float* b3, int act3, float* out, int64_t ldo, int64_t rows, int64_t cout3,
