@@ -13,6 +13,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 KEYS = [("mlp_pm_kernel<2, 2, 1, 4, false>", "mlp_pm<64x256>", 2.0), ("mlp_pm_kernel<2, 2, 2, 2, false>", "mlp_pm<128x128>", 2.0),
         ("mlp_pm_kernel<1, 2, 1, 4, false>", "mlp_pm<32x256>", 2.0), ("mlp_pm_kernel<1, 1, 2, 2, false>", "mlp_pm<64x64>", 2.0),
         ("mlp_pm_kernel<2, 1, 2, 2, true>", "mlp_pm<64x32,ksplit>", 2.0), ("mlp_pm_lds_kernel", "mlp_pm<lds128x128>", 2.0),
+        ("mlp_pm_seq_kernel", "mlp_pm<seq128x128>", 2.0), ("mlp_chain3_kernel", "mlp_chain3_pm", 2.0),
         ("mlp_pm_stream_kernel", "mlp_pm<stream>", 2.0), ("att_pool_pm_kernel", "att_pool_pm", 2.0),
         ("affine_act_pm_kernel", "affine_act_pm", 2.0), ("bilinear_pm_kernel", "bilinear_resize_pm", 2.0),
         ("upsampled_patch_rows_pm_kernel", "upsampled_patch_rows_pm", 2.0),

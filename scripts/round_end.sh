@@ -6,7 +6,7 @@
 #   4. per-op / per-shape table on one stream                                      -> <tag>_hot_path_ops_by_shape_one_stream.txt
 #   5. fused LFA: level table and PMC of the level-0 launch; MFMA-busy PMC of the dominant GEMM
 #   6. training step (bf16 autocast and fp32; MIOpen's cold start alone is ~100 s: generous limits) + its kernel statistics
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "$(dirname "$0")/.." || exit 1
 REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
 bash scripts/profile_round.sh "$TAG" > /dev/null
@@ -24,12 +24,18 @@ done
   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --streams 1 --trace-all 2>&1 >/dev/null | grep -v amdgpu.ids; } > "$OUT/${TAG}_hot_path_ops_by_shape_one_stream.txt"
 timeout 200 python scripts/bench_lfa.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_lfa_levels.txt"
 bash scripts/pmc_lfa.sh 0 1 f32 > /dev/null 2>&1; cp "$OUT/lfa_pmc_0_1_f32.txt" "$OUT/${TAG}_lfa_pmc_level0_half1.txt"
-bash scripts/pmc_pm_shape.sh 1024 2304 38400 f32 7 > /dev/null 2>&1; cp "$OUT/pm_shape_pmc_1024_2304_38400_f32_7.txt" "$OUT/${TAG}_mlp_pm_lds_pmc_1024_2304_38400.txt"
+bash scripts/pmc_pm_shape.sh 1024 2304 38400 f32 0 > /dev/null 2>&1; cp "$OUT/pm_shape_pmc_1024_2304_38400_f32_0.txt" "$OUT/${TAG}_mlp_pm_seq_pmc_1024_2304_38400.txt"
 for P in bf16 fp32; do
     timeout 400 python bench.py --mode train --precision $P --steps 8 --warmup 3 --no-cpu-baseline --cudnn-benchmark 0 \
         > "$OUT/${TAG}_bench_train_$P.json" 2> "$OUT/${TAG}_bench_train_$P.err"
 done
 timeout 300 bash scripts/prof_train.sh --precision bf16 > /dev/null 2>&1; cp "$OUT/train_kernels.txt" "$OUT/${TAG}_rocprofv3_kernel_stats_train_bf16.txt"; cp "$OUT/train_under_rocprof.json" "$OUT/${TAG}_bench_train_bf16_under_rocprof.json"
+# round 5: exact-KNN PMC, pose solver (bench + kernel statistics), input pipeline
+bash scripts/pmc_knn.sh "$TAG" > /dev/null 2>&1
+timeout 200 python scripts/bench_pose.py > "$OUT/${TAG}_pose_bench.json" 2> "$OUT/${TAG}_pose_bench.err"
+( cd /tmp && rm -rf /tmp/prof_pose && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_pose -o k -- python "$REPO/scripts/bench_pose.py" --steps 4 > /dev/null 2> "$OUT/${TAG}_pose_prof.err"
+  DB=$(find /tmp/prof_pose -name '*.db' | head -1); python "$REPO/scripts/rocpd_stats.py" "$DB" --top 25 > "$OUT/${TAG}_pose_kernels.txt" 2>&1 )
+timeout 120 python scripts/bench_inputs.py > "$OUT/${TAG}_inputs_bench.json" 2> "$OUT/${TAG}_inputs_bench.err"
 python -c "
 import json
 for n in ('default', 'config4', 'config5'):
