@@ -56,6 +56,7 @@ SIGNATURES = {
     "ffb6d_affine_relu_maxpool_pm": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "ffb6d_bilinear_resize_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_mlp_chain3_pm_f32": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _vp]),
+    "ffb6d_mlp_chain3_pm_bf16": (_i32, [_vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _vp]),
     "ffb6d_upsampled_patch_rows_pm": (_i32, [_i32, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "ffb6d_posenc_mlp_pm": (_i32, [_i32, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp, _i64, _i64, _i32, _i64, _vp]),
     "ffb6d_lfa_pm": (_i32, [_i32, _i32, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _i64,

@@ -97,12 +97,12 @@ def out_padded(m, cout_to, dt=F32):
     return cached(m, "outpad%d%s" % (cout_to, dt), mlp_sources(m), build)
 
 
-def kc_padded(m, cout_to):
-    """out_padded(m, cout_to) in float32 with the weight k-chunked (ops_pm.k_chunked): the last layer of csrc/mlp_chain.hip"""
+def kc_padded(m, cout_to, dt=F32, perm=False):
+    """out_padded(m, cout_to) with the weight k-chunked (ops_pm.k_chunked): the last layer of csrc/mlp_chain.hip"""
     def build():
-        w, b = out_padded(m, cout_to, F32)
-        return ops_pm.k_chunked(w), b
-    return cached(m, "kcpad%d" % cout_to, mlp_sources(m), build)
+        w, b = out_padded(m, cout_to, dt)
+        return ops_pm.k_chunked(w, perm), b
+    return cached(m, "kcpad%d%s%d" % (cout_to, dt, perm), mlp_sources(m), build)
 
 
 def split(m, k1, dt=F32):
@@ -142,7 +142,7 @@ HEADS_ALIGN_LAST = True
 # ... and the keypoint head on the side stream while the other two run on main (only with two_streams)
 HEADS_ON_BOTH_STREAMS = True
 # ... and the three layers after the first of each head (128 -> 128 -> 128 -> c) as one launch with the hidden activations in
-# registers (csrc/mlp_chain.hip; fp32 only)
+# registers (csrc/mlp_chain.hip; fp32, and bf16 since round 5)
 HEADS_CHAIN_FUSED = True
 # The long-row fp32 GEMMs (p2r fusion, PSP bottleneck, z GEMMs, the heads' stacked first layer) in the tile-sequence form
 # (csrc/mlp_pm.hip: mlp_pm_seq_kernel -- a finished tile's epilogue rides between the MFMAs of the next tile of the same workgroup);
@@ -151,12 +151,12 @@ GEMM_SEQ_FORM = True
 LFA_WIDTHS = (32, 64, 128, 256)
 
 
-def folded_kc(m, dt):
+def folded_kc(m, dt, perm=False):
     """folded(m) with the weight in the k-chunked layout of the fused LFA kernel's output MLP (ops_pm.k_chunked)"""
     def build():
         w, b = folded(m, dt=dt)
-        return ops_pm.k_chunked(w), b
-    return cached(m, "kc%s" % dt, mlp_sources(m), build)
+        return ops_pm.k_chunked(w, perm), b
+    return cached(m, "kc%s%d" % (dt, perm), mlp_sources(m), build)
 
 
 def building_block(bb, xyz, f_pc, nei):
@@ -587,12 +587,14 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
         """the derived weights of a head's remaining layers (folded / k-chunked / padded: cached on the modules) -- built HERE, on the
         main stream, so that cached tensors always belong to main's allocator pool even when the head itself runs on the side stream"""
         layers = list(seq)[1:]
-        if HEADS_CHAIN_FUSED and y.dtype == torch.float32 and len(layers) == 3 and y.shape[-1] == 128 and \
+        if HEADS_CHAIN_FUSED and y.dtype in (torch.float32, torch.bfloat16) and len(layers) == 3 and y.shape[-1] == 128 and \
                 [tuple(m.conv.weight.shape[:2]) for m in layers[:2]] == [(128, 128)] * 2 and layers[2].conv.weight.shape[1] == 128 \
                 and layers[2].conv.weight.shape[0] <= 32 and all(m.act_code in (0, 1, 2) for m in layers):
             # the three remaining layers as one launch, hidden activations in registers (csrc/mlp_chain.hip)
             cout = layers[2].conv.weight.shape[0]
-            parts = [folded_kc(m, F32) + (m.act_code,) for m in layers[:2]] + [kc_padded(layers[2], 32) + (layers[2].act_code,)]
+            perm = y.dtype == torch.bfloat16        # bf16: layers 2 and 3 take k in the order the accumulators supply it (csrc/mlp_chain.hip)
+            parts = [folded_kc(layers[0], y.dtype) + (layers[0].act_code,), folded_kc(layers[1], y.dtype, perm) + (layers[1].act_code,),
+                     kc_padded(layers[2], 32, y.dtype, perm) + (layers[2].act_code,)]
             return ("chain", layers, parts, cout)
         last, cout = layers[-1], layers[-1].conv.weight.shape[0]
         mult = 16 // y.element_size()

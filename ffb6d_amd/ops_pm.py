@@ -221,34 +221,48 @@ def xyz_table(xyz):
     return torch.nn.functional.pad(xyz.detach().float(), (0, 1)).contiguous()
 
 
-def k_chunked(w):
+def k_chunked(w, perm=False):
     """[cout, d] weight -> [d / VL, cout, VL] (VL = 16 bytes of consecutive k): the layout csrc/lfa_pm.hip reads the output
-    MLP's weight in (one coalesced 16-byte load per channel and k-chunk)."""
+    MLP's weight in (one coalesced 16-byte load per channel and k-chunk).
+    perm (bfloat16, d a multiple of 32): the chunks in the order the accumulators of a 32x32x16 MFMA layer supply k in
+    (csrc/mlp_chain.hip): chunk 2m + h holds the input channels base + (0..3), base + 8 + (0..3), base = 32 (m >> 1) + 16 (m & 1) + 4 h."""
     vl = 16 // w.element_size()
     cout, d = w.shape
-    return w.detach().reshape(cout, d // vl, vl).permute(1, 0, 2).contiguous()
+    w = w.detach()
+    if perm:
+        if vl != 8 or d % 32:
+            raise ValueError("the permuted chunk order is the bfloat16 chain's: 8 k per chunk, d a multiple of 32")
+        q = torch.arange(d // 8, device=w.device)
+        m, h = q // 2, q % 2
+        base = 32 * (m // 2) + 16 * (m % 2) + 4 * h
+        off = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11], device=w.device)
+        w = w[:, (base[:, None] + off[None, :]).reshape(-1)]
+    return w.reshape(cout, d // vl, vl).permute(1, 0, 2).contiguous()
 
 
 def mlp_chain3(x, layer1, layer2, layer3, cout3):
     """Three shared MLPs in a row as one launch (csrc/mlp_chain.hip; the layers after the first of a prediction head,
-    ffb6d.py:135-157): x [..., 128] float32 rows (a channel slice of a wider row buffer is fine); layer_i = (W k-chunked, bias, act)
-    with W1, W2 = k_chunked([128,128]), W3 = k_chunked([32,128]) (rows >= cout3 zero), biases float32 [128], [128], [32] -> [..., cout3]."""
+    ffb6d.py:135-157): x [..., 128] float32 or bfloat16 rows (a channel slice of a wider row buffer is fine); layer_i = (W k-chunked, bias,
+    act) with W1, W2 = k_chunked([128,128]), W3 = k_chunked([32,128]) (rows >= cout3 zero) of x's dtype -- in bfloat16 W2 and W3 with
+    perm=True --, biases float32 [128], [128], [32] -> [..., cout3] of x's dtype."""
     _need_gpu(x)
     lib = _lib.load()
     a, ldx = rows_view(x.detach())
-    if x.dtype != torch.float32 or a.shape[1] != 128:
-        raise ValueError("mlp_chain3 takes float32 rows of 128 channels")
+    if x.dtype not in (torch.float32, torch.bfloat16) or a.shape[1] != 128:
+        raise ValueError("mlp_chain3 takes float32 / bfloat16 rows of 128 channels")
+    vl = 16 // x.element_size()
     (w1, b1, a1), (w2, b2, a2), (w3, b3, a3) = layer1, layer2, layer3
-    for w, b, shape, n in ((w1, b1, (32, 128, 4), 128), (w2, b2, (32, 128, 4), 128), (w3, b3, (32, 32, 4), 32)):
-        if tuple(w.shape) != shape or w.dtype != torch.float32 or not w.is_contiguous() or b.dtype != torch.float32 or b.numel() != n:
-            raise ValueError(f"k-chunked float32 weight {shape} and float32 bias [{n}] expected, got {tuple(w.shape)} / {tuple(b.shape)}")
+    for w, b, shape, n in ((w1, b1, (128 // vl, 128, vl), 128), (w2, b2, (128 // vl, 128, vl), 128), (w3, b3, (128 // vl, 32, vl), 32)):
+        if tuple(w.shape) != shape or w.dtype != x.dtype or not w.is_contiguous() or b.dtype != torch.float32 or b.numel() != n:
+            raise ValueError(f"k-chunked {x.dtype} weight {shape} and float32 bias [{n}] expected, got {tuple(w.shape)} {w.dtype} / {tuple(b.shape)}")
     rows = a.shape[0]
-    out = torch.empty(tuple(x.shape[:-1]) + (int(cout3),), dtype=torch.float32, device=x.device)
-    nbytes = 4 * (rows * (128 + int(cout3)) + 2 * 128 * 128 + 32 * 128)
+    out = torch.empty(tuple(x.shape[:-1]) + (int(cout3),), dtype=x.dtype, device=x.device)
+    nbytes = x.element_size() * (rows * (128 + int(cout3)) + 2 * 128 * 128 + 32 * 128)
+    fn = lib.ffb6d_mlp_chain3_pm_bf16 if x.dtype == torch.bfloat16 else lib.ffb6d_mlp_chain3_pm_f32
     with torch.cuda.device(x.device), _lib.traced("mlp_chain3_pm", nbytes, (128, int(cout3), rows)):
-        rc = lib.ffb6d_mlp_chain3_pm_f32(a.data_ptr(), ldx, w1.data_ptr(), b1.data_ptr(), int(a1), w2.data_ptr(), b2.data_ptr(), int(a2),
-                                         w3.data_ptr(), b3.data_ptr(), int(a3), out.data_ptr(), int(cout3), rows, int(cout3), _stream(x))
-    _lib.check(rc, "ffb6d_mlp_chain3_pm_f32")
+        rc = fn(a.data_ptr(), ldx, w1.data_ptr(), b1.data_ptr(), int(a1), w2.data_ptr(), b2.data_ptr(), int(a2),
+                w3.data_ptr(), b3.data_ptr(), int(a3), out.data_ptr(), int(cout3), rows, int(cout3), _stream(x))
+    _lib.check(rc, "ffb6d_mlp_chain3_pm")
     return out
 
 

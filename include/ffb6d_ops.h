@@ -200,6 +200,14 @@ int ffb6d_bilinear_resize_pm(int dtype, const void* in, void* out, int64_t B, in
 int ffb6d_mlp_chain3_pm_f32(const float* x, int64_t ldx, const float* w1k, const float* b1, int act1, const float* w2k, const float* b2,
                             int act2, const float* w3k, const float* b3, int act3, float* out, int64_t ldo, int64_t rows, int64_t cout3,
                             ffb6d_stream_t stream);
+/* bfloat16 twin (round 5): rows, weights and output bfloat16, biases float32, accumulation and epilogue arithmetic float32, the hidden
+ * activations rounded to bfloat16 where the separate launches would store them.  Weights k-chunked in chunks of 8 ([K/8][cout][8]); W1 in
+ * the natural k order, W2 and W3 with their chunks PERMUTED to the order the accumulators of the previous layer supply k in: chunk 2m + h
+ * (m = 0..7, h = 0..1) holds the input channels base + (0..3), base + 8 + (0..3) with base = 32 (m >> 1) + 16 (m & 1) + 4 h
+ * (ffb6d_amd.ops_pm.k_chunked(w, perm=True)). */
+int ffb6d_mlp_chain3_pm_bf16(const void* x, int64_t ldx, const void* w1k, const float* b1, int act1, const void* w2k, const float* b2,
+                             int act2, const void* w3k, const float* b3, int act3, void* out, int64_t ldo, int64_t rows, int64_t cout3,
+                             ffb6d_stream_t stream);
 /* PSPUpsample's convolution where its output is read (pspnet.py:34-45; the last colour stage feeds the heads only through the `choose`
  * pick, ffb6d.py:302-312): out [B*P, 9, C] = the 3x3 patches of the align_corners bilinear up-sampling of in [B,IH,IW,C] to OH x OW
  * around the picked pixels idx [B*P] (flat Y*OW + X within the frame; int32 / int64), tap-major, zeros outside the map -- the operand

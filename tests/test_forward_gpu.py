@@ -289,7 +289,7 @@ def test_forward_builds_the_index_pyramid_itself_when_it_is_missing(device, two_
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_head_forms_equal_the_dense_last_stage(device, precision, n_pts=12288, height=480, width=640, n_frames=2):
     """forward_pm's forms around the prediction heads -- the last colour stage evaluated at the picked pixels only
-    (LAST_STAGE_AT_CHOSEN), first layers as one stacked GEMM, the remaining layers of a head as one launch (fp32), keypoint head on the side stream -- against the
+    (LAST_STAGE_AT_CHOSEN), first layers as one stacked GEMM, the remaining layers of a head as one launch, keypoint head on the side stream -- against the
     same network with all of them off (the full 480 x 640 map, then the `choose` pick; ffb6d.py:302-318).  fp32: the hot-path bar
     (the K = 576 GEMM sums the convolution's products in another order than the dense path); bf16: the bf16 bar of the whole-forward parity tests (5e-2 of the range)."""
     from ffb6d_amd import forward_pm
@@ -312,7 +312,7 @@ def test_head_forms_equal_the_dense_last_stage(device, precision, n_pts=12288, h
             calls, chain = [], forward_pm.ops_pm.mlp_chain3
             forward_pm.ops_pm.mlp_chain3 = lambda *a, **k: (calls.append(1), chain(*a, **k))[1]
             got = {k: v.float() for k, v in run().items()}
-            assert len(calls) == (3 if precision == "fp32" else 0)          # the fused chain is an fp32 kernel
+            assert len(calls) == 3                                           # the fused chain: one launch per head, fp32 and (round 5) bf16
     finally:
         forward_pm.ops_pm.mlp_chain3 = chain
         for n, v in keep.items():

@@ -147,6 +147,42 @@ def test_mlp_chain3_matches_the_separate_layers(device, rows, cout, acts, sliced
     assert float((got[:, :cout] - y).abs().max()) <= 1e-6 * scale
 
 
+@pytest.mark.parametrize("rows,cout,acts,sliced", [(517, 22, (1, 1, 0), True), (128, 3, (1, 2, 0), False), (33, 24, (0, 1, 1), True),
+                                                    (100000, 22, (1, 1, 0), True)])
+def test_mlp_chain3_bf16_matches_the_separate_layers(device, rows, cout, acts, sliced):
+    """the bfloat16 chain (round 5): layers 2 and 3 take k in the order the accumulators of the previous layer supply it (weights
+    k-chunked with perm=True).  Against float64 of the same bf16-rounded operands WITH the hidden activations rounded to bf16 where the
+    chain (and the separate launches) round them, and against three ffb6d_mlp_pm launches."""
+    if rows > 1000 and torch.device(device).type == "cpu":
+        pytest.skip("the large case is for the device")
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(rows + cout + 1)
+    wide = torch.randn(rows, 384, generator=g).to(BF)
+    x = (wide[:, 128:256] if sliced else wide[:, :128].contiguous()).to(device)
+    ws = [(torch.randn(128, 128, generator=g) / 11).to(BF), (torch.randn(128, 128, generator=g) / 11).to(BF), (torch.randn(cout, 128, generator=g) / 11).to(BF)]
+    bs = [torch.randn(128, generator=g), torch.randn(128, generator=g), torch.randn(cout, generator=g)]
+    cpad = -(-cout // 4) * 4
+    w3p, b3p = torch.zeros(32, 128, dtype=BF), torch.zeros(32)
+    w3p[:cout], b3p[:cout] = ws[2], bs[2]
+    parts = [(ops_pm.k_chunked(w, perm).to(device), b.to(device), a)
+             for w, b, a, perm in zip([ws[0], ws[1], w3p], [bs[0], bs[1], b3p], acts, (False, True, True))]
+    got = ops_pm.mlp_chain3(x, parts[0], parts[1], parts[2], cpad)
+    assert got.dtype == BF and got.shape == (rows, cpad) and not got[:, cout:].any()
+    y, y64 = x, x.double().cpu()
+    for i, (w, b, a) in enumerate(zip(ws, bs, acts)):
+        y = ops_pm.mlp(y, w.to(device), b.to(device), a)
+        y64 = y64 @ w.double().t() + b.double()
+        y64 = torch.relu(y64) if a == 1 else (torch.nn.functional.leaky_relu(y64, 0.2) if a == 2 else y64)
+        if i < 2:
+            y64 = y64.to(BF).double()                          # the hidden activations are bf16 in both forms
+    # a hidden value that sits on a bf16 rounding boundary may round the other way (fp32 sums in another order): compare on the
+    # output's scale with the bf16 bar of the GEMM tests
+    want = y64
+    tol = 2.0 ** -7 * want.abs() + 2.0 ** -7 * float(want.abs().mean())
+    assert not bool(((got[:, :cout].double().cpu() - want).abs() > tol).any()), float((got[:, :cout].double().cpu() - want).abs().max())
+    assert not bool(((got[:, :cout].double() - y.double()).abs().cpu() > tol).any())
+
+
 @pytest.mark.parametrize("B,h,w,C,P,idt", [(2, 6, 8, 8, 40, torch.int64), (1, 5, 7, 16, 70, torch.int32), (3, 1, 1, 8, 4, torch.int64),
                                            (2, 12, 16, 64, 333, torch.int64)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

@@ -102,6 +102,13 @@ def test_mlp_chain3_on_the_emulator(emu, rows, cout, acts, sliced):
     TPM.test_mlp_chain3_matches_the_separate_layers(torch.device("cpu"), rows, cout, acts, sliced)
 
 
+@pytest.mark.parametrize("rows,cout,acts,sliced", [(517, 22, (1, 1, 0), True), (128, 3, (1, 2, 0), False), (33, 24, (0, 1, 1), True)])
+def test_mlp_chain3_bf16_on_the_emulator(emu, rows, cout, acts, sliced):
+    """csrc/mlp_chain.hip: tests/test_pm_gpu.py's own check with CPU tensors"""
+    import test_pm_gpu as TPM
+    TPM.test_mlp_chain3_bf16_matches_the_separate_layers(torch.device("cpu"), rows, cout, acts, sliced)
+
+
 @pytest.mark.parametrize("B,h,w,C,P,idt", [(2, 6, 8, 8, 40, torch.int64), (1, 5, 7, 16, 70, torch.int32), (3, 1, 1, 8, 4, torch.int64)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_upsampled_patch_rows_on_the_emulator(emu, B, h, w, C, P, idt, dt):
