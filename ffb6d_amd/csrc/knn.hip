@@ -19,7 +19,7 @@
 //     blockIdx.y and the per-split sorted lists are merged by a second tiny kernel
 //     (splits are merged in index order, preserving the lowest-index tie rule).
 //
-// Since knn_pruned.hip exists this scan only serves SMALL support sets (< 2048 points; larger ones
+// Since knn_pruned.hip exists this scan only serves SMALL support sets (< 512 points since round 5, < 2048 before; larger ones
 // are Morton-prepared and searched with tile pruning) and the host-pointer cpp_knn* entry points
 // route through ffb6d_knn_batch_device, i.e. through whichever kernel fits the shape.
 //
@@ -483,8 +483,10 @@ extern "C" {
 int ffb6d_knn_uses_pruning(int64_t B, int64_t S, int64_t Q, int K)
 {
     // sorting + tile boxes pay off once the support set is a few tiles long; tiny sets are
-    // cheaper to scan outright
-    return (B >= 1 && Q >= 1 && K >= 1 && K <= 32 && S >= 2048) ? 1 : 0;
+    // cheaper to scan outright.  Round 5 measured the threshold on the 22 searches of a pyramid (bs = 8): 2048 -> 512 moves the
+    // 768-point supports (five searches, among them 76 800 grid queries against 768 points: 148 -> 127 us, and the K = 16 self search
+    // of level 2: 108 -> 35 us) to the Morton-ordered kernels: pyramid alone 908 -> 808 us, same indices; 256 gains nothing more.
+    return (B >= 1 && Q >= 1 && K >= 1 && K <= 32 && S >= 512) ? 1 : 0;
 }
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
