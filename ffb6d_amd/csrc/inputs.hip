@@ -7,8 +7,10 @@
 //       cld / rgb_pt / nrm_pt = per-point rows of the xyz, colour and normal images; cld_rgb_nrm = their concatenation
 //
 // Here, without any host round trip (the reference's nonzero / shuffle run in numpy inside DataLoader workers):
-//   1. every pixel gets a 64-bit sort key  frame << 32 | (valid ? hash32(seed, frame, pixel) : 0xffffffff);
-//   2. ONE radix sort over all frames (rocprim) puts each frame's valid pixels first, in uniformly random order;
+//   1. every pixel gets a 32-bit sort key  valid ? hash32(seed, frame, pixel) : 0xffffffff;
+//   2. ONE stable segmented radix sort (csrc/seg_sort.hip: the frames are the segments; round 5 -- rocprim::radix_sort_pairs on 64-bit
+//      (frame, hash) keys before: the same permutation, 0.68 -> see profiles/r05_inputs_bench.json) puts each frame's valid pixels
+//      first, in uniformly random order;
 //   3. the first N entries of a frame's segment are the sample: a uniformly random N-subset in uniformly random order.
 //      A frame with fewer than N valid pixels repeats its permutation cyclically (the reference repeats the ascending
 //      list and shuffles afterwards: same multiset up to which pixels get the extra copy, and the prefix of any length --
@@ -18,7 +20,7 @@
 #include "common.h"
 #include "ffb6d_ops.h"
 
-#include <rocprim/rocprim.hpp>
+#include "seg_sort.h"
 
 namespace ffb6d {
 namespace {
@@ -31,23 +33,38 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)     // murmur3 finaliser: 
     return x;
 }
 
+// A workgroup keys 2048 consecutive pixels of a frame and adds its count of valid ones to n_valid[b] with ONE atomic (round 5: one
+// atomic per wave on eight addresses was 38 400 serialised device-scope atomics per batch -- 437 us of a 24-us kernel,
+// profiles/r05_inputs_bench.json).
+constexpr int KEYS_PER_BLOCK = 2048;
 __global__ void __launch_bounds__(BLK)
-sample_keys_kernel(const float* __restrict__ depth, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals,
+sample_keys_kernel(const float* __restrict__ depth, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                    int32_t* __restrict__ n_valid, int HW, float min_depth, uint32_t seed_lo, uint32_t seed_hi)
 {
+    __shared__ int wave_count[BLK / 64];
     const int b = blockIdx.y;
-    const int pix = blockIdx.x * BLK + threadIdx.x;
-    bool valid = false;
-    if (pix < HW) {
-        valid = depth[(size_t)b * HW + pix] > min_depth;           // NaN compares false: invalid
-        const uint32_t h = mix32(mix32((uint32_t)pix ^ seed_lo) + 0x9e3779b9u * (uint32_t)(b + 1) + seed_hi);
-        // valid keys stay below 0xffffffff so that every invalid pixel sorts behind every valid one
-        const uint32_t k = valid ? (h == 0xffffffffu ? 0xfffffffeu : h) : 0xffffffffu;
-        keys[(size_t)b * HW + pix] = ((unsigned long long)b << 32) | k;
-        vals[(size_t)b * HW + pix] = (uint32_t)pix;
+    int mine = 0;
+#pragma unroll
+    for (int r = 0; r < KEYS_PER_BLOCK / BLK; ++r) {
+        const int pix = blockIdx.x * KEYS_PER_BLOCK + r * BLK + threadIdx.x;
+        bool valid = false;
+        if (pix < HW) {
+            valid = depth[(size_t)b * HW + pix] > min_depth;           // NaN compares false: invalid
+            const uint32_t h = mix32(mix32((uint32_t)pix ^ seed_lo) + 0x9e3779b9u * (uint32_t)(b + 1) + seed_hi);
+            // valid keys stay below 0xffffffff so that every invalid pixel sorts behind every valid one
+            keys[(size_t)b * HW + pix] = valid ? (h == 0xffffffffu ? 0xfffffffeu : h) : 0xffffffffu;
+            vals[(size_t)b * HW + pix] = (uint32_t)pix;
+        }
+        mine += (int)__popcll(__ballot(valid));                        // (the wave's count: the same number in every lane)
     }
-    const unsigned long long ball = __ballot(valid);
-    if ((threadIdx.x & 63) == 0 && ball) atomicAdd(n_valid + b, (int)__popcll(ball));
+    if ((threadIdx.x & 63) == 0) wave_count[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < BLK / 64; ++w) total += wave_count[w];
+        if (total) atomicAdd(n_valid + b, total);
+    }
 }
 
 // choose[b,j] = sorted pixel (j mod n_valid[b]); cld [B,N,3] and cld_rgb_nrm [B,9,N] gathered from the images
@@ -140,19 +157,26 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct SampleLayout { size_t keys_in, keys_out, vals_in, vals_out, temp, temp_bytes, total; };
 
+segsort::Plan sample_plan(int64_t B, int64_t HW)
+{
+    segsort::Plan p;
+    p.ngroups = 1;
+    p.B = (int)B;
+    p.g[0].pos0 = 0;
+    p.g[0].S = (int)HW;
+    return p;
+}
+
 SampleLayout sample_layout(int64_t B, int64_t HW)
 {
     SampleLayout L;
     const size_t n = (size_t)B * HW;
     size_t off = 0;
-    L.keys_in = off; off += align256(n * 8);
-    L.keys_out = off; off += align256(n * 8);
+    L.keys_in = off; off += align256(n * 4);
+    L.keys_out = off; off += align256(n * 4);
     L.vals_in = off; off += align256(n * 4);
     L.vals_out = off; off += align256(n * 4);
-    size_t need = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, need, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
-                                    (uint32_t*)nullptr, n, 0u, 64u, (hipStream_t) nullptr);
-    L.temp = off; L.temp_bytes = align256(need + 256); off += L.temp_bytes;
+    L.temp = off; L.temp_bytes = align256(segsort::temp_bytes(sample_plan(B, HW)) + 256); off += L.temp_bytes;
     L.total = off;
     return L;
 }
@@ -186,24 +210,25 @@ extern "C" int ffb6d_sample_points_f32(const float* depth, float min_depth, cons
         return set_error(FFB6D_ERR_WORKSPACE, "sample_points: workspace of %zu bytes required, got %zu", L.total,
                          workspace ? workspace_bytes : (size_t)0);
     char* ws = static_cast<char*>(workspace);
-    auto* keys_in = reinterpret_cast<unsigned long long*>(ws + L.keys_in);
-    auto* keys_out = reinterpret_cast<unsigned long long*>(ws + L.keys_out);
+    auto* keys_in = reinterpret_cast<uint32_t*>(ws + L.keys_in);
+    auto* keys_out = reinterpret_cast<uint32_t*>(ws + L.keys_out);
     auto* vals_in = reinterpret_cast<uint32_t*>(ws + L.vals_in);
     auto* vals_out = reinterpret_cast<uint32_t*>(ws + L.vals_out);
     hipStream_t st = as_stream(stream);
     FFB6D_HIP_TRY(hipMemsetAsync(n_valid, 0, (size_t)B * sizeof(int32_t), st));
-    hipLaunchKernelGGL(sample_keys_kernel, dim3((unsigned)ceil_div(HW, BLK), (unsigned)B), dim3(BLK), 0, st, depth, keys_in, vals_in,
+    hipLaunchKernelGGL(sample_keys_kernel, dim3((unsigned)ceil_div(HW, KEYS_PER_BLOCK), (unsigned)B), dim3(BLK), 0, st, depth, keys_in, vals_in,
                        n_valid, (int)HW, min_depth, (uint32_t)seed, (uint32_t)(seed >> 32));
-    unsigned end_bit = 32;
-    while ((1LL << (end_bit - 32)) < B) ++end_bit;
-    size_t have = L.temp_bytes;
-    FFB6D_HIP_TRY(rocprim::radix_sort_pairs(ws + L.temp, have, keys_in, keys_out, vals_in, vals_out, (size_t)(B * HW), 0u, end_bit, st));
+    segsort::Plan plan = sample_plan(B, HW);
+    bool in_alt = false;
+    const hipError_t se = segsort::sort_pairs(plan, keys_in, vals_in, keys_out, vals_out, 32, ws + L.temp, L.temp_bytes, st, &in_alt);
+    if (se != hipSuccess) return set_error(FFB6D_ERR_HIP, "sample_points: segmented sort failed: %s", hipGetErrorString(se));
+    const uint32_t* sorted = in_alt ? vals_out : vals_in;
     const dim3 grid((unsigned)ceil_div(N, BLK), (unsigned)B);
     if (rgb_is_u8)
-        hipLaunchKernelGGL((assemble_points_kernel<uint8_t>), grid, dim3(BLK), 0, st, vals_out, n_valid, xyz,
+        hipLaunchKernelGGL((assemble_points_kernel<uint8_t>), grid, dim3(BLK), 0, st, sorted, n_valid, xyz,
                            static_cast<const uint8_t*>(rgb), nrm, reinterpret_cast<long long*>(choose), cld, cld_rgb_nrm, (int)HW, (int)N);
     else
-        hipLaunchKernelGGL((assemble_points_kernel<float>), grid, dim3(BLK), 0, st, vals_out, n_valid, xyz,
+        hipLaunchKernelGGL((assemble_points_kernel<float>), grid, dim3(BLK), 0, st, sorted, n_valid, xyz,
                            static_cast<const float*>(rgb), nrm, reinterpret_cast<long long*>(choose), cld, cld_rgb_nrm, (int)HW, (int)N);
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;

@@ -1,6 +1,6 @@
 // ffb6d_amd/csrc/seg_sort.hip -- stable segmented LSD radix sort of (u32 key, u32 value) pairs for gfx950; see seg_sort.h.
 //
-// One 8-bit digit per pass, two launches per pass:
+// One 8-bit digit per pass, two launches per pass (three when a segment has more than 48 chunks: seg_prefix_kernel):
 //   1. seg_hist_kernel:    a workgroup counts the digits of its chunk (2048 consecutive keys of one segment) -> hist[workgroup][256];
 //   2. seg_scatter_kernel: thread d of a workgroup adds up the counts of digit d over the segment's workgroups (all of them: the digit's
 //      total; those in front: what precedes this chunk) -- at most a few dozen 1 KB rows, L2 resident; a 256-wide exclusive scan of the
@@ -58,9 +58,36 @@ seg_hist_kernel(const Plan p, const uint32_t* __restrict__ keys, int shift, uint
     hist[(size_t)blockIdx.x * 256 + threadIdx.x] = cnt[threadIdx.x];
 }
 
+// Long segments (an image of 307 200 pixels is 150 chunks): the sums over a segment's chunks are made ONCE per segment instead of once
+// per chunk -- hist[chunk][d] becomes the count of digit d in the chunks in front of it, totals[segment][d] the digit's total.
+// One workgroup per segment, thread = digit, eight loads in flight.
+__global__ void __launch_bounds__(BLK)
+seg_prefix_kernel(const Plan p, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals)
+{
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUPS; ++i)
+        if (i < p.ngroups && (int)blockIdx.x >= i * p.B) g = i;            // segments are numbered group-major: g * B + b
+    const int b = blockIdx.x - g * p.B;
+    const int nblk = (p.g[g].S + CHUNK - 1) / CHUNK;
+    uint32_t* h = hist + ((size_t)p.blk0[g] + (size_t)b * nblk) * 256 + threadIdx.x;
+    uint32_t run = 0;
+    int c = 0;
+    for (; c + 8 <= nblk; c += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = h[(size_t)(c + u) * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { h[(size_t)(c + u) * 256] = run; run += v[u]; }
+    }
+    for (; c < nblk; ++c) { const uint32_t v = h[(size_t)c * 256]; h[(size_t)c * 256] = run; run += v; }
+    totals[(size_t)blockIdx.x * 256 + threadIdx.x] = run;
+}
+
+template <bool PREFIXED>
 __global__ void __launch_bounds__(BLK)
 seg_scatter_kernel(const Plan p, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t* __restrict__ keys_out,
-                   uint32_t* __restrict__ vals_out, int shift, const uint32_t* __restrict__ hist)
+                   uint32_t* __restrict__ vals_out, int shift, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals)
 {
     __shared__ uint32_t off[256];              // first output slot (inside the segment) of this chunk's keys with digit d
     __shared__ uint32_t wcnt[4][256];          // per wave: keys with digit d seen so far; after the barrier: keys of the waves in front
@@ -69,12 +96,17 @@ seg_scatter_kernel(const Plan p, const uint32_t* __restrict__ keys, const uint32
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {
         // digit d = threadIdx.x: total over the segment's chunks, and what the chunks in front of this one hold
-        const uint32_t* h = hist + (size_t)(blockIdx.x - w.c) * 256 + threadIdx.x;
         uint32_t total = 0, before = 0;
-        for (int c = 0; c < w.nblk; ++c) {
-            const uint32_t v = h[(size_t)c * 256];
-            total += v;
-            before += c < w.c ? v : 0u;
+        if constexpr (PREFIXED) {              // seg_prefix_kernel has run
+            before = hist[(size_t)blockIdx.x * 256 + threadIdx.x];
+            total = totals[((size_t)w.g * p.B + w.b) * 256 + threadIdx.x];
+        } else {
+            const uint32_t* h = hist + (size_t)(blockIdx.x - w.c) * 256 + threadIdx.x;
+            for (int c = 0; c < w.nblk; ++c) {
+                const uint32_t v = h[(size_t)c * 256];
+                total += v;
+                before += c < w.c ? v : 0u;
+            }
         }
         // exclusive scan of `total` over the 256 digits: inside the wave by shuffles, across the four waves through LDS
         uint32_t incl = total;
@@ -163,7 +195,7 @@ int plan_blocks(Plan& p)
 size_t temp_bytes(const Plan& p)
 {
     Plan q = p;
-    return (size_t)plan_blocks(q) * 256 * sizeof(uint32_t);
+    return ((size_t)plan_blocks(q) + (size_t)p.ngroups * p.B) * 256 * sizeof(uint32_t);      // chunk histograms + per-segment totals
 }
 
 hipError_t sort_pairs(Plan& p, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt, int key_bits, void* temp,
@@ -172,15 +204,26 @@ hipError_t sort_pairs(Plan& p, uint32_t* keys, uint32_t* vals, uint32_t* keys_al
     const int nblk = plan_blocks(p);
     *sorted_in_alt = false;
     if (nblk == 0 || key_bits <= 0) return hipSuccess;
-    if (temp_size < (size_t)nblk * 256 * sizeof(uint32_t)) return hipErrorInvalidValue;
+    const int nseg = p.ngroups * p.B;
+    if (temp_size < ((size_t)nblk + nseg) * 256 * sizeof(uint32_t)) return hipErrorInvalidValue;
     uint32_t* hist = static_cast<uint32_t*>(temp);
+    uint32_t* totals = hist + (size_t)nblk * 256;
+    int longest = 0;
+    for (int i = 0; i < p.ngroups; ++i) longest = std::max(longest, (p.g[i].S + CHUNK - 1) / CHUNK);
+    const bool prefixed = longest > 48;        // beyond a few dozen chunks per segment the per-chunk sums cost more than a launch
     bool alt = false;
     for (int shift = 0; shift < key_bits; shift += 8) {
         const uint32_t* ki = alt ? keys_alt : keys;
         const uint32_t* vi = alt ? vals_alt : vals;
         hipLaunchKernelGGL(seg_hist_kernel, dim3((unsigned)nblk), dim3(BLK), 0, st, p, ki, shift, hist);
-        hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)nblk), dim3(BLK), 0, st, p, ki, vi, alt ? keys : keys_alt, alt ? vals : vals_alt,
-                           shift, hist);
+        if (prefixed) {
+            hipLaunchKernelGGL(seg_prefix_kernel, dim3((unsigned)nseg), dim3(BLK), 0, st, p, hist, totals);
+            hipLaunchKernelGGL((seg_scatter_kernel<true>), dim3((unsigned)nblk), dim3(BLK), 0, st, p, ki, vi, alt ? keys : keys_alt,
+                               alt ? vals : vals_alt, shift, hist, totals);
+        } else {
+            hipLaunchKernelGGL((seg_scatter_kernel<false>), dim3((unsigned)nblk), dim3(BLK), 0, st, p, ki, vi, alt ? keys : keys_alt,
+                               alt ? vals : vals_alt, shift, hist, totals);
+        }
         alt = !alt;
     }
     *sorted_in_alt = alt;

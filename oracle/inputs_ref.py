@@ -56,3 +56,31 @@ def depth_normal(depth_mm, fx, fy, k_size=5, distance_threshold=2000, difference
     inv = np.where(ok, np.float32(1.0) / np.where(ok, length, np.float32(1.0)), np.float32(0.0)).astype(np.float32)
     out[np.ix_(ys, xs)] = n * inv[..., None]
     return out
+
+
+def sample_order(depth, seed, min_depth=1e-6):
+    """The permutation ffb6d_sample_points_f32 documents (csrc/inputs.hip), restated: every pixel of frame b gets the 32-bit key
+    mix32(mix32(pixel ^ seed_lo) + 0x9e3779b9 * (b + 1) + seed_hi) (murmur3's finaliser; 0xffffffff is reserved for invalid pixels), the
+    frame's pixels are sorted by key, STABLY.  depth [B,H,W] float32 -> (order int64 [B,H*W], n_valid [B]): the first n_valid[b] entries
+    of order[b] are the frame's valid pixels in the sampled order (the sample is its prefix).  Test infrastructure."""
+    d = np.asarray(depth, np.float32)
+    B = d.shape[0]
+    HW = d[0].size
+    lo, hi = np.uint32(seed & 0xffffffff), np.uint32((seed >> 32) & 0xffffffff)
+
+    def mix32(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b); x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35); x ^= x >> np.uint32(16)
+        return x
+
+    order, n_valid = np.empty((B, HW), np.int64), np.empty(B, np.int64)
+    pix = np.arange(HW, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        for b in range(B):
+            valid = d[b].reshape(-1) > np.float32(min_depth)            # NaN compares false
+            h = mix32(mix32(pix ^ lo) + np.uint32((0x9e3779b9 * (b + 1)) & 0xffffffff) + hi)
+            key = np.where(valid, np.where(h == np.uint32(0xffffffff), np.uint32(0xfffffffe), h), np.uint32(0xffffffff))
+            order[b] = np.argsort(key, kind="stable")
+            n_valid[b] = int(valid.sum())
+    return order, n_valid
+

@@ -76,6 +76,24 @@ def test_sample_points_is_a_uniform_subset_and_reproducible(device):
     assert float((first[valid] / trials - p / 4).abs().max()) < 6 * (p / 4 * (1 - p / 4) / trials) ** 0.5
 
 
+@pytest.mark.parametrize("h,w,n", [(120, 160, 2048), (480, 640, 12288), (60, 80, 6000)])
+def test_sample_points_is_the_documented_permutation(device, h, w, n, frames=3):
+    """The sample IS the prefix of the frame's valid pixels sorted stably by the documented 32-bit hash (oracle/inputs_ref.sample_order):
+    pins the library's own segmented radix sort (csrc/seg_sort.hip, round 5) at the full image size -- 150 chunks per segment, the
+    path with per-segment prefix sums -- at the small size (fused sums) and with wrap-around (more samples than valid pixels)."""
+    deps = np.stack([_depth(20 + b, h, w) for b in range(frames)])
+    deps = np.nan_to_num(deps, nan=0.0, posinf=0.0)
+    if n > h * w:
+        deps[:, h // 2:, :] = 0.0
+    seed = 0x1234567_89abcdef
+    got = inputs.sample_points(torch.from_numpy(deps).to(device), n, seed=seed)
+    order, n_valid = inputs_ref.sample_order(deps, seed)
+    assert got["n_valid"].cpu().tolist() == n_valid.tolist()
+    for b in range(frames):
+        want = order[b, np.arange(n) % n_valid[b]]
+        assert np.array_equal(got["choose"][b, 0].cpu().numpy(), want), b
+
+
 def test_assemble_inputs_feeds_the_model(device):
     rng = np.random.RandomState(0)
     deps = torch.from_numpy(np.stack([_depth(7), _depth(8)])).to(device)
