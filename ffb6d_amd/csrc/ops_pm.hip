@@ -345,37 +345,40 @@ struct PspSizes { int n; int s[PSP_MAX]; int off[PSP_MAX + 1]; };
 // each horizontal bin: part[b, y, xbin, :] (fp32), xbin running over the sum(s) horizontal bins of all levels.  Pass 2: a
 // workgroup per (frame, bin) adds the rows of its vertical extent.  (One workgroup per bin cannot pull the 1x1 level's
 // 10 MB through a single CU in reasonable time; this way the map is streamed once by H*B workgroups.)
+// Round 5: a workgroup per (frame, image row, LEVEL) -- four times the workgroups, and as many threads as the row has 16-byte units
+// (512 channels = 128 units: half of a 256-thread block idled): the kernel was latency bound at 2 waves per workgroup on 480
+// workgroups (80 us for 78 MB = 0.12 of HBM).  Each level re-reads the row (L2 hits after the first).
 template <typename T>
 __global__ void __launch_bounds__(BLK)
 psp_rowsum_pm_kernel(const void* __restrict__ x, float* __restrict__ part, int H, int W, int q, int nx, PspSizes sz)
 {
     using U = Unit<T>;
     const int by = blockIdx.x;                               // b*H + y
+    const int l = blockIdx.y;                                // level
     const size_t src = (size_t)by * W * q;
-    for (int c = threadIdx.x; c < q; c += BLK) {
-        int slot = 0;
-        for (int l = 0; l < sz.n; ++l) {
-            const int s = sz.s[l];
-            for (int j = 0; j < s; ++j, ++slot) {
-                const int x0 = (j * W) / s, x1 = ((j + 1) * W + s - 1) / s;
-                float acc[U::VL];
+    const int s = sz.s[l];
+    int slot0 = 0;
+    for (int i = 0; i < l; ++i) slot0 += sz.s[i];
+    for (int c = threadIdx.x; c < q; c += blockDim.x) {
+        for (int j = 0; j < s; ++j) {
+            const int x0 = (j * W) / s, x1 = ((j + 1) * W + s - 1) / s;
+            float acc[U::VL];
 #pragma unroll
-                for (int e = 0; e < U::VL; ++e) acc[e] = 0.f;
-                for (int xx = x0; xx < x1; xx += 8) {          // 8 independent loads in flight, surplus ones are dropped
-                    U v[8];
+            for (int e = 0; e < U::VL; ++e) acc[e] = 0.f;
+            for (int xx = x0; xx < x1; xx += 8) {          // 8 independent loads in flight, surplus ones are dropped
+                U v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = U::load(x, src + (size_t)min(xx + u, x1 - 1) * q + c);
+                for (int u = 0; u < 8; ++u) v[u] = U::load(x, src + (size_t)min(xx + u, x1 - 1) * q + c);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (xx + u < x1) {
+                for (int u = 0; u < 8; ++u)
+                    if (xx + u < x1) {
 #pragma unroll
-                            for (int e = 0; e < U::VL; ++e) acc[e] += v[u].v[e];
-                        }
-                }
-                float* dst = part + (((size_t)by * nx + slot) * q + c) * U::VL;
-#pragma unroll
-                for (int e = 0; e < U::VL; ++e) dst[e] = acc[e];
+                        for (int e = 0; e < U::VL; ++e) acc[e] += v[u].v[e];
+                    }
             }
+            float* dst = part + (((size_t)by * nx + slot0 + j) * q + c) * U::VL;
+#pragma unroll
+            for (int e = 0; e < U::VL; ++e) dst[e] = acc[e];
         }
     }
 }
@@ -401,6 +404,7 @@ psp_binsum_pm_kernel(const float* __restrict__ part, float* __restrict__ out, in
     }
 }
 
+// general form (any row length): index arithmetic per thread
 template <typename T>
 __global__ void __launch_bounds__(BLK)
 psp_prior_sum_pm_kernel(const float* __restrict__ z, void* __restrict__ out, int H, int W, int q, PspSizes sz,
@@ -440,6 +444,65 @@ psp_prior_sum_pm_kernel(const float* __restrict__ z, void* __restrict__ out, int
         for (int e = 0; e < U::VL; ++e) res.v[e] += h0l * (w0l * a[e] + w1l * bq[e]) + h1l * (w0l * cc[e] + w1l * d[e]);
     }
     res.store(out, t);
+}
+
+// Round 5: the general form writes 157 MB (8 x 60 x 80 x 1024 fp32) in 117 us = 0.17 of HBM -- it is bound by the L2, not by HBM or the
+// vector unit: every output unit re-reads its 16 corner units of z (200 KB per frame: beyond the L1), 16 bytes read per byte written,
+// 21 TB/s of L2 traffic.  Here a workgroup owns XP consecutive pixels of one image row for 256 (or q) channel units: the pixel is
+// UNIFORM per iteration, so source indices and weights live on the scalar unit, and a level's four corner units stay in registers until
+// the pixel walk leaves the bin pair (every 13-80 pixels): z is read ~10x less often.  Same arithmetic per output element.
+constexpr int PSP_XP = 16;
+template <typename T>
+__global__ void __launch_bounds__(BLK)
+psp_prior_sum_row_pm_kernel(const float* __restrict__ z, void* __restrict__ out, int H, int W, int q, PspSizes sz)
+{
+    using U = Unit<T>;
+    const int x_beg = blockIdx.x * PSP_XP, x_end = min(W, x_beg + PSP_XP);
+    const int by = blockIdx.y;                                   // b * H + oy
+    const int oy = by % H;
+    const size_t b = by / H;
+    const int c = blockIdx.z * blockDim.x + threadIdx.x;         // channel unit (the launcher makes q a multiple of blockDim.x)
+    const int M = q * U::VL;
+    const float* zb = z + b * (size_t)sz.off[sz.n] * M + (size_t)c * U::VL;
+    float cor[PSP_MAX][4][U::VL];                                // corner units of every level, valid while key[l] matches
+    int key[PSP_MAX];
+#pragma unroll
+    for (int l = 0; l < PSP_MAX; ++l) key[l] = -1;
+    for (int ox = x_beg; ox < x_end; ++ox) {
+        U res;
+#pragma unroll
+        for (int e = 0; e < U::VL; ++e) res.v[e] = 0.f;
+#pragma unroll
+        for (int l = 0; l < PSP_MAX; ++l) {
+            if (l < sz.n) {
+                const int s = sz.s[l];
+                const float rh = (float)s / (float)H, rw = (float)s / (float)W;
+                const float h1r = src_index(rh, oy, false);
+                const int h1 = (int)h1r;
+                const int h1p = (h1 < s - 1) ? 1 : 0;
+                const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+                const float w1r = src_index(rw, ox, false);
+                const int w1 = (int)w1r;
+                const int w1p = (w1 < s - 1) ? 1 : 0;
+                const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+                const int k = 2 * w1 + w1p;                      // (h1, h1p are fixed for the row)
+                if (k != key[l]) {                               // uniform: the whole workgroup reloads together
+                    key[l] = k;
+                    const float* m = zb + (size_t)sz.off[l] * M;
+                    const float* src[4] = {m + (size_t)(h1 * s + w1) * M, m + (size_t)(h1 * s + w1 + w1p) * M,
+                                           m + (size_t)((h1 + h1p) * s + w1) * M, m + (size_t)((h1 + h1p) * s + w1 + w1p) * M};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int e = 0; e < U::VL; ++e) cor[l][t][e] = src[t][e];
+                }
+#pragma unroll
+                for (int e = 0; e < U::VL; ++e)
+                    res.v[e] += h0l * (w0l * cor[l][0][e] + w1l * cor[l][1][e]) + h1l * (w0l * cor[l][2][e] + w1l * cor[l][3][e]);
+            }
+        }
+        res.store(out, ((size_t)by * W + ox) * q + c);
+    }
 }
 
 int fill_sizes(PspSizes& sz, const int* sizes, int n)
@@ -662,8 +725,9 @@ int ffb6d_psp_pool_pm(int dtype, const void* x, float* out, int64_t B, int64_t H
     const int q = (int)(C / VL);
     hipStream_t st = as_stream(stream);
     DISPATCH_DT(dtype, T, {
-        hipLaunchKernelGGL((psp_rowsum_pm_kernel<T>), dim3((unsigned)(B * H)), dim3(BLK), 0, st, x, static_cast<float*>(workspace),
-                           (int)H, (int)W, q, nx, sz);
+        const int threads = std::min(BLK, (q + 63) / 64 * 64);
+        hipLaunchKernelGGL((psp_rowsum_pm_kernel<T>), dim3((unsigned)(B * H), (unsigned)sz.n), dim3(threads), 0, st, x,
+                           static_cast<float*>(workspace), (int)H, (int)W, q, nx, sz);
     })
     hipLaunchKernelGGL(psp_binsum_pm_kernel, dim3((unsigned)(B * sz.off[sz.n])), dim3(BLK), 0, st,
                        static_cast<const float*>(workspace), out, (int)H, (int)W, (int)C, nx, sz);
@@ -681,11 +745,21 @@ int ffb6d_psp_prior_sum_pm(int dtype, const float* z, void* out, int64_t B, int6
     FFB6D_REQUIRE(B >= 0 && H >= 1 && W >= 1 && M >= VL && M % VL == 0, "psp_prior_sum_pm: bad shape");
     if (B == 0) return FFB6D_OK;
     FFB6D_REQUIRE(z && out && al16(out), "psp_prior_sum_pm: bad pointer");
-    const size_t total = (size_t)B * H * W * (M / VL);
-    DISPATCH_DT(dtype, T, {
-        hipLaunchKernelGGL((psp_prior_sum_pm_kernel<T>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, as_stream(stream),
-                           z, out, (int)H, (int)W, (int)(M / VL), sz, total);
-    })
+    const int q = (int)(M / VL);
+    const size_t npix = (size_t)B * H * W;
+    if (q % 64 == 0 && (q <= BLK || q % BLK == 0) && B * H < 65536) {      // whole waves per pixel: a workgroup walks XP pixels of a row
+        const int threads = std::min(q, BLK);
+        const dim3 grid((unsigned)ceil_div(W, PSP_XP), (unsigned)(B * H), (unsigned)(q / threads));
+        DISPATCH_DT(dtype, T, {
+            hipLaunchKernelGGL((psp_prior_sum_row_pm_kernel<T>), grid, dim3(threads), 0, as_stream(stream), z, out, (int)H, (int)W, q, sz);
+        })
+    } else {
+        const size_t total = npix * q;
+        DISPATCH_DT(dtype, T, {
+            hipLaunchKernelGGL((psp_prior_sum_pm_kernel<T>), dim3((unsigned)ceil_div((int64_t)total, BLK)), dim3(BLK), 0, as_stream(stream),
+                               z, out, (int)H, (int)W, q, sz, total);
+        })
+    }
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }

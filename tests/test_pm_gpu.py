@@ -317,6 +317,17 @@ def test_colour_branch_glue_pm_matches_torch(device):
         off += s * s
     got = ops_pm.psp_prior_sum(d(z), sizes, (60, 80)).cpu()
     torch.testing.assert_close(got, want.permute(0, 2, 3, 1).contiguous(), rtol=1e-5, atol=1e-5)
+    for M, hw in ((1024, (12, 16)), (512, (9, 7)), (256, (5, 6))):          # rows of whole waves: the per-wave index arithmetic (round 5)
+        z = torch.randn(2, 50, M, generator=g)
+        want, off = 0, 0
+        for s in sizes:
+            want = want + F.interpolate(z[:, off:off + s * s].transpose(1, 2).reshape(2, M, s, s), size=hw, mode="bilinear", align_corners=False)
+            off += s * s
+        got = ops_pm.psp_prior_sum(d(z), sizes, hw).cpu()
+        torch.testing.assert_close(got, want.permute(0, 2, 3, 1).contiguous(), rtol=1e-5, atol=1e-5)
+        xx = torch.randn(2, hw[0], hw[1], M // 2, generator=g)
+        want = torch.cat([F.adaptive_avg_pool2d(xx.permute(0, 3, 1, 2), s).flatten(2) for s in sizes], dim=2).transpose(1, 2)
+        torch.testing.assert_close(ops_pm.psp_pool(d(xx), sizes).cpu(), want.contiguous(), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("B,N,C1,C2,dt", [(2, 1000, 16, 16, torch.int64), (1, 777, 32, 32, torch.int32), (2, 192, 64, 64, torch.int64),
@@ -506,6 +517,13 @@ def test_row_operators_bf16(device):
                                     align_corners=False)
         off += s * s
     _close_bf16(ops_pm.psp_prior_sum(d(z), sizes, (60, 80), dtype=BF).cpu(), want.permute(0, 2, 3, 1), "prior")
+    z = torch.randn(2, 50, 1024, generator=g)
+    want, off = 0, 0
+    for s in sizes:
+        want = want + F.interpolate(z[:, off:off + s * s].double().transpose(1, 2).reshape(2, 1024, s, s), size=(12, 16), mode="bilinear",
+                                    align_corners=False)
+        off += s * s
+    _close_bf16(ops_pm.psp_prior_sum(d(z), sizes, (12, 16), dtype=BF).cpu(), want.permute(0, 2, 3, 1), "prior, whole waves per pixel")
     from oracle import ops_ref
     xyz = torch.rand(2, 300, 3, generator=g)
     nei = torch.randint(0, 300, (2, 300, 16), generator=g)
