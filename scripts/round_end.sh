@@ -32,6 +32,7 @@ done
 timeout 300 bash scripts/prof_train.sh --precision bf16 > /dev/null 2>&1; cp "$OUT/train_kernels.txt" "$OUT/${TAG}_rocprofv3_kernel_stats_train_bf16.txt"; cp "$OUT/train_under_rocprof.json" "$OUT/${TAG}_bench_train_bf16_under_rocprof.json"
 # round 5: exact-KNN PMC, pose solver (bench + kernel statistics), input pipeline
 bash scripts/pmc_knn.sh "$TAG" > /dev/null 2>&1
+timeout 120 python scripts/pyramid_loop.py --iters 20 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_pyramid_alone.txt"
 timeout 200 python scripts/bench_pose.py > "$OUT/${TAG}_pose_bench.json" 2> "$OUT/${TAG}_pose_bench.err"
 ( cd /tmp && rm -rf /tmp/prof_pose && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_pose -o k -- python "$REPO/scripts/bench_pose.py" --steps 4 > /dev/null 2> "$OUT/${TAG}_pose_prof.err"
   DB=$(find /tmp/prof_pose -name '*.db' | head -1); python "$REPO/scripts/rocpd_stats.py" "$DB" --top 25 > "$OUT/${TAG}_pose_kernels.txt" 2>&1 )
