@@ -48,7 +48,7 @@ def test_sample_choose_properties(device):
         inputs.sample_choose(torch.zeros(1, 60, 80, device=device), 128)
 
 
-def test_sample_points_is_a_uniform_subset_and_reproducible(device):
+def test_sample_points_is_a_uniform_subset_and_reproducible(device, trials=300):
     """Same seed -> same sample; different seeds -> different samples; every valid pixel is (about) equally likely to be
     drawn and to land in the first quarter (the index pyramid's 'random' sub-sampling takes prefixes)."""
     d = torch.from_numpy(np.stack([_depth(5), _depth(6)])).to(device)
@@ -61,7 +61,6 @@ def test_sample_points_is_a_uniform_subset_and_reproducible(device):
     n_valid = int(a["n_valid"][0])
     hits = torch.zeros(120 * 160, device=device)
     first = torch.zeros(120 * 160, device=device)
-    trials = 300
     for s in range(trials):
         ch = inputs.sample_points(d[:1], 2048, seed=1000 + s)["choose"][0, 0]
         hits[ch] += 1
