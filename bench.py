@@ -584,7 +584,8 @@ def main():
                                  "upconv_fold": forward_pm.UPCONV_FOLD if isinstance(forward_pm.UPCONV_FOLD, str) else
                                  (None if forward_pm.UPCONV_FOLD is None else sorted(forward_pm.UPCONV_FOLD)),
                                  "psp_train_fold": model.PyramidPooling.fold_in_training,
-                                 "final_rows_log_softmax": model.FinalHead.rows_log_softmax, "upsample_rows": ops.UPSAMPLE_ROWS},
+                                 "final_rows_log_softmax": model.FinalHead.rows_log_softmax, "upsample_rows": ops.UPSAMPLE_ROWS,
+                                 "pyramid_one_event": forward_pm.PYRAMID_ONE_EVENT},
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "
                                       f"{args.dist_backend if world > 1 else 'no'} process group)"},
             "breakdown_ms": ({"step": fwd_ms, "knn_pyramid_alone": pyr_alone_ms,

@@ -76,6 +76,7 @@ SIGNATURES = {
     "ffb6d_psp_pool_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp]),
     "ffb6d_psp_prior_sum_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp]),
     "ffb6d_depth_to_cloud_f32": (_i32, [_vp, _vp, _c.c_float, _vp, _i64, _i64, _i64, _vp]),
+    "ffb6d_pyramid_sets_f32": (_i32, [_vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "ffb6d_sample_points_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "ffb6d_sample_points_f32": (_i32, [_vp, _c.c_float, _vp, _vp, _i32, _vp, _c.c_uint64, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                        _i64, _vp, _sz, _vp]),

@@ -307,3 +307,114 @@ extern "C" int ffb6d_depth_to_cloud_f32(const float* depth, const double* K, flo
     FFB6D_LAUNCH_CHECK();
     return FFB6D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Point sets of the index pyramid (linemod_dataset.py:299-323) in ONE launch: the cloud as [B,N,3] rows, its 16-byte coordinate table,
+// the prefixes that are the coarser cloud levels, and the xyz image at the strides the pixel <-> point searches use.  These were 13
+// ATen launches (slices, transposes, a pad) in front of the set preparation: 0.2 ms of dependent launches on the stream every index of
+// the step waits for (profiles/r05_step_timeline.txt).  Pure copies: bit-identical to the slices.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace ffb6d {
+namespace {
+
+constexpr int PYR_MAX_LEVELS = 6, PYR_MAX_GRIDS = 4;
+
+struct PyrSets {
+    const float* cld; long long cld_bs, cld_cs, cld_ps;          // cloud source: element strides of frame, coordinate, point
+    float* level_out[PYR_MAX_LEVELS]; int level_n[PYR_MAX_LEVELS];
+    float* table;
+    const float* dpt;                                             // [B,3,H,W]
+    float* grid_out[PYR_MAX_GRIDS]; int grid_m[PYR_MAX_GRIDS], grid_h[PYR_MAX_GRIDS], grid_w[PYR_MAX_GRIDS];
+    int B, N, n_levels, H, W, n_grids, s0, h0, w0;
+    unsigned cloud_blocks;
+};
+
+__global__ void __launch_bounds__(BLK)
+pyramid_sets_kernel(const PyrSets p)
+{
+    if (blockIdx.x < p.cloud_blocks) {
+        const long long t = (long long)blockIdx.x * BLK + threadIdx.x;
+        if (t >= (long long)p.B * p.N) return;
+        const int b = (int)(t / p.N), n = (int)(t - (long long)b * p.N);
+        const float* s = p.cld + b * p.cld_bs + n * p.cld_ps;
+        const float x = s[0], y = s[p.cld_cs], z = s[2 * p.cld_cs];
+        if (p.table) reinterpret_cast<float4*>(p.table)[t] = make_float4(x, y, z, 0.f);
+#pragma unroll
+        for (int k = 0; k < PYR_MAX_LEVELS; ++k)
+            if (k < p.n_levels && n < p.level_n[k]) {
+                float* o = p.level_out[k] + ((long long)b * p.level_n[k] + n) * 3;
+                o[0] = x; o[1] = y; o[2] = z;
+            }
+        return;
+    }
+    // one thread per pixel of the finest grid (stride s0); the coarser grids (stride s0 * m) are subsets of it
+    const long long t = (long long)(blockIdx.x - p.cloud_blocks) * BLK + threadIdx.x;
+    const long long per = (long long)p.h0 * p.w0;
+    if (t >= p.B * per) return;
+    const int b = (int)(t / per);
+    const int r = (int)(t - b * per);
+    const int gy = r / p.w0, gx = r - gy * p.w0;
+    const size_t hw = (size_t)p.H * p.W;
+    const float* s = p.dpt + (size_t)b * 3 * hw + (size_t)(gy * p.s0) * p.W + (size_t)gx * p.s0;
+    const float x = s[0], y = s[hw], z = s[2 * hw];
+#pragma unroll
+    for (int k = 0; k < PYR_MAX_GRIDS; ++k)
+        if (k < p.n_grids) {
+            const int m = p.grid_m[k];
+            const int Y = gy / m, X = gx / m;
+            if (Y * m == gy && X * m == gx && Y < p.grid_h[k] && X < p.grid_w[k]) {
+                float* o = p.grid_out[k] + ((size_t)b * p.grid_h[k] * p.grid_w[k] + (size_t)Y * p.grid_w[k] + X) * 3;
+                o[0] = x; o[1] = y; o[2] = z;
+            }
+        }
+}
+
+}  // namespace
+}  // namespace ffb6d
+
+extern "C" int ffb6d_pyramid_sets_f32(const float* cloud, int64_t cloud_frame_stride, int64_t cloud_coord_stride,
+                                      int64_t cloud_point_stride, int64_t B, int64_t N, int n_levels, const int64_t* level_n,
+                                      float* const* level_out, float* table, const float* dpt_xyz, int64_t H, int64_t W,
+                                      int n_grids, const int* strides, float* const* grid_out, ffb6d_stream_t stream)
+{
+    using namespace ffb6d;
+    FFB6D_REQUIRE(B >= 0 && N >= 0 && n_levels >= 0 && n_levels <= PYR_MAX_LEVELS && n_grids >= 0 && n_grids <= PYR_MAX_GRIDS,
+                  "pyramid_sets: at most %d cloud levels and %d grids", PYR_MAX_LEVELS, PYR_MAX_GRIDS);
+    FFB6D_REQUIRE(B * N < (1LL << 31) && H >= 0 && W >= 0 && B * 3 * H * W < (1LL << 40), "pyramid_sets: too large");
+    PyrSets p = {};
+    const bool cloud_part = (n_levels > 0 || table) && B * N > 0;
+    if (cloud_part) {
+        FFB6D_REQUIRE(cloud && (n_levels == 0 || (level_n && level_out)), "pyramid_sets: null cloud pointer");
+        FFB6D_REQUIRE(!table || (reinterpret_cast<uintptr_t>(table) & 15) == 0, "pyramid_sets: the coordinate table must be 16-byte aligned");
+        p.cld = cloud; p.cld_bs = cloud_frame_stride; p.cld_cs = cloud_coord_stride; p.cld_ps = cloud_point_stride;
+        p.table = table; p.n_levels = n_levels;
+        for (int k = 0; k < n_levels; ++k) {
+            FFB6D_REQUIRE(level_n[k] >= 0 && level_n[k] <= N && (level_out[k] || level_n[k] == 0), "pyramid_sets: level %d: bad size or null output", k);
+            p.level_n[k] = (int)level_n[k]; p.level_out[k] = level_out[k];
+        }
+        p.cloud_blocks = (unsigned)ceil_div(B * N, (int64_t)BLK);
+    }
+    p.B = (int)B; p.N = (int)N;
+    long long grid_threads = 0;
+    if (n_grids > 0 && B > 0) {
+        FFB6D_REQUIRE(dpt_xyz && strides && grid_out && H >= 1 && W >= 1, "pyramid_sets: null image pointer");
+        int s0 = strides[0];
+        for (int k = 0; k < n_grids; ++k) {
+            FFB6D_REQUIRE(strides[k] >= 1 && strides[k] <= H && strides[k] <= W && grid_out[k], "pyramid_sets: grid %d: bad stride or null output", k);
+            s0 = strides[k] < s0 ? strides[k] : s0;
+        }
+        p.dpt = dpt_xyz; p.H = (int)H; p.W = (int)W; p.n_grids = n_grids; p.s0 = s0; p.h0 = (int)(H / s0); p.w0 = (int)(W / s0);
+        for (int k = 0; k < n_grids; ++k) {
+            FFB6D_REQUIRE(strides[k] % s0 == 0, "pyramid_sets: every stride must be a multiple of the smallest one");
+            p.grid_m[k] = strides[k] / s0; p.grid_h[k] = (int)(H / strides[k]); p.grid_w[k] = (int)(W / strides[k]);
+            p.grid_out[k] = grid_out[k];
+        }
+        grid_threads = (long long)B * p.h0 * p.w0;
+    }
+    const long long blocks = (long long)p.cloud_blocks + ceil_div((int64_t)grid_threads, (int64_t)BLK);
+    if (blocks == 0) return FFB6D_OK;
+    FFB6D_REQUIRE(blocks < (1LL << 31), "pyramid_sets: too many workgroups");
+    hipLaunchKernelGGL(pyramid_sets_kernel, dim3((unsigned)blocks), dim3(BLK), 0, as_stream(stream), p);
+    FFB6D_LAUNCH_CHECK();
+    return FFB6D_OK;
+}

@@ -397,11 +397,17 @@ PYRAMID_KEYS = ([k % i for i in range(4) for k in ('cld_xyz%d', 'cld_nei_idx%d',
                 + [k % i for i in range(3) for k in ('r2p_up_nei_idx%d', 'p2r_up_nei_idx%d')])
 
 
+# A/B: True = every consumer waits for the whole pyramid (the schedule of rounds 3-5: the point branch starts when all 22 searches are done)
+PYRAMID_ONE_EVENT = False
+
+
 class StreamedPyramid(dict):
     """The input dict of a forward whose index pyramid (linemod_dataset.py:299-353) is not built yet: it is built on a third
-    (high-priority) HIP stream under the colour stem; `level(i, stream)` / `up_level(i, stream)` make `stream` wait for the event of
-    that level.  Since round 3 the builder launches all 22 searches as one batch (pyramid.PyramidBuilder), so the events of all seven
-    levels fire together ~1 ms after the forward starts (round 2: level 0 after 0.5 ms, the last one after 2.2 ms)."""
+    (high-priority) HIP stream under the colour stem.  The builder launches the 22 searches as two batches (pyramid.PyramidBuilder):
+    the K = 16 searches, whose indices the point branch's first layers need -- `level(i, stream)` / `up_level(i, stream)` make
+    `stream` wait for them -- then the K = 1 searches, first read by the first fusion stage (`nearest(stream)`).  With ONE batch
+    (rounds 3-5) the point branch started 1.5 ms into the step and the colour stream waited 0.28 ms for it at the first fusion
+    (profiles/r05_step_timeline.txt)."""
 
     def __init__(self, net, inputs, main, side):
         super().__init__(inputs)
@@ -410,15 +416,18 @@ class StreamedPyramid(dict):
         idx = net._index_stream(dev) if side is not main else main
         idx.wait_stream(main)
         with torch.cuda.stream(idx):
-            cld = inputs['cld_rgb_nrm'][:, :3, :].transpose(1, 2).contiguous()      # linemod_dataset.py:285,318
-            # coordinate table of the fused local feature aggregation (16-byte rows): every coarser level is a prefix of the
-            # cloud (linemod_dataset.py:322-323), so ONE table serves all four levels through its frame stride
-            self.table0 = ops_pm.xyz_table(cld)
+            # the cloud as rows (linemod_dataset.py:285,318), every coarser level (a prefix of it, :322-323), the image grids and the
+            # coordinate table of the fused local feature aggregation (16-byte rows; ONE table serves all four levels through its
+            # frame stride) in one launch
+            sets, self.table0 = pyramid.point_sets(inputs['cld_rgb_nrm'].float(), inputs['dpt_xyz'].float(), channel_major=True,
+                                                   with_table=True)
             if idx is not main:
                 self.table0.record_stream(side)
-            b = pyramid.PyramidBuilder(cld, inputs['dpt_xyz'], getattr(net, 'index_dtype', torch.int64))
-            for i in range(7):
-                d = b.encoder_level(i) if i < 4 else b.decoder_level(i - 4)
+            b = pyramid.PyramidBuilder(sets[('c', 0)], inputs['dpt_xyz'], getattr(net, 'index_dtype', torch.int64), sets=sets)
+            # first event: the K = 16 indices and level 0's sub-sampling prefix (what the first encoder level of the point branch
+            # reads); second: the other prefixes (small copies, kept off the first level's critical chain) and the K = 1 indices
+            for keys in (lambda: b.neighbour_keys(sub_levels=(0,)), lambda: {**b.sub_index_keys((1, 2, 3)), **b.nearest_keys()}):
+                d = keys()
                 ev = torch.cuda.Event()
                 ev.record(idx)
                 self.events.append(ev)
@@ -430,13 +439,26 @@ class StreamedPyramid(dict):
         self.waited = set()
         self.single = idx is main
 
+    def _wait(self, which, stream):
+        if PYRAMID_ONE_EVENT:
+            which = 1
+        if not self.single and (which, stream) not in self.waited:
+            stream.wait_event(self.events[which])
+            self.waited.add((which, stream))
+
     def level(self, i, stream):
-        if not self.single and (i, stream) not in self.waited:
-            stream.wait_event(self.events[i])
-            self.waited.add((i, stream))
+        """neighbour indices (K = 16) of every level and level 0's sub-sampling prefix: the first batch of searches; the prefixes of
+        the coarser levels come with the second event"""
+        self._wait(0, stream)
+        if i > 0:
+            self._wait(1, stream)
 
     def up_level(self, i, stream):
-        self.level(4 + i, stream)
+        self._wait(0, stream)
+
+    def nearest(self, stream):
+        """the K = 1 indices (interpolation, pixel <- point): the second batch"""
+        self._wait(1, stream)
 
     def xyz_table(self, i):
         """coordinate table of encoder level i: the first N_i rows of every frame of the level-0 table (valid after level(i))"""
@@ -465,6 +487,13 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
             if not two_streams:
                 return
             (inputs.up_level if up else inputs.level)(i, main)
+
+    def need_nearest():
+        """the K = 1 indices are about to be used"""
+        if lazy:
+            inputs.nearest(side)
+            if two_streams:
+                inputs.nearest(main)
 
     def on_side():
         return torch.cuda.stream(side)
@@ -536,6 +565,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
             p0 = ops_pm.random_sample(f_enc, inputs['cld_sub_idx%d' % i])
         if i == 0:
             ds_emb.append(f_enc)
+        need_nearest()
         rgb_emb, p_emb = fuse(i, net.ds_fuse_p2r_pre_layers, net.ds_fuse_p2r_fuse_layers, net.ds_fuse_r2p_pre_layers,
                               net.ds_fuse_r2p_fuse_layers, rgb0, p0, inputs['p2r_ds_nei_idx%d' % i],
                               inputs['r2p_ds_nei_idx%d' % i])
@@ -549,6 +579,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
     for i in range(n_up - 1):
         rgb0 = cnn_stage(net.cnn_up_stages[i], rgb_emb)
         need(i, up=True)
+        need_nearest()
         with on_side():
             p0 = decode(net.rndla_up_stages[i], ds_emb[-i - 2], p_emb, inputs['cld_interp_idx%d' % (n_up - i - 1)])
         rgb_emb, p_emb = fuse(i, net.up_fuse_p2r_pre_layers, net.up_fuse_p2r_fuse_layers, net.up_fuse_r2p_pre_layers,

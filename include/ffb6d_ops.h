@@ -302,6 +302,19 @@ int ffb6d_psp_prior_sum_pm(int dtype, const float* z, void* out, int64_t B, int6
 int ffb6d_depth_to_cloud_f32(const float* depth, const double* K, float cam_scale, float* out,
                              int64_t B, int64_t H, int64_t W, ffb6d_stream_t stream);
 
+/* The point sets of the index pyramid (linemod_dataset.py:299-323) in one launch -- what the dataset code produces with slices:
+ *   level_out[k] [B, level_n[k], 3] = the first level_n[k] points of every frame of the cloud (level_n[0] = N: the cloud itself as
+ *                                      rows; the coarser levels are prefixes of the once-shuffled cloud, :322-323),
+ *   table [B, N, 4] = rows {x, y, z, 0} (16-byte coordinate rows of ffb6d_lfa_pm; may be NULL),
+ *   grid_out[g] [B, (H / strides[g]) * (W / strides[g]), 3] = the xyz image dpt_xyz [B,3,H,W] at pixels (y * s, x * s), row-major
+ *                                      (:299-311); every stride must be a multiple of the smallest one.
+ * The cloud is read through element strides: point-major [B,N,3] = (3 N, 1, 3); the first three channels of cld_rgb_nrm [B,9,N]
+ * = (9 N, N, 1).  At most 6 levels and 4 grids.  Pure copies (bit-identical to the slices). */
+int ffb6d_pyramid_sets_f32(const float* cloud, int64_t cloud_frame_stride, int64_t cloud_coord_stride, int64_t cloud_point_stride,
+                           int64_t B, int64_t N, int n_levels, const int64_t* level_n, float* const* level_out, float* table,
+                           const float* dpt_xyz, int64_t H, int64_t W, int n_grids, const int* strides, float* const* grid_out,
+                           ffb6d_stream_t stream);
+
 /* Debug helper: number of entries of idx[0:count] outside [0, M) written to *bad (device int32). */
 int ffb6d_check_index_range(const void* idx, int idx_bits, int64_t count, int64_t M,
                             int32_t* bad, ffb6d_stream_t stream);

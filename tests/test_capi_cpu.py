@@ -87,6 +87,20 @@ def test_pose_entry_points_validate_arguments_without_a_gpu(native_lib):
     assert native_lib.ffb6d_best_fit_transform_f32(None, None, 2, 0, None, None) == -1
 
 
+def test_pyramid_sets_validates_arguments_without_a_gpu(native_lib):
+    import ctypes
+    from ffb6d_amd import _lib
+    f = native_lib.ffb6d_pyramid_sets_f32
+    assert f(None, 0, 0, 0, 0, 0, 0, None, None, None, None, 0, 0, 0, None, None, None) == 0          # nothing to do
+    assert f(None, 0, 0, 0, 2, 16, 7, None, None, None, None, 0, 0, 0, None, None, None) == -1 and "at most" in _lib.last_error()
+    n = (ctypes.c_int64 * 1)(16)
+    out = (ctypes.c_void_p * 1)(None)
+    assert f(None, 48, 1, 3, 2, 16, 1, n, out, None, None, 0, 0, 0, None, None, None) == -1 and "null cloud" in _lib.last_error()
+    st = (ctypes.c_int * 2)(2, 3)
+    g = (ctypes.c_void_p * 2)(64, 64)
+    assert f(None, 0, 0, 0, 1, 0, 0, None, None, None, ctypes.c_void_p(64), 8, 8, 2, st, g, None) == -1 and "multiple" in _lib.last_error()
+
+
 def test_workspace_query_is_pure_host_logic(native_lib):
     # small support, many query blocks -> brute-force scan without split, no scratch
     assert native_lib.ffb6d_knn_uses_pruning(64, 256, 12288, 16) == 0

@@ -93,6 +93,29 @@ def test_sample_points_is_the_documented_permutation(device, h, w, n, frames=3):
         assert np.array_equal(got["choose"][b, 0].cpu().numpy(), want), b
 
 
+@pytest.mark.parametrize("n,h,w", [(12288, 480, 640), (1100, 104, 136), (1000, 50, 70)])
+def test_pyramid_point_sets_equal_the_slices(device, n, h, w, frames=3):
+    """ffb6d_pyramid_sets_f32 (one launch) against the dataset code's slices (linemod_dataset.py:299-323): cloud rows, prefixes,
+    coordinate table, strided xyz grids -- from point-major and from channel-major clouds, sizes the strides do not divide."""
+    from ffb6d_amd import pyramid, ops_pm
+    rng = np.random.RandomState(n)
+    crn = torch.from_numpy(rng.randn(frames, 9, n).astype(np.float32)).to(device)
+    dpt = torch.from_numpy(rng.randn(frames, 3, h, w).astype(np.float32)).to(device)
+    cld = crn[:, :3, :].transpose(1, 2).contiguous()
+    for cm in (True, False):
+        sets, table = pyramid.point_sets(crn if cm else cld, dpt, channel_major=cm, with_table=True)
+        assert torch.equal(table, ops_pm.xyz_table(cld))
+        cur = cld
+        for i in range(5):
+            assert torch.equal(sets[('c', i)], cur), (cm, i)
+            if i < 4:
+                cur = cur[:, :cur.shape[1] // pyramid.SUB_RATIO[i], :].contiguous()
+        for s in (2, 4, 8):
+            assert torch.equal(sets[('g', s)], pyramid.strided_grid(dpt, s)), (cm, s)
+    sets, table = pyramid.point_sets(cld, dpt)
+    assert table is None and torch.equal(sets[('c', 0)], cld)
+
+
 def test_assemble_inputs_feeds_the_model(device):
     rng = np.random.RandomState(0)
     deps = torch.from_numpy(np.stack([_depth(7), _depth(8)])).to(device)
