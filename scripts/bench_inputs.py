@@ -34,6 +34,11 @@ def timed(fn):
 
 out = {"batch": a.batch, "n_points": a.n_points, "frame": [H, W]}
 xyz = inputs.depth_to_cloud(depth, K)
+# the first second of a process is not steady state on the host side (measured: a call of the pipeline enqueues in 0.4 ms, but in 2.4 ms
+# during the first ~50 calls), and this pipeline is host-bound at 1 ms per batch: warm up before timing anything
+for _ in range(60):
+    inputs.assemble_inputs(rgb, depth, nrm, K, a.n_points, seed=7)
+torch.cuda.synchronize()
 out["depth_to_cloud_us"] = timed(lambda: inputs.depth_to_cloud(depth, K))
 out["sample_points_us"] = timed(lambda: inputs.sample_points(depth, a.n_points, xyz, rgb, nrm, seed=7))
 out["assemble_inputs_us"] = timed(lambda: inputs.assemble_inputs(rgb, depth, nrm, K, a.n_points, seed=7))
