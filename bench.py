@@ -85,7 +85,7 @@ def parse():
                          "1: everything on one stream")
     ap.add_argument("--overlap-pyramid", type=int, default=1,
                     help="1 (default, inference with --streams 2): the forward builds the index pyramid itself on a third HIP "
-                         "stream (forward_pm.StreamedPyramid: all 22 searches as one batch, ~1 ms, under the colour stem); "
+                         "stream (forward_pm.StreamedPyramid: the 22 searches as a K = 16 and a K = 1 batch, ~1 ms, under the colour stem); "
                          "0: whole pyramid first, then the forward")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5),
                     help="BASELINE.json workload: 2 = bs=8, N=12288, 22 classes, fp32 (the headline metric, default); "
@@ -589,7 +589,7 @@ def main():
                        "parallelism": f"dp{world} (independent batches, one process per GPU, "
                                       f"{args.dist_backend if world > 1 else 'no'} process group)"},
             "breakdown_ms": ({"step": fwd_ms, "knn_pyramid_alone": pyr_alone_ms,
-                              "note": "the forward builds the index pyramid itself (all 22 searches as one batch) on a third HIP stream, "
+                              "note": "the forward builds the index pyramid itself (the 22 searches as two batches: K = 16, then K = 1) on a third HIP stream, "
                                       "under the network (forward_pm.StreamedPyramid); knn_pyramid_alone = the same 22 "
                                       "searches run by themselves after the timed region"}
                              if pyramid_on_side else {"knn_pyramid": pyr_ms, "forward": fwd_ms}),
