@@ -1,7 +1,7 @@
 """bench.py's own launch paths on the GPU box (the driver's contract): the multi-rank self-spawn (`--gpus N` re-executes the
 script under torch.distributed.run, one process per rank) exercised with two ranks sharing the one GPU of the box over gloo
--- inference (batch sharding, no data-path collective, MAX over ranks) -- and with eight ranks, inference and training (DDP gradient
-all-reduce, train_lm.py:559-563,625-628): BASELINE configuration 3's launch shape rehearsed on one GPU."""
+-- inference (batch sharding, no data-path collective, MAX over ranks) and training (DDP gradient all-reduce,
+train_lm.py:559-563,625-628) -- and with eight ranks (inference): BASELINE configuration 3's launch shape rehearsed on one GPU."""
 import json
 import os
 import subprocess
@@ -44,11 +44,13 @@ def test_bench_spawns_eight_ranks_on_the_one_gpu():
     assert abs(line["value"] - 16 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
 
 
-def test_bench_train_mode_wraps_ddp_on_eight_ranks():
-    """... and the training half: DistributedDataParallel over eight ranks (one frame each), gradient all-reduce every step"""
-    line = _bench("--gpus", "8", "--dist-backend", "gloo", "--mode", "train", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                  "--batch", "1", "--cudnn-benchmark", "0", timeout=1200)
-    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8
+def test_bench_train_mode_wraps_ddp_on_two_ranks():
+    """... and the training half: DistributedDataParallel over two ranks sharing the GPU (one frame each), gradient all-reduce every step.
+    (Eight training ranks on one GPU were 173 s of MIOpen cold starts in the GPU suite; the eight-rank launch shape is covered by the
+    inference test above, the gradient averaging by tests/test_multigpu_gpu.py and the gloo tests of tests/test_distributed_cpu.py.)"""
+    line = _bench("--gpus", "2", "--dist-backend", "gloo", "--mode", "train", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                  "--batch", "1", "--cudnn-benchmark", "0", timeout=600)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2
     assert "train" in line["metric"] and line["value"] > 0
 
 
