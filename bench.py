@@ -113,9 +113,9 @@ MLP_KERNEL_NAMES = {"mlp_pm<128x128>": "mlp_pm_kernel<2, 2, 2, 2, false>", "mlp_
                     "mlp_pm<32x256>": "mlp_pm_kernel<1, 2, 1, 4, false>", "mlp_pm<64x64>": "mlp_pm_kernel<1, 1, 2, 2, false>",
                     "mlp_pm<64x32,ksplit>": "mlp_pm_kernel<2, 1, 2, 2, true>",
                     "mlp_pm<stream>": "mlp_pm_stream_kernel<T, TM, NS, LSM, TWO>", "mlp_pm<lds128x128>": "mlp_pm_lds_kernel<T>",
-                    "mlp_pm<seq128x128>": "mlp_pm_seq_kernel<TWO>",
+                    "mlp_pm<seq128x128>": "mlp_pm_seq_kernel<TWO>", "mlp_pm<big256x256>": "mlp_pm_big_kernel",
                     "att_pool_pm": "att_pool_pm_kernel<TM, TN>", "lfa_pm": "lfa_pm_kernel<T, D, MODE, P>"}
-PM_TILES = {1: "128x128", 2: "64x256", 3: "32x256", 4: "64x64", 5: "64x32,ksplit", 6: "stream", 7: "lds128x128", 8: "seq128x128"}
+PM_TILES = {1: "128x128", 2: "64x256", 3: "32x256", 4: "64x64", 5: "64x32,ksplit", 6: "stream", 7: "lds128x128", 8: "seq128x128", 9: "big256x256"}
 
 
 def gemm_flops(name, rec_tag, batch):
@@ -579,10 +579,11 @@ def main():
                        "forms": {"lfa_fused": forward_pm.LFA_FUSED, "posenc_fused": forward_pm.POSENC_FUSED, "stem_fused": forward_pm.STEM_FUSED,
                                  "last_stage_at_chosen": forward_pm.LAST_STAGE_AT_CHOSEN, "heads_share_first": forward_pm.HEADS_SHARE_FIRST, "heads_align_last": forward_pm.HEADS_ALIGN_LAST,
                                  "heads_on_both_streams": forward_pm.HEADS_ON_BOTH_STREAMS, "heads_chain_fused": forward_pm.HEADS_CHAIN_FUSED,
-                                 "gemm_seq_form": forward_pm.GEMM_SEQ_FORM,
+                                 "gemm_seq_form": forward_pm.GEMM_SEQ_FORM, "gemm_big_form": forward_pm.GEMM_BIG_FORM,
                                  "miopen": ("find mode (cudnn.benchmark), " if args.cudnn_benchmark else "immediate mode, ") + miopen_db,
                                  "upconv_fold": forward_pm.UPCONV_FOLD if isinstance(forward_pm.UPCONV_FOLD, str) else
                                  (None if forward_pm.UPCONV_FOLD is None else sorted(forward_pm.UPCONV_FOLD)),
+                                 "upconv_fold_bf16": forward_pm.UPCONV_FOLD_BF16,
                                  "psp_train_fold": model.PyramidPooling.fold_in_training,
                                  "final_rows_log_softmax": model.FinalHead.rows_log_softmax, "upsample_rows": ops.UPSAMPLE_ROWS,
                                  "pyramid_one_event": forward_pm.PYRAMID_ONE_EVENT},

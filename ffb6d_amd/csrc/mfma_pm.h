@@ -80,5 +80,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
+// LDS-DMA (`buffer_load_dwordx4 ... lds`): 16 bytes per lane from rs[voffset + soffset] straight into LDS at lds_dst + 16 * lane
+// (lds_dst wave-uniform: the hardware takes it from M0; out-of-range lanes deliver zeros).  Counts on vmcnt like any buffer load;
+// a reader in another wave needs the issuer's vmcnt wait AND a barrier.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_dst, int voffset, int soffset)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
+}
+
 }  // namespace pm
 }  // namespace ffb6d

@@ -148,6 +148,9 @@ HEADS_CHAIN_FUSED = True
 # (csrc/mlp_pm.hip: mlp_pm_seq_kernel -- a finished tile's epilogue rides between the MFMAs of the next tile of the same workgroup);
 # False: the LDS-tiled form (one tile per workgroup) for those launches.  Equal bits.
 GEMM_SEQ_FORM = True
+# The long-row bf16 GEMMs with K >= 256 on the 256 x 256 tile with LDS-DMA operand loads (csrc/mlp_pm_big.hip); False: the LDS-tiled
+# 128 x 128 form for those launches.  Equal bits.
+GEMM_BIG_FORM = True
 LFA_WIDTHS = (32, 64, 128, 256)
 
 
@@ -251,16 +254,18 @@ def pyramid_pooling(pp, x):
     return ops_pm.mlp(x, wx, pp.bottleneck.bias.detach().float(), ops.ACT_RELU, add=prior, role="cnn")
 
 
-# Which PSPUpsample blocks run in the folded form (csrc/upconv.hip): "auto" = every block in fp32, none in bf16 (measured,
-# profiles/r02_opt_in_forms_ab.json: fp32 step 28.8 -> 23.8 ms; in bf16 MIOpen's convolution of the up-sampled map is faster than the
-# z GEMM + the tap blend, 17.2 -> 18.1 ms); None = every block in both precisions; a frozenset of input widths = those blocks
-# (tests / A/B set the attribute).
+# Which PSPUpsample blocks run in the folded form (csrc/upconv.hip): "auto" = every block in fp32 (measured, profiles/r02_opt_in_forms_ab.json:
+# step 28.8 -> 23.8 ms) and, since round 6, in bf16 (UPCONV_FOLD_BF16; profiles/r06_upconv_fold_bf16_ab_start.json: configuration 5
+# 11.19 -> 10.16 ms in one process -- the round-2 record that kept it off, 17.2 -> 18.1 ms, was three GEMM generations old); None = every
+# block in both precisions; a frozenset of input widths = those blocks (tests / A/B set the attribute).
 UPCONV_FOLD = "auto"
+# ... and what "auto" means in bf16 (a boolean so that scripts/ab_forms.py / bench.py --form can flip it)
+UPCONV_FOLD_BF16 = True
 
 
 def _fold_block(cin, dtype):
     if UPCONV_FOLD == "auto":
-        return dtype == torch.float32
+        return dtype == torch.float32 or UPCONV_FOLD_BF16
     return UPCONV_FOLD is None or cin in UPCONV_FOLD
 
 
@@ -471,6 +476,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
     dev = inputs['rgb'].device
     dt = torch.bfloat16 if getattr(net, "precision", "fp32") == "bf16" else torch.float32
     ops_pm.MLP_SEQ_FORM = GEMM_SEQ_FORM
+    ops_pm.MLP_BIG_FORM = GEMM_BIG_FORM
     main = torch.cuda.current_stream(dev)
     side = net._side_stream(dev) if two_streams else main
     if two_streams:

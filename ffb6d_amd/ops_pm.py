@@ -31,6 +31,17 @@ ACT_LOG_SOFTMAX = 3
 # the tile-sequence form of the long-row fp32 GEMMs (csrc/mlp_pm.hip: mlp_pm_seq_kernel, round 5); False = the LDS-tiled form everywhere
 # (bit-identical results; forward_pm.GEMM_SEQ_FORM sets it per forward for in-process A/B)
 MLP_SEQ_FORM = True
+# the 256 x 256 bf16 tile with LDS-DMA operand loads (csrc/mlp_pm_big.hip, round 6); False = the LDS-tiled 128 x 128 form on those launches
+# (bit-identical results; forward_pm.GEMM_BIG_FORM sets it per forward)
+MLP_BIG_FORM = True
+_big_form_set = None
+
+
+def _sync_big_form(lib):
+    global _big_form_set
+    if _big_form_set is not MLP_BIG_FORM:
+        lib.ffb6d_mlp_pm_set_big_form(int(MLP_BIG_FORM))
+        _big_form_set = MLP_BIG_FORM
 
 
 def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gather=None, out=None, tile_hint=0, role="path"):
@@ -45,6 +56,7 @@ def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gathe
     `role` only labels the launch in traces (bench.py reports the north-star path's GEMMs and the colour decoder's separately)."""
     _need_gpu(x1, w)
     lib = _lib.load()
+    _sync_big_form(lib)
     dt = _dt(x1, w, x2, add, gather[0] if gather is not None else None, out)
     tdt = x1.dtype
     esz = x1.element_size()

@@ -8,7 +8,8 @@ PASSES=("SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ
         "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"
         "FETCH_SIZE"
         "WRITE_SIZE"
-        "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum")
+        "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+        "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU")
 { echo "# rocprofv3 --kernel-trace --pmc <counters> -- python scripts/bench_mlp_pm_shape.py $ARGS  (10 launches; FETCH/WRITE_SIZE unit 1024 B)"
   i=0
   for P in "${PASSES[@]}"; do

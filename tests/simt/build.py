@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "ffb6d_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libsimt_ffb6d.so")
-KERNEL_SOURCES = ["errors.hip", "seg_sort.hip", "mlp_pm.hip", "mlp_chain.hip", "lfa_pm.hip", "train_ops.hip", "train_rows.hip", "upconv.hip", "posenc.hip", "ops_pm.hip", "neighbour_ops.hip", "knn.hip", "knn_pruned.hip", "knn_pick.hip", "pose.hip", "inputs.hip", "holefill.hip"]
+KERNEL_SOURCES = ["errors.hip", "seg_sort.hip", "mlp_pm.hip", "mlp_pm_big.hip", "mlp_chain.hip", "lfa_pm.hip", "train_ops.hip", "train_rows.hip", "upconv.hip", "posenc.hip", "ops_pm.hip", "neighbour_ops.hip", "knn.hip", "knn_pruned.hip", "knn_pick.hip", "pose.hip", "inputs.hip", "holefill.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 # statements after which a wave relies on lock-step execution for LDS traffic between its lanes

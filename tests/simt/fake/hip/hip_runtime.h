@@ -240,6 +240,32 @@ inline u32x4_t buffer_load_b128(Rsrc rs, int voffset, int soffset)
     return v;
 }
 
+// buffer_load_dwordx4 ... lds: 16 bytes per lane, range checked like the register form, written to lds_base + 16 * lane
+// (lds_base wave-uniform: M0 on the hardware)
+inline void buffer_load_lds16(Rsrc rs, unsigned char* lds_base, int voffset, int soffset)
+{
+    const u32x4_t v = buffer_load_b128(rs, voffset, soffset);
+    memcpy(lds_base + 16 * lane(), &v, 16);
+    wave_sync();
+}
+
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+inline u32x2_t buffer_load_b64(Rsrc rs, int voffset, int soffset)
+{
+    wave_sync();
+    u32x2_t v = {0u, 0u};
+    const unsigned vo = (unsigned)voffset;
+    for (int d = 0; d < 2; ++d) {
+        const unsigned off = vo + 4u * d;
+        if (off < rs.size && vo <= 0xffffffffu - 8u) {
+            unsigned w;
+            memcpy(&w, rs.base + (ptrdiff_t)soffset + off, 4);
+            v[d] = w;
+        }
+    }
+    return v;
+}
+
 inline void buffer_store_b128(u32x4_t v, Rsrc rs, int voffset, int soffset)
 {
     wave_sync();
@@ -258,6 +284,8 @@ inline void buffer_store_b128(u32x4_t v, Rsrc rs, int voffset, int soffset)
 typedef simt::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_make_buffer_rsrc(ptr, stride, num, flags) simt::Rsrc{reinterpret_cast<unsigned char*>(ptr), (unsigned)(num)}
 #define __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, aux) simt::buffer_load_b128(rs, vo, so)
+#define __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, aux) simt::buffer_load_b64(rs, vo, so)
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ldsp, size, vo, so, imm, aux) simt::buffer_load_lds16(rs, (unsigned char*)(ldsp), vo, so)
 #define __builtin_amdgcn_raw_buffer_store_b128(v, rs, vo, so, aux) simt::buffer_store_b128(v, rs, vo, so)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) simt::mfma_32x32x2_f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) simt::mfma_32x32x16_bf16(a, b, c)

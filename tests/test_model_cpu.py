@@ -172,11 +172,15 @@ def test_forward_on_cpu_tensors_fails_loudly():
 
 
 def test_upconv_fold_policy(monkeypatch):
-    """forward_pm.UPCONV_FOLD: "auto" (fp32 only, the default) / None (every block) / a set of input widths"""
+    """forward_pm.UPCONV_FOLD: "auto" (the default: every block in fp32; in bf16 by UPCONV_FOLD_BF16, on since round 6) / None (every
+    block) / a set of input widths"""
     import torch
     from ffb6d_amd import forward_pm
-    assert forward_pm.UPCONV_FOLD == "auto"
-    for setting, want32, want16, want_other in (("auto", True, False, True), (frozenset(), False, False, False),
+    assert forward_pm.UPCONV_FOLD == "auto" and forward_pm.UPCONV_FOLD_BF16 is True
+    monkeypatch.setattr(forward_pm, "UPCONV_FOLD_BF16", False)
+    assert forward_pm._fold_block(1024, torch.bfloat16) is False and forward_pm._fold_block(1024, torch.float32) is True
+    monkeypatch.setattr(forward_pm, "UPCONV_FOLD_BF16", True)
+    for setting, want32, want16, want_other in (("auto", True, True, True), (frozenset(), False, False, False),
                                                 (None, True, True, True), (frozenset((1024, 256)), True, True, False)):
         monkeypatch.setattr(forward_pm, "UPCONV_FOLD", setting)
         assert forward_pm._fold_block(1024, torch.float32) is want32

@@ -181,6 +181,41 @@ def test_lds_tiled_bf16_prefetch_past_the_last_step(emu, K1, K2, cout, rows):
     assert torch.equal(got, ops_pm.mlp(x1, w, bias, 1, x2=x2, tile_hint=1))
 
 
+@pytest.mark.parametrize("K1,K2,cout,rows,extra", [(256, 0, 264, 300, "gather"), (128, 64, 130, 520, "add"), (64, 64, 256, 257, None),
+                                                   (192, 0, 72, 64, "gather"), (128, 128, 40, 700, "xgather")])
+def test_big_tile_bf16_form_on_the_emulator(emu, K1, K2, cout, rows, extra):
+    """mlp_pm_big_kernel (csrc/mlp_pm_big.hip, tile_hint 9): 256 x 256 tile, LDS-DMA operand loads into chunk-permuted images; ragged
+    rows and channels (zero rows past the end), one or two sources, gathered / added epilogue rows, gathered operand rows; against
+    float64 and bit-identical to the LDS-tiled form (same products in the same k order per accumulator)"""
+    g = torch.Generator().manual_seed(K1 + cout + rows)
+    BF = torch.bfloat16
+    B = 2 if rows % 2 == 0 else 1
+    P = rows // B
+    kw = {}
+    if extra == "xgather":
+        x1 = torch.randn(B, 90, K1, generator=g).to(BF)
+        kw["x1_gather"] = torch.randint(0, 90, (B, P), generator=g)
+    else:
+        x1 = torch.randn(B, P, K1, generator=g).to(BF)
+    x2 = torch.randn(B, P, K2, generator=g).to(BF) if K2 else None
+    w = (torch.randn(cout, K1 + K2, generator=g) / (K1 + K2) ** 0.5).to(BF)
+    bias = torch.randn(cout, generator=g)
+    if extra == "gather":
+        kw["gather"] = (torch.randn(B, 30, cout, generator=g).to(BF), torch.randint(0, 30, (B, P), generator=g))
+    elif extra == "add":
+        kw["add"] = torch.randn(B, P, cout, generator=g).to(BF)
+    got = ops_pm.mlp(x1, w, bias, 2, x2=x2, tile_hint=9, **kw)
+    assert torch.equal(got.view(torch.int16), ops_pm.mlp(x1, w, bias, 2, x2=x2, tile_hint=7, **kw).view(torch.int16))
+    if rows == 64:                                  # the probe variants of the schedule / the store shape (csrc/mlp_pm_big.hip: VAR)
+        for var in (1, 4, 8):
+            assert torch.equal(got.view(torch.int16), ops_pm.mlp(x1, w, bias, 2, x2=x2, tile_hint=9 + 256 * var, **kw).view(torch.int16)), var
+        assert torch.equal(got.view(torch.int16), ops_pm.mlp(x1, w, None, 0, x2=x2, tile_hint=9, **kw).view(torch.int16)) is False
+        nob = ops_pm.mlp(x1, w, None, 0, x2=x2, tile_hint=9)         # no bias, no Y, identity: negative zeros survive the additions of "nothing"
+        assert torch.equal(nob.view(torch.int16), ops_pm.mlp(x1, w, None, 0, x2=x2, tile_hint=7).view(torch.int16))
+    want = _ref(x1, w, bias, 2, x2=x2, **kw)
+    assert float((got.double() - want).abs().max()) <= 1e-2 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("B,N,C1,C2,idt", [(2, 50, 16, 16, torch.int64), (1, 37, 32, 32, torch.int32), (1, 20, 64, 64, torch.int64),
                                            (3, 9, 8, 24, torch.int64)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
