@@ -56,4 +56,26 @@ template <> struct RowUnit<__bf16> {
     }
 };
 
+// half a bf16 unit: 4 consecutive channels in 8 bytes -- the register footprint of a float32 unit, for per-thread bodies whose
+// register blocking does not fit with 8-channel units (csrc/upconv_body.h: the 2 x 4 output block)
+struct Bf16Half {};
+template <> struct RowUnit<Bf16Half> {
+    static constexpr int VL = 4;
+    float v[4];
+    static __host__ __device__ __forceinline__ RowUnit load(const void* base, size_t unit)
+    {
+        const uint2 w = static_cast<const uint2*>(base)[unit];
+        RowUnit u;
+        u.v[0] = __builtin_bit_cast(float, w.x << 16); u.v[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
+        u.v[2] = __builtin_bit_cast(float, w.y << 16); u.v[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
+        return u;
+    }
+    __host__ __device__ __forceinline__ void store(void* base, size_t unit) const
+    {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};       // round to nearest even
+        static_cast<bf16x4*>(base)[unit] = b;
+    }
+};
+
 }  // namespace ffb6d

@@ -292,6 +292,11 @@ int ffb6d_log_softmax_rows_bwd(int dtype, const void* g, const void* x, void* gx
  * ffb6d_bilinear_resize_pm (ATen's upsample_bilinear2d); fp32 accumulation in both precisions. */
 int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* shift, float slope, void* out, int64_t B, int64_t IH,
                             int64_t IW, int64_t OH, int64_t OW, int64_t C, ffb6d_stream_t stream);
+/* A/B of the kernel form on exact x2 maps: 2 = the measured choice per shape (default: the LDS-staged form -- 8 x 16 output pixels of a
+ * 64-byte channel chunk per workgroup, window staged with LDS-DMA loads -- for bfloat16 maps of <= 64 channels, the per-thread 2 x 4
+ * block elsewhere, bfloat16 on 4-channel half units); 3 = LDS-staged everywhere; 1 = 2 x 4 block everywhere; 0 = as 1 in fp32, one
+ * output pixel per thread in bfloat16 (rounds 2-5).  Identical results. */
+void ffb6d_upconv_set_form(int form);
 /* All adaptive average pools of `sizes` of x [B,H,W,C] -> float32 [B, sum(s*s), C] (bins of sizes[0] first, row-major in a
  * level).  Two passes (row partial sums, then bins) through a workspace of ffb6d_psp_pool_pm_workspace_bytes(...) bytes. */
 size_t ffb6d_psp_pool_pm_workspace_bytes(int64_t B, int64_t H, int64_t C, const int* sizes, int nsizes);

@@ -25,6 +25,14 @@ extern "C" int hostsim_upconv_combine(int dtype, const void* z, const float* shi
     a.rw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
     a.slope = slope;
     a.banded = 1; a.nbx = a.nby = 0;                                // launch order: not used by the bodies
+    if (blocked == 4) {                                             // bf16 on half units (the launcher's bf16 rule, csrc/upconv.hip)
+        if (dtype != 1 || OH != 2 * IH || OW != 2 * IW || OW % 4) return -2;
+        a.q = (int)(C / 4);
+        const int threads = (int)((OW / 4 * a.q + 255) / 256 * 256);
+        for (int rb = 0; rb < (int)(B * OH / 2); ++rb)
+            for (int t = 0; t < threads; ++t) combine_block_body<ffb6d::Bf16Half, 2>(a, rb, t);
+        return 0;
+    }
     if (blocked) {                                                  // the launcher's rule (csrc/upconv.hip)
         if (OH != 2 * IH || OW != 2 * IW || OW % 4) return -2;
         const int threads = (int)((OW / 4 * a.q + 255) / 256 * 256);

@@ -47,6 +47,13 @@ CASES += [(2, 777, 40, 24, 72, 2, 50, 6), (1, 100000, 64, 0, 64, 1, 0, 6), (2, 5
 # test_..._operand_gather; the last one is picked by tile_hint 0
 CASES += [(1, 4800, 1024, 0, 1024, 1, 48, 7), (2, 777, 32, 32, 72, 2, 50, 7), (1, 4100, 256, 0, 200, 1, -1, 7), (8, 192, 512, 256, 256, 2, 0, 7),
           (3, 301, 96, 0, 37, 1, 13, 7), (1, 130, 32, 0, 8, 0, 0, 7), (1, 70000, 256, 0, 256, 1, 0, 0)]
+# the tile-sequence form (hint 8 + 256 * plan; plan bits 0-3 = tiles per workgroup of region A, 4-7 = of region B, 8-15 / 16-22 = tiles / 16
+# of regions B / C): gathered and added epilogue rows, two sources, ragged channels and rows, a three-region plan; the last one is
+# picked by tile_hint 0
+SEQ = lambda ta, tb=1, b16=0, c16=0: 8 + 256 * (ta | tb << 4 | b16 << 8 | c16 << 16)      # noqa: E731
+CASES += [(1, 4800, 1024, 0, 1024, 1, 48, SEQ(2)), (2, 777, 160, 0, 392, 2, 50, SEQ(3)), (1, 4100, 256, 0, 200, 1, -1, SEQ(2)),
+          (8, 192, 512, 256, 520, 2, 0, SEQ(4)), (2, 2100, 128, 0, 640, 0, 0, SEQ(4, 2, 2, 2)), (1, 9000, 128, 128, 1024, 1, 300, SEQ(8, 2, 4, 8)),
+          (1, 140000, 128, 0, 256, 1, 0, 0)]
 
 
 @pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", CASES)
@@ -64,6 +71,31 @@ def test_mlp_pm_matches_fp64_reference(device, B, P, K1, K2, Cout, act, py, hint
                      gather=None if gather is None else (d(gather[0]), d(gather[1])), tile_hint=hint).cpu()
     assert got.shape == want.shape
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_tile_sequence_and_big_tile_forms_equal_the_lds_tiled_form_bit_for_bit(device):
+    """mlp_pm_seq_kernel (fp32, hint 8 + 256 * plan) and mlp_pm_big_kernel (bf16, hint 9) feed every accumulator the same products in
+    the same k order as mlp_pm_lds_kernel (hint 7) and run the same epilogue arithmetic: equal bits on the device -- with gathered and
+    added epilogue rows, two sources, no bias / identity activation (negative zeros must survive the additions of "nothing"), ragged
+    rows and channels, a three-region plan"""
+    g = torch.Generator().manual_seed(5)
+    d = lambda t: None if t is None else t.to(device)                                 # noqa: E731
+    for dt, hints in ((torch.float32, (SEQ(2), SEQ(3), SEQ(4, 2, 2, 2))), (BF, (9,))):
+        for B, P, K1, K2, C, py in ((2, 1500, 192, 0, 392, 40), (1, 2100, 128, 128, 640, -1), (3, 700, 256, 0, 520, 0)):
+            x1 = torch.randn(B, P, K1, generator=g).to(dt)
+            x2 = torch.randn(B, P, K2, generator=g).to(dt) if K2 else None
+            w = (torch.randn(C, K1 + K2, generator=g) / (K1 + K2) ** 0.5).to(dt)
+            bias = torch.randn(C, generator=g)
+            kw = {}
+            if py > 0:
+                kw["gather"] = (d(torch.randn(B, py, C, generator=g).to(dt)), d(torch.randint(0, py, (B, P), generator=g)))
+            elif py < 0:
+                kw["add"] = d(torch.randn(B, P, C, generator=g).to(dt))
+            for b, act in ((bias, 2), (None, 0)):
+                want = ops_pm.mlp(d(x1), d(w), d(b), act, x2=d(x2), tile_hint=7, **kw)
+                for h in hints:
+                    got = ops_pm.mlp(d(x1), d(w), d(b), act, x2=d(x2), tile_hint=h, **kw)
+                    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), (str(dt), K1, K2, C, py, act, h)
 
 
 def test_mlp_pm_channel_slices_and_int32_indices(device):
@@ -446,7 +478,12 @@ def _close_bf16(got, want, what=""):
                                                                   (1, 4100, 512, 0, 200, 1, -1, 7), (8, 192, 512, 256, 256, 2, 0, 7),
                                                                   (1, 70000, 512, 0, 256, 1, 0, 0)] +
     [(1, 100000, 64, 0, 64, 1, 0, 6), (2, 5001, 48, 0, 16, 0, 0, 6), (1, 4100, 256, 0, 128, 1, -1, 6), (3, 1300, 64, 96, 104, 2, 70, 6),
-     (1, 70000, 64, 64, 128, 1, 300, 0), (2, 20000, 256, 0, 64, 2, 0, 0)])
+     (1, 70000, 64, 64, 128, 1, 300, 0), (2, 20000, 256, 0, 64, 2, 0, 0)] +
+    # the 256 x 256 tile with LDS-DMA operand loads (hint 9, csrc/mlp_pm_big.hip; round 6): gathered / added epilogue rows, two sources,
+    # ragged rows and channels, channels not a multiple of 16 (the shared epilogue), one step short of the minimum; the last two are
+    # picked by tile_hint 0 (>= 512 tiles of 256 x 256)
+    [(1, 4800, 1024, 0, 1024, 1, 48, 9), (2, 777, 64, 64, 72, 2, 50, 9), (1, 4100, 512, 0, 200, 1, -1, 9), (8, 192, 512, 256, 256, 2, 0, 9),
+     (3, 301, 128, 0, 264, 1, 13, 9), (1, 520, 192, 64, 40, 0, 0, 9), (2, 38400, 512, 0, 512, 1, 192, 0), (1, 140000, 256, 0, 250, 2, -1, 0)])
 def test_mlp_pm_bf16(device, B, P, K1, K2, Cout, act, py, hint):
     g = torch.Generator().manual_seed(K1 + Cout + P)
     r = lambda *s: torch.randn(*s, generator=g).to(BF)                               # noqa: E731

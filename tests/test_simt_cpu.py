@@ -331,6 +331,29 @@ def test_folded_up_block_through_the_real_launchers(emu, B, cin, cout, h, w):
     assert float((got.permute(0, 3, 1, 2) - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("B,C,h,w,dt", [(2, 16, 6, 8, torch.float32), (1, 64, 9, 10, torch.bfloat16), (1, 32, 1, 1, torch.bfloat16),
+                                        (1, 48, 5, 17, torch.float32)])
+def test_upconv_combine_forms_are_bit_identical_on_the_emulator(emu, B, C, h, w, dt):
+    """csrc/upconv.hip: the LDS-staged form (8 x 16 output pixels of a 64-byte channel chunk per workgroup, window staged with LDS-DMA
+    loads; round 6) against the per-thread forms -- ragged tiles, one-pixel maps, several chunks, both precisions: equal bits"""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(C + h + w)
+    z = torch.randn(B, h, w, 9 * C, generator=g).to(dt)
+    z[0, h // 2, w // 2, 5] = float("nan")                     # a NaN stays confined to the outputs whose taps blend it
+    shift = torch.randn(C, generator=g)
+    outs = []
+    try:
+        for form in (3, 2, 1, 0):
+            lib.ffb6d_upconv_set_form(form)
+            outs.append(ops_pm.upconv_combine(z, shift, 0.25, (2 * h, 2 * w)))
+    finally:
+        lib.ffb6d_upconv_set_form(2)
+    for o in outs[1:]:
+        assert torch.equal(torch.isnan(o), torch.isnan(outs[0]))
+        assert torch.equal(torch.nan_to_num(o).view(torch.uint8), torch.nan_to_num(outs[0]).view(torch.uint8))
+    assert 0 < int(torch.isnan(outs[0]).sum()) < outs[0].numel() // 2
+
+
 @pytest.mark.parametrize("B,N,K,cout,dt", [(2, 40, 16, 16, torch.float32), (1, 33, 16, 128, torch.bfloat16), (3, 17, 5, 24, torch.float32)])
 def test_posenc_mlp_through_the_real_launcher(emu, B, N, K, cout, dt):
     from oracle import ops_ref
