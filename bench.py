@@ -65,8 +65,10 @@ def parse():
                     help="pinned (default): MIOpen reads the committed find-db of ONE search (ffb6d_amd/miopen_pin.py) instead of timing "
                          "its near-tied solvers again on every machine -- the same convolution kernels on every run; fresh: MIOpen's own "
                          "search on an empty user database (what rounds 1-4 measured: the step moves by +-0.4-0.8 ms with the draw)")
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="infer (default, the BASELINE metric): pyramid + forward, eval, no_grad.  train: BASELINE "
+    ap.add_argument("--mode", choices=["infer", "train", "e2e"], default="infer",
+                    help="e2e: sensor -> pose as one pipeline (ffb6d_amd/pipeline.py: input assembly from depth + rgb, forward with the "
+                         "pyramid inside, pose solver), serial and overlapped schedules in one line.  "
+                         "infer (default, the BASELINE metric): pyramid + forward, eval, no_grad.  train: BASELINE "
                          "config 3 shape -- pyramid + forward + backward + Adam step in train() mode, wrapped in "
                          "DistributedDataParallel (RCCL gradient all-reduce) when launched with more than one rank")
     ap.add_argument("--objective", choices=["reference", "proxy"], default="reference",
@@ -95,6 +97,7 @@ def parse():
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
+    ap.add_argument("--e2e-objects", type=int, default=5, help="--mode e2e: objects per frame of the synthetic vote field")
     ap.add_argument("--form", action="append", default=[], metavar="NAME=0|1",
                     help="A/B runs: set a boolean form attribute of ffb6d_amd.forward_pm (HEADS_SHARE_FIRST=0 ...) before the model is "
                          "built; the line's config.forms records what ran")
@@ -207,6 +210,89 @@ def cpu_baseline(args, sd):
     }
 
 
+def run_e2e(args, dev, net, frames):
+    """--mode e2e: K batches through ffb6d_amd.pipeline.SensorToPose, serial and overlapped; one JSON line."""
+    from ffb6d_amd import inputs, pipeline, pose, synth
+    B, N = args.batch, args.n_points
+    rgb = torch.from_numpy(frames["rgb"]).to(dev)                                         # uint8 [B,3,H,W]
+    depth = torch.from_numpy(np.ascontiguousarray(frames["dpt_xyz"][:, 2])).to(dev)       # metres, zeros where invalid
+    sensor = {"rgb": rgb, "depth": depth}
+    n_obj = args.e2e_objects
+    cases = [synth.make_pose_case(900 + b, n_pts=N, n_obj=n_obj, mesh_seed=9) for b in range(B)]
+    stack = lambda key: torch.from_numpy(np.stack([c[key] for c in cases])).to(dev)       # noqa: E731
+    votes = (stack("pcld"), stack("mask"), stack("ctr_of"), stack("kp_of"))
+    rng = np.random.RandomState(3)
+    n_cls = args.n_classes
+    variants = {
+        # the judge-specified workload: 5 objects per frame.  Random-init weights segment nothing, so the solver is fed a synthetic
+        # 5-object vote field of the same shapes; the stage still starts from the forward's completion event
+        "synthetic_votes": dict(pose_inputs=lambda inp, out: votes, mesh_kps=cases[0]["mesh_kps"], mesh_ctr=cases[0]["mesh_ctr"],
+                                r_lst=cases[0]["r_lst"]),
+        # the network's own (noise) votes: argmax of the segmentation, every class that occurs in a frame is solved
+        "network_votes": dict(pose_inputs=None, mesh_kps=((rng.rand(n_cls, 8, 3) - 0.5) * 0.2).astype(np.float32),
+                              mesh_ctr=((rng.rand(n_cls, 3) - 0.5) * 0.02).astype(np.float32),
+                              r_lst=(0.08 + 0.05 * rng.rand(n_cls - 1)).astype(np.float32)),
+    }
+    ev = lambda: torch.cuda.Event(enable_timing=True)                                     # noqa: E731
+    out = {}
+    K = args.steps
+    for name, kw in variants.items():
+        pipe = pipeline.SensorToPose(net, synth.LINEMOD_K, N, kw["mesh_kps"], kw["mesh_ctr"], r_lst=kw["r_lst"],
+                                     pose_inputs=kw["pose_inputs"], seed=7)
+        batches = [sensor] * K
+        res = {}
+        for mode in ("serial", "overlapped"):
+            pipe.run([sensor] * max(2, args.warmup), overlap=mode == "overlapped")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            poses = pipe.run(batches, overlap=mode == "overlapped")
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[mode] = {"ms_per_batch": 1e3 * dt / K, "frames_per_s": B * K / dt}
+            res[mode + "_objects_per_frame"] = float(np.mean([len(f[0]) for p in poses for f in p]))
+        # the three stages alone (HIP events / wall clock for the pose stage, which reads its results back)
+        inp = pipe.assemble(sensor, 0)
+        o = pipe.forward(inp)
+        torch.cuda.synchronize()
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(10):
+            pipe.assemble(sensor, 0)
+        b.record()
+        torch.cuda.synchronize()
+        res["stage_ms"] = {"inputs": a.elapsed_time(b) / 10}
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(5):
+            pipe.forward(inp)
+        b.record()
+        torch.cuda.synchronize()
+        res["stage_ms"]["forward"] = a.elapsed_time(b) / 5
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pipe.solve(inp, o)
+        torch.cuda.synchronize()
+        res["stage_ms"]["pose"] = 1e3 * (time.perf_counter() - t0) / 5
+        out[name] = res
+    main = out["synthetic_votes"]
+    line = {
+        "metric": f"RGB-D frames/sec sensor->pose (480x640, N={N}, bs={B}, {n_obj} objects/frame)", "value": main["overlapped"]["frames_per_s"],
+        "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": args.warmup, "ms_per_step": main["overlapped"]["ms_per_batch"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"sensor -> pose: depth + rgb resident in HBM -> normals, cloud, point sampling (inputs.py) -> FFB6D.forward incl. "
+                               f"the 22-call KNN index pyramid -> pose solver (mean-shift votes + least-squares fit) for {n_obj} objects per "
+                               f"frame; bs={B}, N={N}, 480x640, {args.precision}; serial = the three stages of a batch one after the other, "
+                               f"overlapped = input assembly of batch i+1 and pose solver of batch i on side streams under the forward of "
+                               f"batch i+1 (ffb6d_amd/pipeline.py)"},
+        "e2e": out,
+        "reference_published": "57 ms forward + 18 ms pose = 75 ms per FRAME on the reference's GPU (README.md:305-330); other hardware, "
+                               "not a baseline for vs_baseline",
+        "roofline": None,
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -287,6 +373,14 @@ def main():
               for s in range(args.batch)]
         targets = tuple(torch.from_numpy(np.stack([t[k] for t in tg])).to(dev) for k in ("labels", "kp_targ_ofst", "ctr_targ_ofst"))
         targets = (targets[0].long(),) + targets[1:]
+
+    if args.mode == "e2e":
+        if world > 1:
+            raise SystemExit("--mode e2e is a one-GPU pipeline record")
+        net.two_streams, net.precision, net.index_dtype = bool(args.streams == 2), args.precision, idt
+        run_e2e(args, dev, net, frames)
+        group.close()
+        return
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     phase = {"pyramid": [], "forward": []}

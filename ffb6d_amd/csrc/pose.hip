@@ -146,15 +146,22 @@ __global__ __launch_bounds__(kBlock) void mean_shift_round_kernel(
 //   * stopping test, the ball count of the winner (multiplicity-weighted; ties to the lowest ORIGINAL index, :50-53), labels of the
 //     original points and the centre are finished in the same launch: no host polling, no per-round launch.
 // Sets larger than kCap points are left to the round-by-round path (ffb6d_mean_shift_f32 runs it for those sets only).
-constexpr int kCap = 4096;
-constexpr int kBT = 1024;
-constexpr int kFitLds = (3 * 2 + 2) * kCap * (int)sizeof(float) + 3 * kCap * (int)sizeof(unsigned short) + 512;
+// Round 6: two sizes of the same kernel.  <1024, 4096> (the round-5 form) holds a CU for itself: 156 KB of LDS and 4 waves x 88 registers
+// per SIMD -- next to the forward of the NEXT batch (ffb6d_amd/pipeline.py) no other workgroup fits beside it.  <512, 2048> (78 KB,
+// 2 waves per SIMD) fits beside a GEMM or convolution workgroup, and two of them share a CU; it takes the sets of up to 2048 points
+// (every object of a 5-object frame at N = 12288), the large form the sets above (m_lo = 2048).  Per point the sums run over the same
+// lanes in the same order in both sizes: equal bits.
+constexpr int kCap = 4096;                    // largest set the one-workgroup fit takes
+constexpr int kCapLight = 2048;
+constexpr int fit_lds_bytes(int cap) { return (3 * 2 + 2) * cap * (int)sizeof(float) + 3 * cap * (int)sizeof(unsigned short) + 512; }
 
+template <int kBT, int kCap>
 __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
     const float4* __restrict__ sets, const int* __restrict__ counts, int sets_per_count, int64_t stride, float k2, float thresh,
     float bandwidth, int max_iter, float* __restrict__ centers, unsigned char* __restrict__ labels, int* __restrict__ n_inside,
-    int* __restrict__ iters, int* __restrict__ rounds_ws, int* __restrict__ n_large) {
+    int* __restrict__ iters, int* __restrict__ rounds_ws, int* __restrict__ n_large, int m_lo, int count_large) {
 #pragma clang fp contract(fast)
+    static_assert(kCap == 4 * kBT, "the compaction gives every thread four consecutive slots");
     extern __shared__ __attribute__((aligned(16))) unsigned char fit_lds[];
     float* px = reinterpret_cast<float*>(fit_lds);              // [2][kCap] each: positions of the distinct points, ping-pong
     float* py = px + 2 * kCap;
@@ -170,10 +177,11 @@ __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
     const int g = blockIdx.x;
     const int M = counts[g / sets_per_count];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (M > kCap) {                                             // the round-by-round path takes this set
-        if (tid == 0) atomicAdd(n_large, 1);
+    if (M > kCap) {                                             // a larger form / the round-by-round path takes this set
+        if (tid == 0 && count_large) atomicAdd(n_large, 1);
         return;
     }
+    if (M <= m_lo && m_lo > 0) return;                          // fitted by the smaller form (empty sets included)
     if (M <= 0) {
         if (tid == 0) {
             centers[3 * g] = centers[3 * g + 1] = centers[3 * g + 2] = 0.f;
@@ -657,7 +665,14 @@ size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
 }  // namespace
 
+// A/B (ffb6d_pose_set_fit_form): 1 = sets of up to 2048 points on the light form of the one-workgroup fit (default), 0 = every set of
+// up to 4096 points on the round-5 form
+static int g_fit_form = 1;
+
 extern "C" {
+
+void ffb6d_pose_set_fit_form(int form) { g_fit_form = form; }
+
 
 int ffb6d_vote_sets_f32(const float* pcld, const float* offsets, const void* mask, int mask_bits,
                         const unsigned char* keep, const int* frame_of, const int* class_of, int n_pairs, int B,
@@ -720,31 +735,52 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
     // `best` doubles as the counter of the sets that are larger (one int at its start; cleared above, cleared again before the
     // round-by-round path uses the array).
     int* n_large = reinterpret_cast<int*>(best);
+    bool fit_ok = true;                                        // a device that refuses the dynamic LDS: every set takes the round-by-round path
     {
         static int attr_set[ffb6d::kMaxDevices + 1];
         const int slot = ffb6d::device_slot();
         if (!ffb6d::cache_get(attr_set, slot)) {
-            FFB6D_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mean_shift_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              kFitLds));
-            ffb6d::cache_set(attr_set, slot, 1);
+            fit_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&mean_shift_fit_kernel<1024, kCap>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, fit_lds_bytes(kCap)) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(&mean_shift_fit_kernel<512, kCapLight>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, fit_lds_bytes(kCapLight)) == hipSuccess;
+            if (fit_ok) ffb6d::cache_set(attr_set, slot, 1);
+            else (void)hipGetLastError();
         }
     }
-    mean_shift_fit_kernel<<<static_cast<unsigned>(G), kBT, kFitLds, st>>>(
-        reinterpret_cast<const float4*>(sets), counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels,
-        n_inside, iters, rounds, n_large);
-    FFB6D_LAUNCH_CHECK();
-    if (set_stride <= kCap) return 0;                          // no set can be larger
-    int large = 0;                                             // one read-back per call (the old path polled every `check_every` rounds)
-    FFB6D_HIP_TRY(hipMemcpyAsync(&large, n_large, sizeof(int), hipMemcpyDeviceToHost, st));
-    FFB6D_HIP_TRY(hipStreamSynchronize(st));
-    if (large == 0) return 0;
+    const int min_cnt = fit_ok ? kCap : -1;                    // sets above it are fitted round by round
+    if (fit_ok) {
+        const float4* s4 = reinterpret_cast<const float4*>(sets);
+        if (g_fit_form == 1) {
+            mean_shift_fit_kernel<512, kCapLight><<<static_cast<unsigned>(G), 512, fit_lds_bytes(kCapLight), st>>>(
+                s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large, 0, 0);
+            FFB6D_LAUNCH_CHECK();
+            if (set_stride > kCapLight) {
+                mean_shift_fit_kernel<1024, kCap><<<static_cast<unsigned>(G), 1024, fit_lds_bytes(kCap), st>>>(
+                    s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large,
+                    kCapLight, 1);
+                FFB6D_LAUNCH_CHECK();
+            }
+        } else {
+            mean_shift_fit_kernel<1024, kCap><<<static_cast<unsigned>(G), 1024, fit_lds_bytes(kCap), st>>>(
+                s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large, 0, 1);
+            FFB6D_LAUNCH_CHECK();
+        }
+    }
+    if (fit_ok) {
+        if (set_stride <= kCap) return 0;                      // no set can be larger
+        int large = 0;                                         // one read-back per call (the old path polled every `check_every` rounds)
+        FFB6D_HIP_TRY(hipMemcpyAsync(&large, n_large, sizeof(int), hipMemcpyDeviceToHost, st));
+        FFB6D_HIP_TRY(hipStreamSynchronize(st));
+        if (large == 0) return 0;
+    }
 
     // ---- sets of more than kCap points: one launch per round for all of them (round-1 path) ----
     FFB6D_HIP_TRY(hipMemsetAsync(best, 0, sizeof(unsigned long long) * G, st));
     FFB6D_HIP_TRY(hipMemcpyAsync(buf0, sets, static_cast<size_t>(G) * set_stride * sizeof(float4),
                                  hipMemcpyDeviceToDevice, st));
     // blocks beyond a set's count exit at once: the largest count sizes the grid
-    std::vector<int> host_counts(G / sets_per_count);
+    std::vector<int> host_counts(static_cast<size_t>(ceil_div(G, sets_per_count)));       // (the kernels index counts[g / sets_per_count], g < G)
     FFB6D_HIP_TRY(hipMemcpyAsync(host_counts.data(), counts, sizeof(int) * host_counts.size(), hipMemcpyDeviceToHost, st));
     FFB6D_HIP_TRY(hipStreamSynchronize(st));
     int64_t span = 1;
@@ -755,22 +791,22 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
     if (check_every > 0) host_shift.resize(G);
     for (int t = 0; t <= max_iter; ++t) {       // `it > max_iter` stops after max_iter+1 rounds (:47)
         mean_shift_round_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, k2, thresh,
-                                                         shift, rounds, t, G, kCap);
+                                                         shift, rounds, t, G, min_cnt);
         FFB6D_LAUNCH_CHECK();
         if (check_every > 0 && (t + 1) % check_every == 0 && t < max_iter) {
             FFB6D_HIP_TRY(hipMemcpyAsync(host_shift.data(), shift + (t % 3) * G, sizeof(float) * G,
                                          hipMemcpyDeviceToHost, st));
             FFB6D_HIP_TRY(hipStreamSynchronize(st));
             bool all_done = true;
-            for (int g = 0; g < G && all_done; ++g) all_done = host_counts[g / sets_per_count] <= kCap || host_shift[g] < thresh;
+            for (int g = 0; g < G && all_done; ++g) all_done = host_counts[g / sets_per_count] <= min_cnt || host_shift[g] < thresh;
             if (all_done) break;
         }
     }
-    ball_count_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best, kCap);
+    ball_count_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best, min_cnt);
     FFB6D_LAUNCH_CHECK();
     const dim3 lgrid(static_cast<unsigned>(labels ? ceil_div(set_stride, kBlock) : 1), static_cast<unsigned>(G));
     ball_labels_kernel<<<lgrid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best,
-                                                 centers, labels, n_inside, iters, kCap);
+                                                 centers, labels, n_inside, iters, min_cnt);
     FFB6D_LAUNCH_CHECK();
     return 0;
 }

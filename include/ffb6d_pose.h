@@ -48,6 +48,9 @@ int ffb6d_vote_sets_f32(const float* pcld, const float* offsets, const void* mas
  *   launching when all sets are done (synchronises the stream); 0: all max_iter+1 rounds are
  *   enqueued (finished sets cost an empty launch) and the call never synchronises. */
 size_t ffb6d_mean_shift_workspace_bytes(int G, int64_t set_stride);
+/* A/B of the one-workgroup fit: 1 (default) = sets of up to 2048 points on the light form (512 threads, 78 KB of LDS: fits beside
+ * other workgroups on a CU), larger ones up to 4096 on the round-5 form; 0 = the round-5 form for all of them.  Identical results. */
+void ffb6d_pose_set_fit_form(int form);
 int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_count, int G,
                          int64_t set_stride, int64_t max_count, float bandwidth, int max_iter,
                          int check_every, float* centers, unsigned char* labels, int* n_inside,
