@@ -673,7 +673,7 @@ def main():
                        "forms": {"lfa_fused": forward_pm.LFA_FUSED, "posenc_fused": forward_pm.POSENC_FUSED, "stem_fused": forward_pm.STEM_FUSED,
                                  "last_stage_at_chosen": forward_pm.LAST_STAGE_AT_CHOSEN, "heads_share_first": forward_pm.HEADS_SHARE_FIRST, "heads_align_last": forward_pm.HEADS_ALIGN_LAST,
                                  "heads_on_both_streams": forward_pm.HEADS_ON_BOTH_STREAMS, "heads_chain_fused": forward_pm.HEADS_CHAIN_FUSED,
-                                 "gemm_seq_form": forward_pm.GEMM_SEQ_FORM, "gemm_big_form": forward_pm.GEMM_BIG_FORM,
+                                 "gemm_seq_form": forward_pm.GEMM_SEQ_FORM, "gemm_big_form": forward_pm.GEMM_BIG_FORM, "gemm_seq_lin": forward_pm.GEMM_SEQ_LIN, "gemm_seq_lin_one": forward_pm.GEMM_SEQ_LIN_ONE,
                                  "miopen": ("find mode (cudnn.benchmark), " if args.cudnn_benchmark else "immediate mode, ") + miopen_db,
                                  "upconv_fold": forward_pm.UPCONV_FOLD if isinstance(forward_pm.UPCONV_FOLD, str) else
                                  (None if forward_pm.UPCONV_FOLD is None else sorted(forward_pm.UPCONV_FOLD)),

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ffb6d_mlp_pm_choice": (_i32, [_i64, _i64, _i64, _i64, _i32, _i32, _i32]),
     "ffb6d_mlp_pm_seq_plan": (_i32, [_i64, _i64]),
     "ffb6d_mlp_pm_set_big_form": (None, [_i32]),
+    "ffb6d_mlp_pm_set_seq_lin": (None, [_i32]),
     "ffb6d_att_pool_pm_f32": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _vp]),
     "ffb6d_mlp_pm_bf16": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _i64, _vp,
                                  _i64, _i64, _i64, _i32, _i32, _vp]),

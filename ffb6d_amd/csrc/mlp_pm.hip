@@ -678,17 +678,39 @@ mlp_pm_seq_kernel(const PmParams p)
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [2 stages][W image | X image], bias of the group [tpg * 128] fp32
 
-    int t = blockIdx.x, tpg = p.tpg, pt_lo = 0, pt_hi = p.pt_b;
-    if (t >= p.wg_c) { t -= p.wg_c; tpg = 1; pt_lo = p.pt_c; pt_hi = p.n_pt; }
-    else if (t >= p.wg_b) { t -= p.wg_b; tpg = p.tpg_b; pt_lo = p.pt_b; pt_hi = p.pt_c; }
-    const int n_grp = (p.n_ct + tpg - 1) / tpg;
-    const int xcd = t & 7, sl = t >> 3;
-    const int pt = pt_lo + (sl / n_grp) * 8 + xcd;
-    const int grp = sl % n_grp;
-    if (pt >= pt_hi) return;
-    const int ct0 = grp * tpg;
-    const int ntile = min(tpg, p.n_ct - ct0);
-    const int r0 = pt * 128;
+    // LIN (round 6, p.lin_wg > 0): the tiles of the point tiles of ONE XCD (pt = xcd, xcd + 8, ...; channel tiles fastest) form one list,
+    // cut into p.lin_wg contiguous sequences whose lengths differ by at most one, the longer ones first in dispatch order.  A sequence may
+    // run from one point tile into the next (the X rows change, the W rows start over): with whole-point-tile groups the 2400 tiles of
+    // 1024 -> 1024 on 38400 rows made 1200 workgroups of 2 on 512 slots = three rounds of two tiles, now 512 sequences of 4-5.
+    const bool LIN = p.lin_wg > 0;
+    int pt, ct0, ntile, bias_base, n_bias;
+    if (LIN) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int n_pt_x = (p.n_pt - xcd + 7) >> 3, L = n_pt_x * p.n_ct;
+        const int base = L / p.lin_wg, rem = L - base * p.lin_wg;
+        const int start = j * base + min(j, rem);
+        ntile = base + (j < rem ? 1 : 0);
+        if (j >= p.lin_wg || ntile == 0) return;
+        const int pi = start / p.n_ct;
+        ct0 = start - pi * p.n_ct;
+        pt = xcd + 8 * pi;
+        bias_base = 0;
+        n_bias = p.n_ct * 128;
+    } else {
+        int t = blockIdx.x, tpg = p.tpg, pt_lo = 0, pt_hi = p.pt_b;
+        if (t >= p.wg_c) { t -= p.wg_c; tpg = 1; pt_lo = p.pt_c; pt_hi = p.n_pt; }
+        else if (t >= p.wg_b) { t -= p.wg_b; tpg = p.tpg_b; pt_lo = p.pt_b; pt_hi = p.pt_c; }
+        const int n_grp = (p.n_ct + tpg - 1) / tpg;
+        const int xcd = t & 7, sl = t >> 3;
+        pt = pt_lo + (sl / n_grp) * 8 + xcd;
+        const int grp = sl % n_grp;
+        if (pt >= pt_hi) return;
+        ct0 = grp * tpg;
+        ntile = min(tpg, p.n_ct - ct0);
+        bias_base = ct0 * 128;
+        n_bias = ntile * 128;
+    }
+    int r0 = pt * 128;                                // rows of the tile being multiplied (LIN: moves on with the sequence)
 
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -709,27 +731,31 @@ mlp_pm_seq_kernel(const PmParams p)
 
     // bias of the group's channels -> LDS (-0.0f where there is none: x + (-0.0f) == x for every x, the sign of a zero included)
     float* bias_lds = reinterpret_cast<float*>(lds + 4 * IMG);
-    for (int c = threadIdx.x; c < ntile * 128; c += BLK) {
-        const int ch = ct0 * 128 + c;
+    for (int c = threadIdx.x; c < n_bias; c += BLK) {
+        const int ch = bias_base + c;
         bias_lds[c] = (p.bias && ch < p.cout) ? p.bias[ch] : -0.0f;
     }
 
     // loader: thread -> 16-byte chunk lchunk of the 128-byte segment of rows lrow + 32 i (i < 4), for W and for X
     const int lchunk = threadIdx.x & 7, lrow = threadIdx.x >> 3;
     int w_off[4], x1_off[4], x2_off[4];
+    auto set_x = [&](int rbase) {                     // the loader's X rows: point tile at row rbase
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + lrow + 32 * i;
-        x1_off[i] = OOB;
-        x2_off[i] = OOB;
-        if (r < p.rows) {
-            int xr = r;
-            if (p.xidx)
-                xr = (r / p.P) * p.px + (p.idx64 ? (int)static_cast<const long long*>(p.xidx)[r] : static_cast<const int*>(p.xidx)[r]);
-            x1_off[i] = xr * p.ld1 * SZ + lchunk * 16;
-            x2_off[i] = r * p.ld2 * SZ + lchunk * 16;
+        for (int i = 0; i < 4; ++i) {
+            const int r = rbase + lrow + 32 * i;
+            x1_off[i] = OOB;
+            x2_off[i] = OOB;
+            if (r < p.rows) {
+                int xr = r;
+                if (p.xidx)
+                    xr = (r / p.P) * p.px + (p.idx64 ? (int)static_cast<const long long*>(p.xidx)[r] : static_cast<const int*>(p.xidx)[r]);
+                x1_off[i] = xr * p.ld1 * SZ + lchunk * 16;
+                x2_off[i] = r * p.ld2 * SZ + lchunk * 16;
+            }
         }
-    }
+    };
+    set_x(r0);
+    int l_r0 = r0;                                    // the loader's point tile (it runs two steps ahead of the multiplies)
     auto set_w = [&](int ct) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -756,6 +782,16 @@ mlp_pm_seq_kernel(const PmParams p)
         if (++l_s == nstage) {
             l_s = 0;
             ++l_ct;
+            if (LIN && l_ct == p.n_ct) {              // on to the next point tile of this XCD (the launcher sends no gathered X rows here:
+                l_ct = 0;                             // pure arithmetic, no load inside the counted-wait region)
+                l_r0 += 8 * 128;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = l_r0 + lrow + 32 * i;
+                    x1_off[i] = r < p.rows ? r * p.ld1 * SZ + lchunk * 16 : OOB;
+                    x2_off[i] = r < p.rows ? r * p.ld2 * SZ + lchunk * 16 : OOB;
+                }
+            }
             set_w(l_ct);                              // past the last tile: never used
         }
     };
@@ -770,22 +806,25 @@ mlp_pm_seq_kernel(const PmParams p)
     };
 
     // epilogue geometry of this lane: two output rows (j), their Y rows, as byte offsets into the buffers
-    int o_off[2], y_off[2];
+    int o_off[2], y_off[2], po_off[2], py_off[2];      // of the tile being multiplied / of the finished tile whose epilogue is riding
+    auto set_rows = [&](int rbase) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = r0 + (wn * 2 + j) * 32 + l31;
-        o_off[j] = OOB;
-        y_off[j] = OOB;
-        if (r < p.rows) {
-            o_off[j] = r * p.ldo * SZ;
-            if (p.y) {
-                int yr = r;
-                if (p.gidx)
-                    yr = (r / p.P) * p.py + (p.idx64 ? (int)static_cast<const long long*>(p.gidx)[r] : static_cast<const int*>(p.gidx)[r]);
-                y_off[j] = yr * p.ldy * SZ;
+        for (int j = 0; j < 2; ++j) {
+            const int r = rbase + (wn * 2 + j) * 32 + l31;
+            o_off[j] = OOB;
+            y_off[j] = OOB;
+            if (r < p.rows) {
+                o_off[j] = r * p.ldo * SZ;
+                if (p.y) {
+                    int yr = r;
+                    if (p.gidx)
+                        yr = (r / p.P) * p.py + (p.idx64 ? (int)static_cast<const long long*>(p.gidx)[r] : static_cast<const int*>(p.gidx)[r]);
+                    y_off[j] = yr * p.ldy * SZ;
+                }
             }
         }
-    }
+    };
+    set_rows(r0);
     const float slope = p.act == 0 ? 1.f : (p.act == 1 ? 0.f : 0.2f);
     const float y_on = p.y ? 1.f : 0.f;               // (no Y: the registers hold the zeros of an out-of-range load; x + (-0.0f) == x)
 
@@ -804,17 +843,17 @@ mlp_pm_seq_kernel(const PmParams p)
     auto piece_off = [&](int q, int c0t, const int (&row_off)[2]) {          // byte offset of piece q's 16 bytes in a row buffer, OOB if dead
         const int j = q >> 3, i = (q >> 2) & 1, gq = q & 3;
         const int ch = c0t + (wm * 2 + i) * 32 + 8 * gq + 4 * kh;
-        return ch < p.cout ? max(row_off[j], row_off[j] + ch * SZ) : OOB;  // (a dead row: OOB + ch * SZ wraps negative, max keeps OOB)
+        return (ch < p.cout && row_off[j] != OOB) ? row_off[j] + ch * SZ : OOB;      // (a dead row / channel: out of range, nothing moves)
     };
     auto yload = [&](int ph, int c0t) {               // pieces 4 ph .. 4 ph + 3 of the tile at c0t
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) yreg[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, piece_off(4 * ph + ks, c0t, y_off), 0, 0);
+        for (int ks = 0; ks < 4; ++ks) yreg[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, piece_off(4 * ph + ks, c0t, py_off), 0, 0);
     };
     auto piece = [&](int ph, int ks) {
         const int q = 4 * ph + ks;
         const int j = q >> 3, i = (q >> 2) & 1, gq = q & 3;
         const int ch = pc0 + (wm * 2 + i) * 32 + 8 * gq + 4 * kh;
-        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + (ch - ct0 * 128));
+        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + (ch - bias_base));
         u32x4 ou;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -823,7 +862,7 @@ mlp_pm_seq_kernel(const PmParams p)
             u += y_on != 0.f ? yv : -0.0f;
             ou[c] = __float_as_uint(activate(u, slope));
         }
-        __builtin_amdgcn_raw_buffer_store_b128(ou, rs_o, piece_off(q, pc0, o_off), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(ou, rs_o, piece_off(q, pc0, po_off), 0, 0);
     };
 
     int g = 0;                                        // step of the workgroup's sequence being multiplied
@@ -890,6 +929,13 @@ mlp_pm_seq_kernel(const PmParams p)
             }
         pc0 = c0;
         c0 += 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { po_off[j] = o_off[j]; py_off[j] = y_off[j]; }
+        if (LIN && c0 == p.n_ct * 128) {              // this tile is the first one of the next point tile
+            c0 = 0;
+            r0 += 8 * 128;
+            set_rows(r0);
+        }
         yload(0, pc0);
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
@@ -1070,11 +1116,34 @@ bool launch_lds(PmParams& p, hipStream_t st)
     return true;
 }
 
+// plan bits 4-7 == 15 (no region-B length): balanced contiguous sequences per XCD, bits 0-3 = sequences per workgroup slot
+inline bool seq_plan_is_lin(int plan) { return ((plan >> 4) & 15) == 15; }
+
 template <bool TWO>
 bool launch_seq(PmParams& p, int plan, hipStream_t st)
 {
     p.n_ct = (int)ceil_div(p.cout, 128);
     p.n_pt = (int)ceil_div(p.rows, 128);
+    static int attr_set[kMaxDevices + 1];                                      // per device (common.h: device_slot)
+    const int slot = device_slot();
+    if (!cache_get(attr_set, slot)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pm_seq_kernel<TWO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * 2 * 128 * (128 + 16) + 8 * 128 * (int)sizeof(float)) != hipSuccess)
+            return false;
+        cache_set(attr_set, slot, 1);
+    }
+    if (seq_plan_is_lin(plan) && p.n_ct <= 8 && !p.xidx) {
+        // balanced contiguous sequences per XCD, `rounds` of them per workgroup slot (two slots per CU, 32 CUs per XCD)
+        const int rounds = std::max(1, std::min(plan & 15, 15));
+        const int64_t L = ceil_div(p.n_pt, 8) * p.n_ct;                        // tiles of the fullest XCD
+        p.lin_wg = (int)std::min<int64_t>(64 * rounds, L);
+        if ((plan >> 8) & 255) p.lin_wg = (int)std::min<int64_t>((plan >> 8) & 255, L);     // explicit sequence count per XCD (tests)
+        p.tpg = p.tpg_b = 1; p.pt_b = p.pt_c = p.wg_b = p.wg_c = 0;
+        const size_t lds = 2 * 2 * 128 * (128 + 16) + (size_t)p.n_ct * 128 * sizeof(float);
+        hipLaunchKernelGGL((mlp_pm_seq_kernel<TWO>), dim3((unsigned)(8 * p.lin_wg)), dim3(BLK), lds, st, p);
+        return true;
+    }
+    if (seq_plan_is_lin(plan)) plan = 2;              // (gathered X rows / more than 8 channel tiles: whole-point-tile pairs)
     // plan: bits 0-3 tiles per workgroup in region A, 4-7 in region B, 8-15 tiles of region B / 16, 16-22 tiles of region C / 16
     p.tpg = std::max(1, std::min(plan & 15, std::min(p.n_ct, 8)));
     p.tpg_b = std::max(1, std::min((plan >> 4) & 15, p.tpg));
@@ -1092,14 +1161,6 @@ bool launch_seq(PmParams& p, int plan, hipStream_t st)
     p.wg_c = p.wg_b + (int)((p.pt_c - p.pt_b) / 8 * grp_b * 8);
     const int64_t grid = p.wg_c + ceil_div(p.n_pt - p.pt_c, 8) * p.n_ct * 8;
     const size_t lds = 2 * 2 * 128 * (128 + 16) + (size_t)p.tpg * 128 * sizeof(float);
-    static int attr_set[kMaxDevices + 1];                                      // per device (common.h: device_slot)
-    const int slot = device_slot();
-    if (!cache_get(attr_set, slot)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_pm_seq_kernel<TWO>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * 2 * 128 * (128 + 16) + 8 * 128 * (int)sizeof(float)) != hipSuccess)
-            return false;
-        cache_set(attr_set, slot, 1);
-    }
     hipLaunchKernelGGL((mlp_pm_seq_kernel<TWO>), dim3((unsigned)grid), dim3(BLK), lds, st, p);
     return true;
 }
@@ -1365,6 +1426,11 @@ extern "C" int ffb6d_mlp_pm_choice(int64_t rows, int64_t cout, int64_t k1, int64
 
 // Schedule of the tile-sequence form (see launch_seq for the bit fields): sequence length T of region A, T / 2 in region B, single tiles in
 // region C -- the workgroups the dispatcher hands out last are short, so the 512 slots of the chip drain together.
+// A/B (ffb6d_mlp_pm_set_seq_lin): 0 = whole-point-tile groups in three regions (round 5) for every layer; 1 = balanced sequences, at least
+// two per workgroup slot; 2 = ONE balanced sequence per slot (fastest alone on the chip, profiles/r06_seq_lin_probe.txt)
+static int g_seq_lin = 0;
+extern "C" void ffb6d_mlp_pm_set_seq_lin(int on) { g_seq_lin = on; }
+
 extern "C" int ffb6d_mlp_pm_seq_plan(int64_t rows, int64_t cout)
 {
     // Measured on the long-row launches of the bench step (profiles/r05_seq_gemm_sweep.txt; sweep over T, the regions' sizes):
@@ -1374,6 +1440,14 @@ extern "C" int ffb6d_mlp_pm_seq_plan(int64_t rows, int64_t cout)
     //     tiles (with 2-3 channel tiles per point tile the tail of single tiles measured slower than none).
     const int64_t n_pt = ceil_div(rows, 128), n_ct = ceil_div(cout, 128), tiles = n_pt * n_ct;
     if (n_ct < 2 || tiles < 1024) return 1;
+    if (g_seq_lin && n_ct <= 8) {
+        // round 6: balanced contiguous sequences (they may run from one point tile into the next).  Sequences of ~3 tiles, at least two
+        // per workgroup slot: the dispatcher keeps something to hand out (one resident sequence per slot lost inside the
+        // three-stream step in round 4), the slots drain together (lengths differ by one, the longer ones first)
+        const int64_t per_slot = ceil_div(ceil_div(n_pt, 8) * n_ct, 64);       // tiles per slot of the fullest XCD
+        const int64_t rounds = g_seq_lin == 2 ? 1 : std::min<int64_t>(15, std::max<int64_t>(2, (per_slot + 1) / 3));
+        return (int)(0xF0 | rounds);
+    }
     const int64_t cap = std::min<int64_t>(n_ct, 8);
     int64_t ta = std::min<int64_t>(cap, std::max<int64_t>(2, tiles / 1024));
     if (n_ct % ta != 0) {

@@ -31,6 +31,8 @@ struct PmParams {
     // dispatcher hands out are short ones).  Region A = point tiles [0, pt_b): tpg tiles per workgroup; B = [pt_b, pt_c): tpg_b;
     // C = [pt_c, n_pt): one tile per workgroup.  wg_b / wg_c = first workgroup of regions B / C.
     int tpg, tpg_b, pt_b, pt_c, wg_b, wg_c;
+    // ... or (round 6) lin_wg > 0: every XCD's tile list cut into lin_wg balanced contiguous sequences (mlp_pm_seq_kernel: LIN)
+    int lin_wg = 0;
 };
 
 // epilogue shared by the GEMM kernels: bias, gathered / added row of Y, activation or log-softmax, store

@@ -151,6 +151,14 @@ GEMM_SEQ_FORM = True
 # The long-row bf16 GEMMs with K >= 256 on the 256 x 256 tile with LDS-DMA operand loads (csrc/mlp_pm_big.hip); False: the LDS-tiled
 # 128 x 128 form for those launches.  Equal bits.
 GEMM_BIG_FORM = True
+# Schedule of the tile-sequence form: balanced contiguous sequences per XCD (round 6; csrc/mlp_pm.hip: LIN) instead of whole-point-tile groups
+# (round 5).  GEMM_SEQ_LIN_ONE: one sequence per workgroup slot instead of at least two.  Equal bits.  Measured and left OFF: alone on the
+# chip the seven launches of a step take 3337 / 3295 us against 3361 (+0.7 / +2 %: profiles/r06_seq_lin_probe.txt -- the dispatcher
+# back-fills the round-5 groups well enough that the quantisation the tile counts suggest, 6 tile times against 5, does not materialise),
+# and inside the three-stream step both are 0.07 ms SLOWER (profiles/r06_seq_lin_in_step_ab.json: 19.82 -> 19.89 ms; longer resident
+# sequences get in the way of the side streams' kernels, as the persistent forms of round 4 did).
+GEMM_SEQ_LIN = False
+GEMM_SEQ_LIN_ONE = False
 LFA_WIDTHS = (32, 64, 128, 256)
 
 
@@ -477,6 +485,7 @@ def forward(net, inputs, end_points, two_streams=True, taps=None):
     dt = torch.bfloat16 if getattr(net, "precision", "fp32") == "bf16" else torch.float32
     ops_pm.MLP_SEQ_FORM = GEMM_SEQ_FORM
     ops_pm.MLP_BIG_FORM = GEMM_BIG_FORM
+    ops_pm.MLP_SEQ_LIN = (2 if GEMM_SEQ_LIN_ONE else 1) if GEMM_SEQ_LIN else 0
     main = torch.cuda.current_stream(dev)
     side = net._side_stream(dev) if two_streams else main
     if two_streams:

@@ -34,14 +34,20 @@ MLP_SEQ_FORM = True
 # the 256 x 256 bf16 tile with LDS-DMA operand loads (csrc/mlp_pm_big.hip, round 6); False = the LDS-tiled 128 x 128 form on those launches
 # (bit-identical results; forward_pm.GEMM_BIG_FORM sets it per forward)
 MLP_BIG_FORM = True
-_big_form_set = None
+# schedule of the tile-sequence form (csrc/mlp_pm.hip: LIN): 0 = the round-5 plans (whole-point-tile groups in three regions), 1 = balanced
+# contiguous sequences per XCD with at least two per workgroup slot, 2 = one per slot; forward_pm.GEMM_SEQ_LIN sets it per forward
+MLP_SEQ_LIN = 0
+_big_form_set = _seq_lin_set = None
 
 
 def _sync_big_form(lib):
-    global _big_form_set
+    global _big_form_set, _seq_lin_set
     if _big_form_set is not MLP_BIG_FORM:
         lib.ffb6d_mlp_pm_set_big_form(int(MLP_BIG_FORM))
         _big_form_set = MLP_BIG_FORM
+    if _seq_lin_set != MLP_SEQ_LIN:
+        lib.ffb6d_mlp_pm_set_seq_lin(int(MLP_SEQ_LIN))
+        _seq_lin_set = MLP_SEQ_LIN
 
 
 def mlp(x1, w, bias=None, act=ACT_NONE, x2=None, add=None, gather=None, x1_gather=None, out=None, tile_hint=0, role="path"):

@@ -147,6 +147,10 @@ int ffb6d_mlp_pm_choice(int64_t rows, int64_t cout, int64_t k1, int64_t k2, int 
  * tiles, bits 4-7 = T of the second region, bits 8-15 / 16-22 = tiles (in units of 16) of the second region / of the last region, whose
  * workgroups take one tile each -- a guided schedule: the workgroups handed out last are short.  Identical results. */
 int ffb6d_mlp_pm_seq_plan(int64_t rows, int64_t cout);
+/* Round 6: plan = 0xF0 | rounds (| sequences per XCD << 8): every XCD's tile list (its point tiles, channel tiles fastest) is cut into
+ * 64 * rounds contiguous sequences whose lengths differ by at most one, the longer ones first -- a sequence may run from one point tile
+ * into the next.  What ffb6d_mlp_pm_seq_plan returns for layers of <= 8 channel tiles; ffb6d_mlp_pm_set_seq_lin(0) = the round-5 plans. */
+void ffb6d_mlp_pm_set_seq_lin(int on);
 /* 9 (round 6, bf16): the 256 x 256 tile with LDS-DMA operand loads (csrc/mlp_pm_big.hip: `buffer_load_dwordx4 ... lds` into
  * chunk-permuted 128-byte image rows, eight waves, one workgroup per CU) -- ffb6d_mlp_pm_choice returns it for the bf16 launches with
  * K >= 256, cout >= 192 and at least 512 such tiles; ffb6d_mlp_pm_set_big_form(0) keeps the automatic choice on form 7 (A/B).

@@ -19,6 +19,7 @@ SHAPES = [(1024, 0, 2304, 8, 4800, 0, "cnn  z-GEMM 60x80"), (1024, 0, 1024, 8, 4
           (512, 0, 1024, 8, 4800, 0, "cnn  psp bottleneck"), (512, 0, 512, 8, 4800, 192, "path p2r ds2"), (256, 0, 256, 8, 19200, 192, "path p2r up0"),
           (64, 64, 384, 8, 12288, 0, "path heads' first layer")]
 ts = [int(t) for t in a.ts.split(",")]
+name = lambda v: "auto" if v == 0 else "auto(r05 plans)" if v == -1 else "lds " if v == 7 else ("lin%d" % ((v >> 8) & 15) if ((v >> 12) & 15) == 15 else "T=%d" % (v >> 8))
 torch.manual_seed(0)
 tot = {}
 for K1, K2, C, B, P, py, role in SHAPES:
@@ -29,11 +30,16 @@ for K1, K2, C, B, P, py, role in SHAPES:
     gather = (torch.randn(B, py, C, device=dev), torch.randint(0, py, (B, P), device=dev)) if py else None
     out = torch.empty(B, P, C, device=dev)
     n_ct = (C + 127) // 128
-    variants = [7] + [8 + 256 * t for t in ts if t <= n_ct]
+    variants = [7] + [8 + 256 * t for t in ts if t <= n_ct] + ([8 + 256 * (0xF0 | r) for r in (1, 2, 3, 4)] if n_ct <= 8 else []) + [0, -1]
     ref = ops_pm.mlp(x1, w, b, 1, x2=x2, gather=gather, tile_hint=7).clone()
     times = {v: [] for v in variants}
+    lib = ops_pm._lib.load()
+
+    def run(v):
+        lib.ffb6d_mlp_pm_set_seq_lin(0 if v == -1 else 1)
+        return ops_pm.mlp(x1, w, b, 1, x2=x2, gather=gather, out=out, tile_hint=max(v, 0))
     for v in variants:
-        got = ops_pm.mlp(x1, w, b, 1, x2=x2, gather=gather, out=out, tile_hint=v)
+        got = run(v)
         assert torch.equal(got, ref), (role, v)
     torch.cuda.synchronize()
     for _ in range(a.rounds):
@@ -41,7 +47,7 @@ for K1, K2, C, B, P, py, role in SHAPES:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.reps):
-                ops_pm.mlp(x1, w, b, 1, x2=x2, gather=gather, out=out, tile_hint=v)
+                run(v)
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) * 1e3 / a.reps)
@@ -51,6 +57,6 @@ for K1, K2, C, B, P, py, role in SHAPES:
         us = float(np.median(times[v]))
         tot.setdefault(v, 0.0)
         tot[v] += us
-        line += " %s %7.1f us %.3f |" % ("lds " if v == 7 else "T=%d" % (v >> 8), us, fl / us / 1e6 / PEAK)
+        line += " %s %7.1f us %.3f |" % (name(v), us, fl / us / 1e6 / PEAK)
     print(line, flush=True)
-print("sum over the shapes a variant ran on:", {("lds" if v == 7 else "T=%d" % (v >> 8)): round(t, 1) for v, t in tot.items()})
+print("sum over the shapes a variant ran on:", {name(v): round(t, 1) for v, t in tot.items()})

@@ -51,9 +51,14 @@ CASES += [(1, 4800, 1024, 0, 1024, 1, 48, 7), (2, 777, 32, 32, 72, 2, 50, 7), (1
 # of regions B / C): gathered and added epilogue rows, two sources, ragged channels and rows, a three-region plan; the last one is
 # picked by tile_hint 0
 SEQ = lambda ta, tb=1, b16=0, c16=0: 8 + 256 * (ta | tb << 4 | b16 << 8 | c16 << 16)      # noqa: E731
+# round 6: balanced contiguous sequences per XCD (they may run from one point tile into the next): rounds per workgroup slot, or an explicit
+# number of sequences per XCD
+LIN = lambda rounds, per_xcd=0: 8 + 256 * (0xF0 | rounds | per_xcd << 8)                  # noqa: E731
 CASES += [(1, 4800, 1024, 0, 1024, 1, 48, SEQ(2)), (2, 777, 160, 0, 392, 2, 50, SEQ(3)), (1, 4100, 256, 0, 200, 1, -1, SEQ(2)),
           (8, 192, 512, 256, 520, 2, 0, SEQ(4)), (2, 2100, 128, 0, 640, 0, 0, SEQ(4, 2, 2, 2)), (1, 9000, 128, 128, 1024, 1, 300, SEQ(8, 2, 4, 8)),
           (1, 140000, 128, 0, 256, 1, 0, 0)]
+CASES += [(1, 4800, 1024, 0, 1024, 1, 48, LIN(2, 7)), (2, 3000, 160, 0, 392, 2, 50, LIN(2, 3)), (1, 9000, 256, 0, 200, 1, -1, LIN(2, 5)),
+          (8, 1920, 512, 256, 520, 2, 0, LIN(1, 9)), (2, 38400 // 2, 512, 0, 512, 1, 192, LIN(2)), (1, 98304, 64, 64, 384, 1, 0, 0)]
 
 
 @pytest.mark.parametrize("B,P,K1,K2,Cout,act,py,hint", CASES)
@@ -80,7 +85,7 @@ def test_tile_sequence_and_big_tile_forms_equal_the_lds_tiled_form_bit_for_bit(d
     rows and channels, a three-region plan"""
     g = torch.Generator().manual_seed(5)
     d = lambda t: None if t is None else t.to(device)                                 # noqa: E731
-    for dt, hints in ((torch.float32, (SEQ(2), SEQ(3), SEQ(4, 2, 2, 2))), (BF, (9,))):
+    for dt, hints in ((torch.float32, (SEQ(2), SEQ(3), SEQ(4, 2, 2, 2), LIN(2, 1), LIN(2, 2), LIN(1))), (BF, (9,))):
         for B, P, K1, K2, C, py in ((2, 1500, 192, 0, 392, 40), (1, 2100, 128, 128, 640, -1), (3, 700, 256, 0, 520, 0)):
             x1 = torch.randn(B, P, K1, generator=g).to(dt)
             x2 = torch.randn(B, P, K2, generator=g).to(dt) if K2 else None

@@ -146,6 +146,16 @@ def test_kernel_forms_are_bit_identical_on_the_emulator(emu):
             for t in (2, 3, 4):
                 got = ops_pm.mlp(x, w, b, act, tile_hint=8 + 256 * t, **kw)
                 assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (list(kw), act, t)
+    # round 6: balanced contiguous sequences per XCD (plan 0xF0 | rounds | sequences-per-XCD << 8): 10 point tiles -> XCDs 0 and 1 hold two
+    # point tiles = 8 tiles each, cut into 3 sequences of 3 + 3 + 2 (they run from one point tile into the next) or 5 of 2 + 2 + 2 + 1 + 1
+    x = torch.randn(2, 620, 160, generator=g)
+    Y, idx = torch.randn(2, 40, 392, generator=g), torch.randint(0, 40, (2, 620), generator=g)
+    for kw in ({"gather": (Y, idx)}, {}):
+        for b, act in ((bias, 2), (None, 0)):
+            want = ops_pm.mlp(x, w, b, act, tile_hint=7, **kw)
+            for per_xcd in (3, 5, 0):
+                got = ops_pm.mlp(x, w, b, act, tile_hint=8 + 256 * (0xF0 | 2 | per_xcd << 8), **kw)
+                assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (list(kw), act, per_xcd)
 
 
 @pytest.mark.parametrize("hint", [1, 2, 5, 6, 7])
