@@ -97,6 +97,11 @@ def parse():
     ap.add_argument("--mark-region", action="store_true",
                     help="launch a marker kernel (check_range_kernel) right before and after the timed steps "
                          "so scripts/rocpd_stats.py --between can cut the warm-up out of a rocprofv3 trace")
+    ap.add_argument("--path", choices=["fused", "dropin"], default="fused",
+                    help="dropin (inference, one GPU): the operator-level drop-in -- the reference's dataflow in the reference's channel-major "
+                         "layout through stock conv / BatchNorm modules (ffb6d_amd/dropin.py, pinned to the reference's end_points on CPU) "
+                         "with patch.patch_classes applied, i.e. what patch_reference makes an unmodified reference model execute; "
+                         "fused (default): the package's own point-major inference path")
     ap.add_argument("--e2e-objects", type=int, default=5, help="--mode e2e: objects per frame of the synthetic vote field")
     ap.add_argument("--form", action="append", default=[], metavar="NAME=0|1",
                     help="A/B runs: set a boolean form attribute of ffb6d_amd.forward_pm (HEADS_SHARE_FIRST=0 ...) before the model is "
@@ -293,6 +298,68 @@ def run_e2e(args, dev, net, frames):
     print(json.dumps(line), flush=True)
 
 
+def run_dropin(args, dev, net, cld, dpt_xyz, fixed, idt):
+    """--path dropin: pyramid + the reference-shaped forward with the channel-major HIP operators patched in; one JSON line with the
+    per-operator table (algorithmic bytes by the SURVEY 8d rule / HIP-event time) and the same forward with plain-torch operators."""
+    from ffb6d_amd import _lib, dropin, patch, pyramid
+    stand = dropin.FFB6D(net)
+    ev = lambda: torch.cuda.Event(enable_timing=True)                                     # noqa: E731
+
+    def step():
+        inputs = pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
+        inputs.update(fixed)
+        with torch.no_grad():
+            return stand(inputs)
+
+    def timed(n):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(n):
+            step()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    plain_ms = timed(max(2, args.steps // 2))                 # unpatched: index expansion + torch.gather + permutes, softmax / mul / sum
+    undo = patch.patch_classes(dropin.FFB6D, dropin.Building_block, dropin.Att_pooling)
+    try:
+        ms = timed(args.steps)
+        tr = _lib.Tracer(None)
+        _lib.TRACER = tr
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        _lib.TRACER = None
+    finally:
+        undo()
+    table = {}
+    for name, r in tr.summary().items():
+        table[name] = {"launches_per_step": r["launches"] / 3, "ms_per_step": r["total_ms"] / 3, "algorithmic_GBps": r["gbps"],
+                       "frac_of_hbm_peak": r["gbps"] / HBM_PEAK_GBS}
+    by_shape = {f"{name}{tag}": {"launches_per_step": r["launches"] / 3, "avg_us": r["avg_us"], "algorithmic_GBps": r["gbps"],
+                                 "frac_of_hbm_peak": r["gbps"] / HBM_PEAK_GBS}
+                for (name, tag), r in sorted(tr.summary(by_tag=True).items(), key=lambda kv: -kv[1]["total_ms"])
+                if name in ("random_sample", "nearest_interpolation", "gather_neighbour", "relative_pos_encoding", "att_pool")}
+    gathers = [k for k in ("random_sample", "nearest_interpolation", "gather_neighbour", "relative_pos_encoding", "att_pool") if k in table]
+    dom = max(gathers, key=lambda k: table[k]["ms_per_step"])
+    line = {"metric": METRIC, "value": args.batch / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"operator-level drop-in: on-device 22-call KNN index pyramid + the reference's forward dataflow in the "
+                                   f"reference's channel-major layout (stock conv / BatchNorm / activation modules, NCHW) with the five "
+                                   f"neighbour operators of ffb6d_amd.ops patched in (patch.patch_classes on ffb6d_amd/dropin.py); "
+                                   f"bs={args.batch}, N={args.n_points}, 480x640, fp32, one stream",
+                       "path": "dropin"},
+            "same_forward_with_plain_torch_operators": {"ms_per_step": plain_ms, "frames_per_s": args.batch / (plain_ms * 1e-3)},
+            "roofline": {"bound": "hbm", "achieved": table[dom]["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": table[dom]["frac_of_hbm_peak"], "traffic": None, "kernel": dom,
+                         "note": "the drop-in operator with the largest share of the step; every operator: hot_path_ops / hot_path_ops_by_shape"},
+            "hot_path_ops": table, "hot_path_ops_by_shape": by_shape}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -303,7 +370,7 @@ def main():
     if args.miopen_db == "pinned":
         from ffb6d_amd import miopen_pin
         # before the first convolution: a private copy per process; the fp32 forward-only run also pins the solver
-        miopen_db = miopen_pin.use(rank=local_rank, only_solver=miopen_pin.FWD_SOLVER if (args.mode == "infer" and args.precision == "fp32") else None)
+        miopen_db = miopen_pin.use(rank=local_rank, only_solver=miopen_pin.FWD_SOLVER if (args.mode == "infer" and args.precision == "fp32" and args.path == "fused") else None)
     if world_env > 1:
         # one MIOpen find-db / kernel cache per rank: N ranks tuning the same convolutions at the same
         # time would otherwise contend for the lock of one sqlite user database
@@ -374,6 +441,12 @@ def main():
         targets = tuple(torch.from_numpy(np.stack([t[k] for t in tg])).to(dev) for k in ("labels", "kp_targ_ofst", "ctr_targ_ofst"))
         targets = (targets[0].long(),) + targets[1:]
 
+    if args.path == "dropin":
+        if world > 1 or train:
+            raise SystemExit("--path dropin is a one-GPU inference record")
+        run_dropin(args, dev, net, cld, dpt_xyz, {"rgb": rgb, "cld_rgb_nrm": cld_rgb_nrm, "choose": choose}, idt)
+        group.close()
+        return
     if args.mode == "e2e":
         if world > 1:
             raise SystemExit("--mode e2e is a one-GPU pipeline record")

@@ -9,9 +9,12 @@ search on an MI355X, taken with `scripts/miopen_draw_probe.sh` -- "find once, pi
 copy of it (MIOpen appends problems it has not seen), unless the caller has chosen a database directory already.
 
 Only a benchmark / deployment convenience: results do not depend on it beyond MIOpen's own algorithm-to-algorithm rounding."""
+import atexit
 import os
+import re
 import shutil
 import tempfile
+import warnings
 
 PIN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_pin")
 TAG = "r05 search on MI355X (gfx950, 256 CUs), MIOpen 3.5.0: fp32 NHWC forward problems of the bs = 8, 480 x 640 colour branch"
@@ -31,10 +34,39 @@ def use(rank=0, only_solver=None):
         return "MIOPEN_USER_DB_PATH set by the caller: " + os.environ["MIOPEN_USER_DB_PATH"]
     dst = os.path.join(tempfile.gettempdir(), f"ffb6d_miopen_pin_{os.getpid()}_{rank}")
     os.makedirs(dst, exist_ok=True)
+    atexit.register(shutil.rmtree, dst, ignore_errors=True)          # the private copy goes with the process
     n = 0
     for f in os.listdir(PIN_DIR):
         if f.endswith(".txt"):
             shutil.copy(os.path.join(PIN_DIR, f), os.path.join(dst, f))
             n += 1
     os.environ["MIOPEN_USER_DB_PATH"] = dst
-    return f"pinned user find-db / perf-db ({n} files of ffb6d_amd/miopen_pin: {TAG})" + (f", solver {only_solver} only" if only_solver else "")
+    note = version_note()
+    if note:
+        warnings.warn(note)
+    return f"pinned user find-db / perf-db ({n} files of ffb6d_amd/miopen_pin: {TAG})" + (f", solver {only_solver} only" if only_solver else "") + \
+        (f"; {note}" if note else "")
+
+
+def pinned_version():
+    """(major, minor, patch) of the MIOpen build the pinned files were written by (it is part of their names), or None"""
+    for f in os.listdir(PIN_DIR):
+        m = re.search(r"\.HIP\.(\d+)_(\d+)_(\d+)_", f)
+        if m:
+            return tuple(int(g) for g in m.groups())
+    return None
+
+
+def version_note():
+    """MIOpen reads user databases only under its own version's file name: with another MIOpen build the pin is silently ignored and every
+    process searches again (the step then moves by +-0.4 ms with the draw, like `--miopen-db fresh`).  Returns a note in that case."""
+    try:
+        import torch
+        v = int(torch.backends.cudnn.version() or 0)
+    except Exception:      # pragma: no cover
+        return ""
+    have, want = (v // 1000000, v // 1000 % 1000, v % 1000), pinned_version()
+    if want and v and have != want:
+        return (f"installed MIOpen {have[0]}.{have[1]}.{have[2]} differs from the pinned database's {want[0]}.{want[1]}.{want[2]}: "
+                "the pin is not read, MIOpen searches afresh")
+    return ""

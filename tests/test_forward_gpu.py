@@ -396,7 +396,7 @@ def test_training_step_gradients_match_plain_torch(device, n_pts, height, width,
     gradients plain torch autograd produces for the same forward (oracle/forward_ref.py) -- for EVERY parameter."""
     loss, ours, ref_loss, ref, _ = _step_gradients(device, n_pts, height, width, batch, False)
     assert abs(loss - ref_loss) <= 1e-3 * abs(ref_loss)
-    worst, checked = ("", 0.0), 0
+    worst, checked, loose = ("", 0.0), 0, 0
     for n, r in ref.items():
         g = ours[n]
         if r is None:                                  # a parameter the forward does not reach (none today)
@@ -414,8 +414,10 @@ def test_training_step_gradients_match_plain_torch(device, n_pts, height, width,
         # measured 5e-6 .. 3e-4 on most parameters, up to 7e-3 on a handful run to run: MIOpen's backward-data/weight algorithms and the
         # float atomics of the scatter-add kernels are not bit-reproducible (the largest element of a gradient is the yardstick)
         assert err <= 1e-2, (n, err)
-    print("parameters checked:", checked, "worst:", worst)
+        loose += err > 5e-3
+    print("parameters checked:", checked, "worst:", worst, "above 5e-3:", loose)
     assert checked >= 300
+    assert loose <= max(3, checked // 50), loose          # the round-4 bar (5e-3) still holds for all but a handful of parameters per run
 
 
 def test_training_step_gradients_under_bf16_autocast(device):
