@@ -88,5 +88,26 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
 }
 
+// wait until at most N of this wave's vector-memory operations are outstanding (they complete in order: the N youngest may remain)
+template <int N>
+__device__ __forceinline__ void lds_dma_wait()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);      // vmcnt(N), expcnt / lgkmcnt left alone (gfx9 encoding)
+#endif
+}
+
+// make the compiler treat `v` as used HERE: the wait for the load that produces it is placed at this point of the instruction stream
+// (and not after vector-memory operations issued later, whose completion that wait would then include)
+__device__ __forceinline__ void use_here(unsigned v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#else
+    (void)v;
+#endif
+}
+
 }  // namespace pm
 }  // namespace ffb6d

@@ -204,7 +204,7 @@ __device__ __forceinline__ void pm_epilogue(const PmParams& p, f32x16 (&acc)[TM]
 }
 
 // csrc/mlp_pm_big.hip: the 256 x 256 bf16 tile with LDS-DMA operand loads; false = hipFuncSetAttribute failed
-bool launch_pm_big_bf16(PmParams& p, hipStream_t st, int var = 0);      // var: probe variants (csrc/mlp_pm_big.hip)
+bool launch_pm_big_bf16(PmParams& p, hipStream_t st, int plan = 0);     // plan: tiles per workgroup | probe variant << 4 (csrc/mlp_pm_big.hip)
 // ... can it run this launch?  (bf16 rows of whole 128-byte segments from each source, 16-byte aligned output / Y rows, no log-softmax)
 bool big_form_ok(const PmParams& p);
 

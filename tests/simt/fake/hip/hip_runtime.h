@@ -293,6 +293,8 @@ typedef simt::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_sched_barrier(x) simt::wave_sync()
 // scheduling hints and hardware-id reads: no functional effect on the emulator (workgroups run one after the other)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)             /* memory operations complete at once on the emulator */
+#define __builtin_amdgcn_s_barrier() simt::block_sync()
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) simt::permlane32_swap(a, b)
 #define __builtin_amdgcn_s_getreg(reg_) ((((reg_) & 63) == 20) ? (unsigned)(blockIdx.x & 7u) : 0u)      /* HW_REG_XCC_ID: workgroup b on XCD b % 8 */

@@ -85,7 +85,7 @@ def test_tile_sequence_and_big_tile_forms_equal_the_lds_tiled_form_bit_for_bit(d
     rows and channels, a three-region plan"""
     g = torch.Generator().manual_seed(5)
     d = lambda t: None if t is None else t.to(device)                                 # noqa: E731
-    for dt, hints in ((torch.float32, (SEQ(2), SEQ(3), SEQ(4, 2, 2, 2), LIN(2, 1), LIN(2, 2), LIN(1))), (BF, (9,))):
+    for dt, hints in ((torch.float32, (SEQ(2), SEQ(3), SEQ(4, 2, 2, 2), LIN(2, 1), LIN(2, 2), LIN(1))), (BF, (9, 9 + 256, 9 + 256 * 2, 9 + 256 * 3))):
         for B, P, K1, K2, C, py in ((2, 1500, 192, 0, 392, 40), (1, 2100, 128, 128, 640, -1), (3, 700, 256, 0, 520, 0)):
             x1 = torch.randn(B, P, K1, generator=g).to(dt)
             x2 = torch.randn(B, P, K2, generator=g).to(dt) if K2 else None
@@ -485,10 +485,11 @@ def _close_bf16(got, want, what=""):
     [(1, 100000, 64, 0, 64, 1, 0, 6), (2, 5001, 48, 0, 16, 0, 0, 6), (1, 4100, 256, 0, 128, 1, -1, 6), (3, 1300, 64, 96, 104, 2, 70, 6),
      (1, 70000, 64, 64, 128, 1, 300, 0), (2, 20000, 256, 0, 64, 2, 0, 0)] +
     # the 256 x 256 tile with LDS-DMA operand loads (hint 9, csrc/mlp_pm_big.hip; round 6): gathered / added epilogue rows, two sources,
-    # ragged rows and channels, channels not a multiple of 16 (the shared epilogue), one step short of the minimum; the last two are
-    # picked by tile_hint 0 (>= 512 tiles of 256 x 256)
-    [(1, 4800, 1024, 0, 1024, 1, 48, 9), (2, 777, 64, 64, 72, 2, 50, 9), (1, 4100, 512, 0, 200, 1, -1, 9), (8, 192, 512, 256, 256, 2, 0, 9),
-     (3, 301, 128, 0, 264, 1, 13, 9), (1, 520, 192, 64, 40, 0, 0, 9), (2, 38400, 512, 0, 512, 1, 192, 0), (1, 140000, 256, 0, 250, 2, -1, 0)])
+    # ragged rows and channels (whole 16-channel groups: other widths go to form 7), sequences of 3 / 4 channel tiles per workgroup with a
+    # ragged last group; the last two are picked by tile_hint 0 (>= 512 tiles of 256 x 256)
+    [(1, 4800, 1024, 0, 1024, 1, 48, 9), (2, 777, 64, 64, 80, 2, 50, 9), (1, 4100, 512, 0, 208, 1, -1, 9), (8, 192, 512, 256, 256, 2, 0, 9),
+     (3, 301, 128, 0, 784, 1, 13, 9 + 256 * 3), (1, 520, 192, 64, 48, 0, 0, 9), (1, 9000, 256, 0, 1040, 2, -1, 9 + 256 * 4),
+     (2, 38400, 512, 0, 512, 1, 192, 0), (1, 140000, 256, 0, 256, 2, -1, 0)])
 def test_mlp_pm_bf16(device, B, P, K1, K2, Cout, act, py, hint):
     g = torch.Generator().manual_seed(K1 + Cout + P)
     r = lambda *s: torch.randn(*s, generator=g).to(BF)                               # noqa: E731

@@ -191,8 +191,8 @@ def test_lds_tiled_bf16_prefetch_past_the_last_step(emu, K1, K2, cout, rows):
     assert torch.equal(got, ops_pm.mlp(x1, w, bias, 1, x2=x2, tile_hint=1))
 
 
-@pytest.mark.parametrize("K1,K2,cout,rows,extra", [(256, 0, 264, 300, "gather"), (128, 64, 130, 520, "add"), (64, 64, 256, 257, None),
-                                                   (192, 0, 72, 64, "gather"), (128, 128, 40, 700, "xgather")])
+@pytest.mark.parametrize("K1,K2,cout,rows,extra", [(256, 0, 784, 300, "gather"), (128, 64, 144, 520, "add"), (64, 64, 528, 257, None),
+                                                   (192, 0, 80, 64, "gather"), (128, 128, 48, 700, "xgather")])
 def test_big_tile_bf16_form_on_the_emulator(emu, K1, K2, cout, rows, extra):
     """mlp_pm_big_kernel (csrc/mlp_pm_big.hip, tile_hint 9): 256 x 256 tile, LDS-DMA operand loads into chunk-permuted images; ragged
     rows and channels (zero rows past the end), one or two sources, gathered / added epilogue rows, gathered operand rows; against
@@ -216,9 +216,9 @@ def test_big_tile_bf16_form_on_the_emulator(emu, K1, K2, cout, rows, extra):
         kw["add"] = torch.randn(B, P, cout, generator=g).to(BF)
     got = ops_pm.mlp(x1, w, bias, 2, x2=x2, tile_hint=9, **kw)
     assert torch.equal(got.view(torch.int16), ops_pm.mlp(x1, w, bias, 2, x2=x2, tile_hint=7, **kw).view(torch.int16))
-    if rows == 64:                                  # the probe variants of the schedule / the store shape (csrc/mlp_pm_big.hip: VAR)
-        for var in (1, 4, 8):
-            assert torch.equal(got.view(torch.int16), ops_pm.mlp(x1, w, bias, 2, x2=x2, tile_hint=9 + 256 * var, **kw).view(torch.int16)), var
+    for tpg in ((1, 2, 3, 4) if rows <= 300 else (2,)):   # tiles per workgroup (csrc/mlp_pm_big.hip: a sequence of channel tiles of one point tile)
+        assert torch.equal(got.view(torch.int16), ops_pm.mlp(x1, w, bias, 2, x2=x2, tile_hint=9 + 256 * tpg, **kw).view(torch.int16)), tpg
+    if rows == 64:
         assert torch.equal(got.view(torch.int16), ops_pm.mlp(x1, w, None, 0, x2=x2, tile_hint=9, **kw).view(torch.int16)) is False
         nob = ops_pm.mlp(x1, w, None, 0, x2=x2, tile_hint=9)         # no bias, no Y, identity: negative zeros survive the additions of "nothing"
         assert torch.equal(nob.view(torch.int16), ops_pm.mlp(x1, w, None, 0, x2=x2, tile_hint=7).view(torch.int16))
