@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--local-bn", action="store_true",
                     help="train mode, >1 rank: per-rank BatchNorm statistics, gradients are the only collective (north_star's "
                          "wording); default = torch.nn.SyncBatchNorm like the reference's apex SyncBN (train_lm.py:592)")
+    ap.add_argument("--bn-variants", type=int, default=1,
+                    help="train mode, >1 rank, SyncBatchNorm run: 1 (default) = also time the same steps with per-rank BatchNorm statistics "
+                         "and report both in the line (train_extra.bn_variants); 0 = skip the second variant")
     ap.add_argument("--channels-last", type=int, default=1, help="train mode: keep the colour branch in channels_last (NHWC) memory format")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, one GPU per rank) for real runs; gloo lets several ranks share one GPU "
@@ -580,6 +583,38 @@ def main():
 
         elapsed = distributed.timed_steps(one_step, 0, args.steps, group, sync=torch.cuda.synchronize)
         _lib.TRACER = None
+        # >1 rank, training: what does the step cost in collectives, and what does SyncBatchNorm cost?  One counted step, then the
+        # same steps on a second copy of the model with per-rank BatchNorm statistics (gradients the only collective) -- both variants
+        # in one invocation, so that one run on the 8-GPU node prices SyncBatchNorm.
+        train_extra = None
+        if train and world > 1:
+            with distributed.count_collectives() as cc:
+                step()
+                torch.cuda.synchronize()
+            train_extra = {"python_side_collectives_per_step": cc.counts, "ddp_gradient_buckets": distributed.ddp_bucket_count(ddp),
+                           "sync_batchnorm_layers": sum(isinstance(m, torch.nn.SyncBatchNorm) for m in ddp.modules())}
+            if train_extra["sync_batchnorm_layers"] and args.bn_variants:
+                net2 = model.FFB6D(n_classes=args.n_classes, n_pts=args.n_points)
+                net2.load_state_dict(sd)
+                net2 = net2.to(dev).train()
+                if args.channels_last:
+                    net2 = net2.to(memory_format=torch.channels_last)
+                ddp2 = distributed.wrap_ddp(net2, dev, sync_bn=False)
+                opt2 = torch.optim.Adam(net2.parameters(), lr=1e-5)
+
+                def step2(_timed=False):
+                    inputs = pyramid.build_index_pyramid(cld, dpt_xyz, index_dtype=idt)
+                    inputs.update(rgb=rgb, cld_rgb_nrm=cld_rgb_nrm, choose=choose)
+                    opt2.zero_grad(set_to_none=True)
+                    with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.precision == "bf16"):
+                        out = ddp2(inputs)
+                        loss = ffb6d_loss.training_loss(out, *targets)[0] if targets is not None else sum((v.float() ** 2).mean() for v in out.values())
+                    loss.backward()
+                    opt2.step()
+                el2 = distributed.timed_steps(step2, args.warmup, args.steps, group, sync=torch.cuda.synchronize)
+                train_extra["bn_variants"] = {
+                    "sync_batchnorm": {"ms_per_step": 1e3 * elapsed / args.steps, "frames_per_s": args.batch * world * args.steps / elapsed},
+                    "local_batchnorm": {"ms_per_step": 1e3 * el2 / args.steps, "frames_per_s": args.batch * world * args.steps / el2}}
         if args.mark_region:
             ops.check_index_range(marker, 1)
 
@@ -774,6 +809,8 @@ def main():
             "hot_path_ops_source": f"{N_FULL} untimed steps between warm-up and the timed region with every hand-written launch "
                                    "bracketed by HIP events; the timed region brackets only the roofline kernel's launches",
         }
+        if train_extra is not None:
+            line["train_extra"] = train_extra
         if not args.no_cpu_baseline and world == 1 and not train:
             line["cpu_baseline"] = cpu_baseline(args, sd)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]

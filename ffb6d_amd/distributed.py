@@ -111,3 +111,43 @@ def wrap_ddp(model, device, sync_bn=None):
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     return DistributedDataParallel(model, device_ids=[device.index] if device.type == "cuda" else None,
                                    find_unused_parameters=True, gradient_as_bucket_view=True)
+
+
+class count_collectives:
+    """Context manager: how many collectives does the PYTHON side of a step issue?  (torch.nn.SyncBatchNorm calls torch.distributed from
+    Python: one all_gather of the statistics per BatchNorm layer in forward, one all_reduce per layer in backward; DistributedDataParallel's
+    bucketed gradient all-reduces are issued by its C++ reducer and are reported separately, from its logging data.)
+    `.counts` = {function name: calls}."""
+    NAMES = ("all_reduce", "all_gather", "all_gather_into_tensor", "reduce_scatter_tensor", "broadcast", "all_to_all_single", "barrier")
+
+    def __enter__(self):
+        import torch.distributed as dist
+        self.counts, self._saved = {}, {}
+        for name in self.NAMES:
+            fn = getattr(dist, name, None)
+            if fn is None:
+                continue
+            self._saved[name] = fn
+
+            def wrapped(*a, _fn=fn, _name=name, **kw):
+                self.counts[_name] = self.counts.get(_name, 0) + 1
+                return _fn(*a, **kw)
+            setattr(dist, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        import torch.distributed as dist
+        for name, fn in self._saved.items():
+            setattr(dist, name, fn)
+        return False
+
+
+def ddp_bucket_count(ddp):
+    """gradient buckets (= all-reduces per backward) of a DistributedDataParallel wrapper, or None"""
+    try:
+        data = ddp._get_ddp_logging_data()
+        sizes = str(data.get("bucket_sizes", ""))
+        return len([x for x in sizes.split(",") if x.strip()]) or None
+    except Exception:
+        return None
+

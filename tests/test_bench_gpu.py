@@ -52,6 +52,10 @@ def test_bench_train_mode_wraps_ddp_on_two_ranks():
                   "--batch", "1", "--cudnn-benchmark", "0", timeout=600)
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2
     assert "train" in line["metric"] and line["value"] > 0
+    # the per-step collective census every >1-rank training line carries (over gloo BatchNorm statistics stay per rank: no Python-side
+    # collective, no second variant to time; on RCCL the same fields price SyncBatchNorm, tests/test_multigpu_gpu.py)
+    extra = line["train_extra"]
+    assert extra["sync_batchnorm_layers"] == 0 and extra["python_side_collectives_per_step"] == {} and "bn_variants" not in extra
 
 
 def test_training_step_record_in_bf16(capsys):

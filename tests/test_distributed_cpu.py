@@ -69,9 +69,18 @@ WORKER = textwrap.dedent("""
     local = torch.nn.Linear(3, 2)
     local.load_state_dict({k: v.clone() for k, v in lin.state_dict().items()})
     local(x).pow(2).mean().backward()
+    # the collective counter the training bench and the RCCL tests use (bench.py train_extra, tests/test_multigpu_gpu.py)
+    import torch.distributed as dist
+    with D.count_collectives() as cc:
+        t = torch.ones(3)
+        dist.all_reduce(t)
+        dist.all_reduce(t)
+        dist.broadcast(t, src=0)
+    restored = dist.all_reduce.__module__.startswith("torch.distributed")
     out = dict(rank=g.rank, world=g.world, elapsed=elapsed, calls=calls,
                first_seed_check=float(frames["cld"][0].sum()), total=total, grad=grad,
-               local_grad=local.weight.grad.flatten().tolist())
+               local_grad=local.weight.grad.flatten().tolist(), counted=cc.counts, restored=restored,
+               buckets=D.ddp_bucket_count(ddp))
     print("RESULT " + json.dumps(out), flush=True)
     g.close()
 """) % ROOT
@@ -100,6 +109,8 @@ def test_two_rank_gloo_harness(tmp_path):
     mean = (np.array(res[0]["local_grad"]) + np.array(res[1]["local_grad"])) / 2
     np.testing.assert_allclose(res[0]["grad"], mean, rtol=1e-5, atol=1e-6)
     assert not np.allclose(res[0]["local_grad"], res[1]["local_grad"])   # ranks really saw different frames
+    assert all(r["counted"] == {"all_reduce": 2, "broadcast": 1} and r["restored"] for r in res)
+    assert all(r["buckets"] in (None, 1) for r in res)      # one small bucket (or no logging data in this torch build)
 
 
 def test_single_process_group_is_a_noop():

@@ -48,6 +48,13 @@ def test_bench_two_gpus_over_rccl_training_with_sync_batchnorm_in_bf16():
                   "--cudnn-benchmark", "0", timeout=1200)
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16
     assert "train" in line["metric"] and "SyncBatchNorm" in line["config"]["workload"] and line["value"] > 0
+    # one invocation prices SyncBatchNorm: collectives of a step counted, the same steps timed with per-rank statistics as well
+    extra = line["train_extra"]
+    print("train_extra:", json.dumps(extra))
+    n_bn = extra["sync_batchnorm_layers"]
+    calls = sum(extra["python_side_collectives_per_step"].values())
+    assert n_bn > 50 and calls >= 2 * n_bn                       # one gather of the statistics forward, one reduction backward, per layer
+    assert set(extra["bn_variants"]) == {"sync_batchnorm", "local_batchnorm"} and extra["bn_variants"]["local_batchnorm"]["frames_per_s"] > 0
 
 
 WORKER = textwrap.dedent("""
@@ -118,8 +125,11 @@ WORKER = textwrap.dedent("""
     sync_bn = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in wrapped.modules())
     stats = first_bn_stats(wrapped, inputs)
     bn_eval(wrapped)
-    got = grads_of(wrapped, inputs, targets, 1.0)
-    out = dict(rank=rank, world=world, backend=(dist.get_backend() if world > 1 else "none"), sync_bn=sync_bn, got=got, stats=stats)
+    with D.count_collectives() as cc:                          # Python-side collectives of one training step (SyncBatchNorm's)
+        got = grads_of(wrapped, inputs, targets, 1.0)
+    out = dict(rank=rank, world=world, backend=(dist.get_backend() if world > 1 else "none"), sync_bn=sync_bn, got=got, stats=stats,
+               rccl_ranks=(dist.get_world_size() if world > 1 else 1), collectives=cc.counts,
+               ddp_buckets=(D.ddp_bucket_count(wrapped) if world > 1 else None))
     if rank == 0:                                              # ONE process on all world * PER frames, plain BatchNorm
         ref = build()
         inputs_all, targets_all = batch(0, world * PER)
@@ -179,7 +189,7 @@ def _check(res):
 def test_gradient_worker_one_rank_rehearsal(tmp_path):
     """the worker of the two-rank check with one rank: no collective, plain BatchNorm -- its own reference on the same two frames"""
     res = _run_worker(tmp_path, 1)
-    assert res[0]["world"] == 1 and res[0]["sync_bn"] == 0
+    assert res[0]["world"] == 1 and res[0]["sync_bn"] == 0 and res[0]["collectives"] == {} and res[0]["rccl_ranks"] == 1
     _check(res)
 
 
@@ -188,6 +198,11 @@ def test_two_rccl_ranks_leave_the_gradients_of_the_doubled_batch(tmp_path):
     res = _run_worker(tmp_path, 2)
     assert [r["world"] for r in res] == [2, 2] and all(r["backend"] == "nccl" for r in res)
     assert all(r["sync_bn"] > 50 for r in res)                 # BatchNorm layers were converted (train_lm.py:592)
+    # first contact with a multi-GPU node: what ran (read with pytest -s / in the failure report)
+    print("RCCL ranks:", [r["rccl_ranks"] for r in res], "SyncBatchNorm layers:", res[0]["sync_bn"],
+          "python-side collectives of one step (BatchNorm in eval for the gradient check: none expected here):", res[0]["collectives"],
+          "DDP gradient buckets:", res[0]["ddp_buckets"])
+    assert all(r["rccl_ranks"] == 2 for r in res)
     _check(res)
     for name in res[0]["got"]:                                 # one gradient on both ranks, to the last bits the all-reduce leaves
         np.testing.assert_allclose(res[0]["got"][name], res[1]["got"][name], rtol=1e-6, atol=0, err_msg=name)
