@@ -4,7 +4,7 @@ against the 256 x 256 LDS-DMA form (hint 9, csrc/mlp_pm_big.hip), interleaved in
 output is compared bit for bit with hint 7's first.
     python scripts/big_gemm_probe.py [--rounds 5] [--reps 8] [--hints 7,9]"""
 import argparse, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ffb6d_amd import ops_pm
 

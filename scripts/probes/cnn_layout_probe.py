@@ -2,7 +2,7 @@
 """Planning probe: the colour branch's MIOpen convolutions end to end (stem, 4 encoder stages, 4 decoder stages, no
 fusion), NCHW vs channels_last, plain torch modules, bs=8 480x640."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from ffb6d_amd import model

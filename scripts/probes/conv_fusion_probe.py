@@ -2,7 +2,7 @@
 """Planning probe: MIOpen's fused conv+bias+ReLU (torch.miopen_convolution_relu / _add_relu) against conv followed by the
 affine_act_pm pass, on the colour branch's 3x3 shapes, channels_last, fp32 and bf16 (bs=8)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from ffb6d_amd import ops, ops_pm

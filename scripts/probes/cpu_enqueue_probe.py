@@ -1,7 +1,7 @@
 """How long does the host take to enqueue one forward (pyramid streamed inside)?  If that is close to the GPU step time the
 step is launch-bound and a captured HIP graph is the fix.  Usage: python scripts/cpu_enqueue_probe.py [bf16]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from ffb6d_amd import model, synth

@@ -3,7 +3,7 @@
 input assembly and the pose solver (whose polling blocks the host), GPU stamps (HIP events) of the forward's begin / end on the main stream
 and of the pose solver's on its side stream.    python scripts/e2e_probe.py [--iters 6]"""
 import argparse, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from ffb6d_amd import model, pipeline, synth

@@ -1,7 +1,7 @@
 """Probe: host enqueue time vs GPU time of one step, and hipGraph replay of pyramid+forward."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ffb6d_amd import model as M, pyramid, synth
 
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@
 choose between -- pure writes, streaming copy, channel-major 4-byte gathers (today's layout) and point/pixel-major
 row gathers (a gathered element = C contiguous floats).  Prints achieved GB/s per pattern."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from ffb6d_amd import ops

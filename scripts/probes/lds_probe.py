@@ -1,7 +1,7 @@
 """A/B of the LDS-tiled form of the point-major GEMM (tile_hint 7, mlp_pm_lds_kernel) against the default choice on the long-row
 layers, bf16 and fp32: time, TFLOP/s, largest difference of the results.  Usage: python scripts/lds_probe.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from ffb6d_amd import ops_pm

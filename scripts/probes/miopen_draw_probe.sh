@@ -4,7 +4,7 @@
 # -> gpurun_out/miopen_draw_probe.txt: frames/s, ms per step and the convolution kernels of the 512-channel layers for
 #    (a) find mode twice (the bench default; two processes = two draws), (b) immediate mode (--cudnn-benchmark 0),
 #    (c) find mode with CK's grouped-convolution solver excluded.
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
 run() {   # tag, extra env (NAME=VALUE or -), bench flags...
     local tag=$1 envs=$2; shift 2

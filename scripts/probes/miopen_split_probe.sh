@@ -3,7 +3,7 @@
 # 128..512-channel layers (tuned alone on the chip), which costs a zero-fill launch per convolution (SubTensorOpWithScalar1d, 0.36 ms per
 # step) and float atomics (results not bit-reproducible).  Runs the bench with the pinned perf-db and with the same perf-db with
 # gemm_k_global_split = 0 everywhere.   bash scripts/miopen_split_probe.sh   -> gpurun_out/r05_miopen_split_probe.txt
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
 run() {
     local tag=$1 db=$2

@@ -1,7 +1,7 @@
 """Where the time of mean_shift_fit_kernel goes: one vote set (and 256 copies of it) fitted with the round limit at 1, 2, 3, ... rounds.
     python scripts/pose_fit_probe.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ffb6d_amd import pose, synth
 dev = torch.device("cuda:0")

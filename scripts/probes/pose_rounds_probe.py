@@ -2,7 +2,7 @@
 """Time profile of the one-workgroup mean-shift fit (csrc/pose.hip: mean_shift_fit_kernel) over its rounds: the same vote sets with
 max_iter = 0, 1, 2, 4, 8, 16, 50, 100, 300 (HIP events around the launch alone).   python scripts/pose_rounds_probe.py [--sets 40|320]"""
 import argparse, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ffb6d_amd import pose, synth
 

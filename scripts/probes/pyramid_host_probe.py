@@ -1,7 +1,7 @@
 """Host-side timing of the index pyramid call by call (allocator warm-up: single calls of 8-36 ms among the first twenty, 0.32 ms after)
 and where torch reads the environment per call:  python scripts/pyramid_host_probe.py"""
 import os, sys, time, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ffb6d_amd import inputs, synth, pyramid
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 """What hiding the epilogue is worth with the tail quantisation taken out: rows = 128 * 512 (one point tile per slot of the chip), so the
 LDS-tiled form runs whole rounds of 512 workgroups and the tile-sequence form exactly one round.  python scripts/seq_gemm_potential.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ffb6d_amd import ops_pm
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@
 tile-sequence form (hint 8 + 256 T) for several T, interleaved in one process (rounds x variants x launches), median per launch.
     python scripts/seq_gemm_probe.py [--rounds 5] [--reps 8]"""
 import argparse, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ffb6d_amd import ops_pm
 

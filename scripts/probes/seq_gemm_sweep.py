@@ -3,7 +3,7 @@
 seven long-row fp32 launches of a bench step, alone on the chip; prints the LDS-tiled form, the automatic plan and the best plans.
     python scripts/seq_gemm_sweep.py [--rounds 3] [--reps 6]"""
 import argparse, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ffb6d_amd import ops_pm, _lib
 

@@ -1,7 +1,7 @@
 """Where do the two streams of the fused forward wait for each other?  Event pairs around every cross-stream wait
 (forward_pm.handover), averaged over steps of the default workload (bs=8, N=12288).  Usage: python scripts/stall_probe.py [bf16]   (bf16 = BASELINE config 5: bs=16, bf16 rows)"""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

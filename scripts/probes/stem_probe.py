@@ -2,7 +2,7 @@
 the plain channels-last call, input channels zero-padded to 4 / 8, and space-to-depth (stride-1 4x4 convolution on 12
 channels).  Prints time per call and the max deviation from the plain result.  Usage: python scripts/stem_probe.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 

@@ -2,7 +2,7 @@
 choice on the HBM-bound layers of the step, fp32 and bf16: time, algorithmic GB/s, and the largest difference of the results.
 Usage: python scripts/stream_probe.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from ffb6d_amd import ops_pm

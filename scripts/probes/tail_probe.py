@@ -1,7 +1,7 @@
 """Tile-schedule tail probe for csrc/mlp_pm.hip: one 1024->1024 (and 512->512, 256->256) GEMM at row counts that give
 2304 / 2400 / 3072 tiles (768 resident workgroups = 3.0 / 3.125 / 4.0 rounds).  Usage: python scripts/tail_probe.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from ffb6d_amd import ops_pm

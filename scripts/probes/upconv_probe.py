@@ -3,7 +3,7 @@
 bf16 (bs = 16); bf16 with the 2 x 4 block form on half units (round 6) and with the one-pixel-per-thread form; bit-equality of the two.
     python scripts/upconv_probe.py [--reps 20]"""
 import argparse, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ffb6d_amd import _lib, ops_pm
 
