@@ -669,11 +669,11 @@ def main():
         r = roofline_of(tracer, roof_op) if roof_op else None
         if r:
             traffic, traffic_set = None, None
-            pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            # HBM bytes per launch measured offline with rocprofv3 --pmc on the default workload (config 2, fp32, pm).  The table holds
+            pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == 2 else "pmc_traffic_config%d.json" % args.config)
+            # HBM bytes per launch measured offline with rocprofv3 --pmc on the same workload (config 2: fp32; config 5: bf16).  The table holds
             # the mean over ALL launches of the kernel instantiation in a step -- both sides of the ridge -- so `traffic_set` gives the
             # algorithmic bytes per launch over that same set of launches (the figure to set `traffic` beside), not this group's only
-            if os.path.exists(pmc_file) and args.precision == "fp32" and args.config == 2:
+            if os.path.exists(pmc_file) and args.precision == ("bf16" if args.config == 5 else "fp32") and args.batch == (16 if args.config == 5 else 8):
                 with open(pmc_file) as fh:
                     table = json.load(fh)
                     key = roof_op.replace(",mfma>", ">").replace(",hbm>", ">")

@@ -124,7 +124,7 @@ upconv_combine_lds_kernel(const upconv::CombineArgs a, const int nty, const int 
                 const U p00 = at(r0 + c0), p01 = at(r0 + c1), p10 = at(r1 + c0), p11 = at(r1 + c1);
 #pragma unroll
                 for (int e = 0; e < U::VL; ++e) {
-                    const float v = h0l * (w0l * p00.v[e] + w1l * p01.v[e]) + h1l * (w0l * p10.v[e] + w1l * p11.v[e]);
+                    const float v = upconv::blend2(h0l, upconv::blend2(w0l, p00.v[e], w1l, p01.v[e]), h1l, upconv::blend2(w0l, p10.v[e], w1l, p11.v[e]));
                     acc[e] += in ? v : 0.f;
                 }
             }

@@ -1,15 +1,16 @@
 #!/bin/bash
-# Round-end records on the GPU box, all from HEAD's defaults:  bash scripts/round_end.sh r04   (through gpurun; ~12 minutes)
+# Round-end records on the GPU box, all from HEAD's defaults:  bash scripts/round_end.sh r06   (through gpurun; ~15 minutes)
 #   1. scripts/profile_round.sh: kernel stats + PMC FETCH_SIZE / WRITE_SIZE passes of the default bench
 #   2. the default bench line with cpu_baseline                                   -> <tag>_bench_default_run.json
 #   3. configurations 4 and 5: bench line with cpu_baseline + rocprofv3 kernel stats -> <tag>_bench_config{4,5}_run.json, <tag>_kernels_config{4,5}.txt
 #   4. per-op / per-shape table on one stream                                      -> <tag>_hot_path_ops_by_shape_one_stream.txt
 #   5. fused LFA: level table and PMC of the level-0 launch; MFMA-busy PMC of the dominant GEMM
 #   6. training step (bf16 autocast and fp32; MIOpen's cold start alone is ~100 s: generous limits) + its kernel statistics
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.." || exit 1
 REPO=$PWD; OUT=$REPO/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
 bash scripts/profile_round.sh "$TAG" > /dev/null
+bash scripts/profile_round.sh "${TAG}_config5" --config 5 > /dev/null            # PMC traffic of the bf16 workload (roofline.traffic of its line)
 timeout 300 python bench.py > "$OUT/${TAG}_bench_default_run.json" 2> "$OUT/${TAG}_bench_default.err"
 for C in 4 5; do
     timeout 300 python bench.py --config $C > "$OUT/${TAG}_bench_config${C}_run.json" 2> "$OUT/${TAG}_bench_config${C}.err"
@@ -37,9 +38,22 @@ timeout 200 python scripts/bench_pose.py > "$OUT/${TAG}_pose_bench.json" 2> "$OU
 ( cd /tmp && rm -rf /tmp/prof_pose && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_pose -o k -- python "$REPO/scripts/bench_pose.py" --steps 4 > /dev/null 2> "$OUT/${TAG}_pose_prof.err"
   DB=$(find /tmp/prof_pose -name '*.db' | head -1); python "$REPO/scripts/rocpd_stats.py" "$DB" --top 25 > "$OUT/${TAG}_pose_kernels.txt" 2>&1 )
 timeout 120 python scripts/bench_inputs.py > "$OUT/${TAG}_inputs_bench.json" 2> "$OUT/${TAG}_inputs_bench.err"
+# round 6: sensor -> pose pipeline (serial / overlapped), operator-level drop-in, bf16 GEMM and upconv form tables, config-5 GEMM PMC
+timeout 300 python bench.py --mode e2e --steps 20 > "$OUT/${TAG}_bench_e2e.json" 2> "$OUT/${TAG}_bench_e2e.err"
+timeout 400 python bench.py --path dropin --steps 10 > "$OUT/${TAG}_bench_dropin.json" 2> "$OUT/${TAG}_bench_dropin.err"
+timeout 200 python scripts/probes/big_gemm_probe.py --hints 7,9 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_big_gemm_forms.txt"
+timeout 200 python scripts/probes/upconv_probe.py 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_upconv_forms.txt"
+bash scripts/pmc_pm_shape.sh 1024 1024 76800 bf16 9 > /dev/null 2>&1; cp "$OUT/pm_shape_pmc_1024_1024_76800_bf16_9.txt" "$OUT/${TAG}_mlp_pm_big_pmc_1024_1024_76800.txt"
 python -c "
 import json
 for n in ('default', 'config4', 'config5'):
     p = json.load(open('$OUT/${TAG}_bench_%s_run.json' % n))
     print(n, round(p['value'], 1), 'frames/s', round(p['ms_per_step'], 2), 'ms', p['roofline']['kernel'], round(p['roofline']['frac'], 3), 'traffic', p['roofline']['traffic'], 'cpu', p.get('cpu_baseline', {}).get('value'))
+"
+python -c "
+import json
+e = json.load(open('$OUT/${TAG}_bench_e2e.json'))['e2e']['synthetic_votes']
+print('e2e serial', round(e['serial']['ms_per_batch'], 2), 'overlapped', round(e['overlapped']['ms_per_batch'], 2), e['stage_ms'])
+d = json.load(open('$OUT/${TAG}_bench_dropin.json'))
+print('dropin', round(d['ms_per_step'], 2), 'ms; plain torch operators', round(d['same_forward_with_plain_torch_operators']['ms_per_step'], 2))
 "
