@@ -124,7 +124,7 @@ upconv_combine_lds_kernel(const upconv::CombineArgs a, const int nty, const int 
                 const U p00 = at(r0 + c0), p01 = at(r0 + c1), p10 = at(r1 + c0), p11 = at(r1 + c1);
 #pragma unroll
                 for (int e = 0; e < U::VL; ++e) {
-                    const float v = upconv::blend2(h0l, upconv::blend2(w0l, p00.v[e], w1l, p01.v[e]), h1l, upconv::blend2(w0l, p10.v[e], w1l, p11.v[e]));
+                    const float v = upconv::blend2<T>(h0l, upconv::blend2<T>(w0l, p00.v[e], w1l, p01.v[e]), h1l, upconv::blend2<T>(w0l, p10.v[e], w1l, p11.v[e]));
                     acc[e] += in ? v : 0.f;
                 }
             }
@@ -177,8 +177,9 @@ extern "C" int ffb6d_upconv_combine_pm(int dtype, const void* z, const float* sh
     a.slope = slope;
     a.banded = 1;         // XCD-band workgroup order (measured +0-6 %, profiles/r03_upconv_blend_forms_ab.txt)
     const int64_t zbytes = B * IH * IW * 9 * C * (dtype == 1 ? 2 : 4);
-    // Which form (profiles/r06_upconv_probe_v2.txt, us per launch at bs = 8 fp32 / bs = 16 bf16: LDS-staged | 2 x 4 block | one pixel):
-    //   fp32 C = 256: 269 | 177;  fp32 C = 64: 263 | 194;  bf16 C = 256: 399 | 363 | 429;  bf16 C = 64: 335 | 418 | 444
+    // Which form (profiles/r06_upconv_probe_v3_fma.txt, us per launch at bs = 8 fp32 / bs = 16 bf16: LDS-staged | 2 x 4 block | one pixel;
+    // fp32 with the unfused blend, profiles/r06_upconv_probe_v2.txt):
+    //   fp32 C = 256: 269 | 177;  fp32 C = 64: 263 | 194;  bf16 C = 256: 330 | 266 | 337;  bf16 C = 64: 275 | 294 | 346
     // -- every form is bound by vector-ALU issue (profiles/r06_upconv_pmc_*.txt: 93-160 lane operations per output element at 4 cycles
     // per wave instruction, 60 % of the SIMD cycles), the LDS-staged one wins where a pixel's channels are one chunk or two
     const bool lds_form = g_form == 3 || (g_form == 2 && dtype == 1 && C <= 64);

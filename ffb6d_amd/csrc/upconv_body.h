@@ -24,10 +24,18 @@ namespace upconv {
 
 template <typename T> using Unit = RowUnit<T>;      // csrc/row_unit.h
 
-// a0 * x0 + a1 * x1 as ONE product and one fused multiply-add (round 6): every form of the blend is bound by vector-ALU issue
-// (profiles/r06_upconv_pmc_*.txt), the fused form is a quarter fewer instructions -- and one rounding fewer.  Every body below blends
-// through this function (horizontal pair, then vertical pair, tap by tap), so the forms stay bit-identical to one another.
-__host__ __device__ __forceinline__ float blend2(float a0, float x0, float a1, float x1) { return fmaf(a1, x1, a0 * x0); }
+// a0 * x0 + a1 * x1.  Every form of the blend is bound by vector-ALU issue (profiles/r06_upconv_pmc_*.txt), so the instruction count IS the
+// time -- and it depends on the element type (profiles/r06_upconv_probe_v3_fma.txt): on bfloat16 units one product + one fused
+// multiply-add is a quarter fewer instructions (2 x 4 block 363 -> 266 us, 418 -> 294 us); on float32 units hipcc packs the unfused
+// products and sums of neighbouring channels into v_pk_mul_f32 / v_pk_add_f32 (1.5 instructions per element) and does not pack the
+// fused form (2 per element): 177 -> 195 us.  So: fused for bfloat16 (and its half units), unfused for float32.  Every body below blends
+// through this function (horizontal pair, then vertical pair, tap by tap): the forms of one precision stay bit-identical to one another.
+template <typename T>
+__host__ __device__ __forceinline__ float blend2(float a0, float x0, float a1, float x1)
+{
+    if constexpr (sizeof(T) == sizeof(float)) return a0 * x0 + a1 * x1;
+    else return fmaf(a1, x1, a0 * x0);
+}
 
 // XCD-aware order of a 2-D launch (MI355X: 8 XCDs with private L2s, workgroup i of a 1-D grid runs on XCD i % 8 -- observed
 // dispatch rule, speed only): XCD x gets the x-th contiguous eighth of the row-major (by, bx) blocks, i.e. a band of
@@ -101,7 +109,7 @@ __host__ __device__ __forceinline__ void combine_body(const CombineArgs& a, int 
             const U p00 = U::load(a.z, r0 + i0), p01 = U::load(a.z, r0 + i1), p10 = U::load(a.z, r1 + i0), p11 = U::load(a.z, r1 + i1);
 #pragma unroll
             for (int e = 0; e < U::VL; ++e) {
-                const float v = blend2(h0l, blend2(w0l, p00.v[e], w1l, p01.v[e]), h1l, blend2(w0l, p10.v[e], w1l, p11.v[e]));
+                const float v = blend2<T>(h0l, blend2<T>(w0l, p00.v[e], w1l, p01.v[e]), h1l, blend2<T>(w0l, p10.v[e], w1l, p11.v[e]));
                 acc[e] += in ? v : 0.f;
             }
         }
@@ -190,7 +198,7 @@ __host__ __device__ __forceinline__ void tap_select(const CombineArgs& a, const 
                     pa = ax.a[j] == cc ? win[r][cc].v[e] : pa;
                     pb = ax.b[j] == cc ? win[r][cc].v[e] : pb;
                 }
-                s[r][j][e] = blend2(ax.l0[j], pa, ax.l1[j], pb);
+                s[r][j][e] = blend2<T>(ax.l0[j], pa, ax.l1[j], pb);
             }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -205,7 +213,7 @@ __host__ __device__ __forceinline__ void tap_select(const CombineArgs& a, const 
                     sa = ay.a[i] == r ? s[r][j][e] : sa;
                     sb = ay.b[i] == r ? s[r][j][e] : sb;
                 }
-                const float v = blend2(ay.l0[i], sa, ay.l1[i], sb);
+                const float v = blend2<T>(ay.l0[i], sa, ay.l1[i], sb);
                 acc[i][j][e] += in ? v : 0.f;
             }
         }
@@ -240,7 +248,7 @@ __host__ __device__ __forceinline__ void win_blend(const Axis2& ay, const Axis4&
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < U::VL; ++e)
-                s[r][j][e] = blend2(ax.l0[j], win[r][pattern_a(KXM, j)].v[e], ax.l1[j], win[r][pattern_a(KXM, j) + 1].v[e]);
+                s[r][j][e] = blend2<T>(ax.l0[j], win[r][pattern_a(KXM, j)].v[e], ax.l1[j], win[r][pattern_a(KXM, j) + 1].v[e]);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -248,7 +256,7 @@ __host__ __device__ __forceinline__ void win_blend(const Axis2& ay, const Axis4&
             const bool in = ay.in[i] && ax.in[j];
 #pragma unroll
             for (int e = 0; e < U::VL; ++e) {
-                const float v = blend2(ay.l0[i], s[pattern_a(KYM, i)][j][e], ay.l1[i], s[pattern_a(KYM, i) + 1][j][e]);
+                const float v = blend2<T>(ay.l0[i], s[pattern_a(KYM, i)][j][e], ay.l1[i], s[pattern_a(KYM, i) + 1][j][e]);
                 acc[i][j][e] += in ? v : 0.f;
             }
         }
