@@ -488,7 +488,7 @@ def main():
             # --precision bf16: mixed precision as the reference trains (apex amp, train_lm.py:600) -- torch.autocast runs
             # the convolutions / 1x1 layers in bfloat16 with fp32 master weights; the neighbour operators (ops_cl), the decoder's
             # LogSoftmax and the up-samplings work on rows in that activation dtype with fp32 arithmetic inside and round their outputs
-            # to it (DESIGN.md section 6)
+            # to it (DESIGN.md section 7)
             with torch.enable_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.precision == "bf16"):
                 out = ddp(inputs)
                 if targets is not None:        # the reference's objective (train_lm.py:245-259) on the synthetic targets

@@ -313,7 +313,7 @@ class FinalHead(nn.Sequential):
         y = self[0](x)
         if y.is_cuda and self.rows_log_softmax:
             # the same operator on rows, in the map's own dtype: under autocast ATen's log_softmax is an fp32 operator that writes the two
-            # largest maps of the decoder as fp32 (measured with the multi-lane gather backward: 61.2 -> 54.0 ms
+            # largest maps of the decoder as fp32 (history: profiles/r03_r04_training_step_history_notes.md; measured with the multi-lane gather backward: 61.2 -> 54.0 ms
             # per bf16 training step, profiles/r04_start_bench_train_bf16_{default,optin}.json)
             return ops_cl.channel_log_softmax(y)
         return self[1](y)

@@ -5,7 +5,7 @@ Building_block.gather_neighbour / relative_pos_encoding RandLANet.py:216-234, th
 RandLANet.py:245-248; plus the LogSoftmax of the colour decoder's `final` layer, pspnet.py:108-112), but every [B,C,...] tensor they take or return is read and written as ROWS of C contiguous channels --
 torch's channels_last memory of a [B,C,N,K] tensor, which is what MIOpen's NHWC convolutions produce and consume -- in the
 activation dtype (bf16 under torch.autocast).  A training step built from them has no transposing copy and no bf16 <-> fp32 cast
-between a convolution and a neighbour operator (round 3's profile: 15 + 5 ms of an 82 ms step, DESIGN.md section 6).
+between a convolution and a neighbour operator (round 3's profile: 15 + 5 ms of an 82 ms step, DESIGN.md section 7).
 
 Forward gathers and the max-pool are the inference kernels (csrc/ops_pm.hip); the backward bodies are csrc/train_rows.hip.
 Tensors of other layouts are accepted (one copy into rows); channel counts that are not a multiple of the 16-byte unit

@@ -1,7 +1,7 @@
 """In-process A/B of forward_pm's boolean form attributes on the default workload (bs = 8, N = 12288, fp32, three streams; --precision bf16
 --batch 16 = BASELINE configuration 5):
 one model and one set of MIOpen solver choices, the forms toggled between blocks of steps.  `bench.py --form` runs each setting in
-its own process, where MIOpen's search alone moves the step by +-0.8 ms -- more than the forms compared here.
+its own process, where MIOpen's search alone moves the step by +-0.8 ms (round 4; since round 5 the bench pins MIOpen, ffb6d_amd/miopen_pin.py) -- more than the forms compared here.
 
     python scripts/ab_forms.py HEADS_SHARE_FIRST,HEADS_ALIGN_LAST HEADS_ON_BOTH_STREAMS
 compares: every listed attribute off / the first group on / the first two groups on / ...; prints one JSON line."""

@@ -1,5 +1,5 @@
 #!/bin/bash
-# how much of the bench line is MIOpen's solver draw, and which deterministic setting is best.
+# (round 4, profiles/r05_design_md_history_notes.md section 7): how much of the bench line is MIOpen's solver draw, and which deterministic setting is best.
 #   bash scripts/miopen_draw_probe.sh   (through gpurun; ~5 minutes: immediate mode compiles its kernels on a cold cache)
 # -> gpurun_out/miopen_draw_probe.txt: frames/s, ms per step and the convolution kernels of the 512-channel layers for
 #    (a) find mode twice (the bench default; two processes = two draws), (b) immediate mode (--cudnn-benchmark 0),

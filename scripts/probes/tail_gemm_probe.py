@@ -1,4 +1,4 @@
-"""The two GEMMs of the step's tail (DESIGN 4b'): K = 576 -> 64 on the picked pixels' patch rows and the heads' stacked first layer
+"""The two GEMMs of the step's tail (profiles/r05_design_md_history_notes.md 4b'): K = 576 -> 64 on the picked pixels' patch rows and the heads' stacked first layer
 (64 + 64 -> 384, two sources), per kernel form (tile_hint), fp32 at bs = 8 and bf16 at bs = 16.  Usage: python scripts/tail_gemm_probe.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

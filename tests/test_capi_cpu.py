@@ -105,7 +105,7 @@ def test_workspace_query_is_pure_host_logic(native_lib):
     # small support, many query blocks -> brute-force scan without split, no scratch
     assert native_lib.ffb6d_knn_uses_pruning(64, 256, 12288, 16) == 0
     assert native_lib.ffb6d_knn_workspace_bytes(64, 256, 12288, 16) == 0
-    # from 512 support points on the Morton-prepared search is the faster one (DESIGN 5, round 5)
+    # from 512 support points on the Morton-prepared search is the faster one (DESIGN.md 5, round 5)
     assert native_lib.ffb6d_knn_uses_pruning(64, 1024, 12288, 16) == 1
     # big support -> Morton-prepared sets + sort scratch
     assert native_lib.ffb6d_knn_uses_pruning(8, 76800, 768, 16) == 1

@@ -125,7 +125,7 @@ def test_stacked_head_gemm_on_the_emulator(emu, dt):
 
 
 def test_kernel_forms_are_bit_identical_on_the_emulator(emu):
-    """DESIGN 4a' / 4a'': stream form and LDS-tiled form feed every accumulator the same products in the same k order as the
+    """DESIGN.md 4a (forms 2 and 3): stream form and LDS-tiled form feed every accumulator the same products in the same k order as the
     tile kernels -- equal bits (the emulated MFMA is deterministic, so any difference would be one of operand order)"""
     g = torch.Generator().manual_seed(9)
     x = torch.randn(1, 300, 128, generator=g)
@@ -430,7 +430,7 @@ def test_whole_fused_forward_on_the_emulator_matches_the_plain_torch_restatement
 
 
 def test_head_forms_equal_the_dense_last_stage_on_the_emulator(emu):
-    """DESIGN 4b': the last colour stage at the picked pixels + the heads' forms against the dense evaluation of the same network
+    """the last colour stage at the picked pixels + the heads' forms against the dense evaluation of the same network
     (tests/test_forward_gpu.py's own check with CPU tensors; one ragged frame: 1100 points, 72 x 88 pixels -- two whole forwards)"""
     import test_forward_gpu as TF
     TF.test_head_forms_equal_the_dense_last_stage(torch.device("cpu"), "fp32", n_pts=1100, height=72, width=88, n_frames=1)
