@@ -106,6 +106,9 @@ def parse():
                          "with patch.patch_classes applied, i.e. what patch_reference makes an unmodified reference model execute; "
                          "fused (default): the package's own point-major inference path")
     ap.add_argument("--e2e-objects", type=int, default=5, help="--mode e2e: objects per frame of the synthetic vote field")
+    ap.add_argument("--fit-spread", type=int, default=None, choices=(0, 1, 2),
+                    help="--mode e2e: the pose solver's chip-wide first rounds (pose.set_fit_spread): 0 never, 2 always, 1 (default) = "
+                         "calls of few sets, and never under the overlapped schedule")
     ap.add_argument("--form", action="append", default=[], metavar="NAME=0|1",
                     help="A/B runs: set a boolean form attribute of ffb6d_amd.forward_pm (HEADS_SHARE_FIRST=0 ...) before the model is "
                          "built; the line's config.forms records what ran")
@@ -222,6 +225,8 @@ def run_e2e(args, dev, net, frames):
     """--mode e2e: K batches through ffb6d_amd.pipeline.SensorToPose, serial and overlapped; one JSON line."""
     from ffb6d_amd import inputs, pipeline, pose, synth
     B, N = args.batch, args.n_points
+    if args.fit_spread is not None:
+        pose.set_fit_spread(args.fit_spread)              # (1: the overlapped schedule still switches it off, pipeline.py)
     rgb = torch.from_numpy(frames["rgb"]).to(dev)                                         # uint8 [B,3,H,W]
     depth = torch.from_numpy(np.ascontiguousarray(frames["dpt_xyz"][:, 2])).to(dev)       # metres, zeros where invalid
     sensor = {"rgb": rgb, "depth": depth}

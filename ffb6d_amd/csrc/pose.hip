@@ -129,6 +129,107 @@ __global__ __launch_bounds__(kBlock) void mean_shift_round_kernel(
     }
 }
 
+// One point of the one-workgroup fit against the positions [0, n): 4 lanes per point, lane `sub` takes the pairs x = 2 sub, 2 sub + 8, ...
+// (two per step), then the four lanes meet.  aw / ax / ay / az: sums of w and w * position, am: multiplicity at the point's own
+// position, r: lowest index there.  Shared by the fit kernel and by the kernel that spreads a set's first rounds over the chip: the same
+// instructions in the same order, hence the same bits.
+__device__ __forceinline__ void fit_pair_sums(const float* cx_, const float* cy_, const float* cz_, const float* pm, int n, int sub, v2f kk,
+                                              v2f cx, v2f cy, v2f cz, float& aw, float& ax_, float& ay_, float& az_, float& am_, int& r)
+{
+#pragma clang fp contract(fast)
+    v2f sw = {0.f, 0.f}, sx = {0.f, 0.f}, sy = {0.f, 0.f}, sz = {0.f, 0.f}, mult = {0.f, 0.f};
+    int r0 = 1 << 30, r1 = 1 << 30;                   // (a point always finds itself: the sentinel never survives)
+#pragma unroll 2
+    for (int x = 2 * sub; x < n; x += 8) {
+        const v2f ax = *reinterpret_cast<const v2f*>(&cx_[x]);
+        const v2f ay = *reinterpret_cast<const v2f*>(&cy_[x]);
+        const v2f az = *reinterpret_cast<const v2f*>(&cz_[x]);
+        const v2f am = *reinterpret_cast<const v2f*>(&pm[x]);
+        const v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
+        const v2f d2 = dx * dx + dy * dy + dz * dz;
+        const v2f e = d2 * kk;
+        v2f w;
+        w.x = __builtin_amdgcn_exp2f(e.x);
+        w.y = __builtin_amdgcn_exp2f(e.y);
+        w *= am;
+        sw += w;
+        sx += w * ax;
+        sy += w * ay;
+        sz += w * az;
+        const bool h0 = d2.x == 0.f, h1 = d2.y == 0.f;   // the same position (a far padding point never is)
+        mult.x += h0 ? am.x : 0.f;
+        mult.y += h1 ? am.y : 0.f;
+        r0 = h0 ? min(r0, x) : r0;
+        r1 = h1 ? min(r1, x + 1) : r1;
+    }
+    aw = sw.x + sw.y; ax_ = sx.x + sx.y; ay_ = sy.x + sy.y; az_ = sz.x + sz.y; am_ = mult.x + mult.y;
+    r = min(r0, r1);
+#pragma unroll
+    for (int o = 1; o < 4; o <<= 1) {
+        aw += __shfl_xor(aw, o);
+        ax_ += __shfl_xor(ax_, o);
+        ay_ += __shfl_xor(ay_, o);
+        az_ += __shfl_xor(az_, o);
+        am_ += __shfl_xor(am_, o);
+        r = min(r, __shfl_xor(r, o));
+    }
+}
+
+// ---- the first two rounds of a set spread over the chip (round 6) -------------------------------------------------
+// A fit is a chain of ~260 rounds in ONE workgroup, and its first rounds are the whole cost of the early collapse: round 0 of a
+// 1700-vote set is 3 M weighted pairs = 1.25 ms on one CU, round 1 0.45 ms, the other ~260 rounds 3.3 us each
+// (profiles/r06_pose_rounds_probe.txt) -- while a call with 40 sets (the centre votes of a batch) leaves 216 CUs idle.  This kernel
+// makes ONE round for 128 points of a set per workgroup (the set in LDS as the fit keeps it, the fit's own pair function): new
+// positions, multiplicity and representative of every point (one float4) and the set's largest move (atomic max), to global memory --
+// into the round-by-round path's two position buffers and move slots, idle while the fits run.  ffb6d_mean_shift_f32 runs it twice
+// (round 0 on the votes, round 1 on round 0's positions); the fit kernel then STARTS from those results -- round 1's only when round 0
+// found no duplicate and did not converge, which is when its own round 1 would have read exactly these positions with multiplicity 1.
+// Same arithmetic per point as the fit's own rounds: equal bits (tests/test_pose_gpu.py compares the two paths).
+constexpr int kSpreadMin = 512;               // smaller sets: the fit's own first rounds are cheap
+constexpr int kSpreadBT = 512;
+
+__global__ __launch_bounds__(kSpreadBT) void mean_shift_spread_round_kernel(
+    const float4* __restrict__ in, const int* __restrict__ counts, int sets_per_count, int64_t stride, int cap, float k2,
+    float4* __restrict__ out, unsigned* __restrict__ move_of) {
+#pragma clang fp contract(fast)
+    extern __shared__ __attribute__((aligned(16))) unsigned char spread_lds[];
+    float* px = reinterpret_cast<float*>(spread_lds);
+    float *py = px + cap, *pz = py + cap, *pm = pz + cap;
+    const int g = blockIdx.y;
+    const int M = counts[g / sets_per_count];
+    const int q0 = blockIdx.x * (kSpreadBT / 4);
+    if (M < kSpreadMin || M > cap || q0 >= M) return;
+    const int tid = threadIdx.x, sub = tid & 3;
+    const int n = (M + 7) & ~7;
+    for (int j = tid; j < n; j += kSpreadBT) {
+        float4 p = make_float4(kFar, kFar, kFar, 0.f);
+        if (j < M) p = in[g * stride + j];
+        px[j] = p.x; py[j] = p.y; pz[j] = p.z;
+        pm[j] = j < M ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const int q = q0 + (tid >> 2);
+    const int qc = min(q, M - 1);
+    const float ccx = px[qc], ccy = py[qc], ccz = pz[qc];
+    const v2f cx = {ccx, ccx}, cy = {ccy, ccy}, cz = {ccz, ccz};
+    const v2f kk = {k2, k2};
+    float aw, ax, ay, az, am;
+    int r;
+    fit_pair_sums(px, py, pz, pm, n, sub, kk, cx, cy, cz, aw, ax, ay, az, am, r);
+    float mv = 0.f;
+    if (q < M && sub == 0) {
+        const float nx = ax / aw, ny = ay / aw, nz = az / aw;
+        const float ex = nx - ccx, ey = ny - ccy, ez = nz - ccz;
+        mv = sqrtf(ex * ex + ey * ey + ez * ez);
+        if (!(mv == mv)) mv = __uint_as_float(0x7f800000u);     // NaN never counts as converged
+        // .w: the representative (< 4096) and the multiplicity (a count of ones, <= 4096) of the point, as bits
+        out[g * stride + q] = make_float4(nx, ny, nz, __uint_as_float((unsigned)r | ((unsigned)am << 16)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mv = fmaxf(mv, __shfl_xor(mv, o));
+    if ((tid & 63) == 0) atomicMax(&move_of[g], __float_as_uint(mv));     // moves are >= +0: their order is the order of their bits
+}
+
 // ---- the whole fit of one vote set in ONE workgroup (round 5) ---------------------------------------------------
 // What the round-by-round kernels above cost on a batch of 8 frames x 5 objects (profiles/r05_pose_start.json): 903 launches, 80 ms,
 // 2.5e11 weighted pairs -- the sets need 220-260 rounds to meet the reference's stopping rule (largest move < bandwidth / 1000), and every
@@ -159,7 +260,8 @@ template <int kBT, int kCap>
 __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
     const float4* __restrict__ sets, const int* __restrict__ counts, int sets_per_count, int64_t stride, float k2, float thresh,
     float bandwidth, int max_iter, float* __restrict__ centers, unsigned char* __restrict__ labels, int* __restrict__ n_inside,
-    int* __restrict__ iters, int* __restrict__ rounds_ws, int* __restrict__ n_large, int m_lo, int count_large) {
+    int* __restrict__ iters, int* __restrict__ rounds_ws, int* __restrict__ n_large, int m_lo, int count_large,
+    const float4* __restrict__ pre0, const float4* __restrict__ pre1, const unsigned* __restrict__ pre_move, int G) {
 #pragma clang fp contract(fast)
     static_assert(kCap == 4 * kBT, "the compaction gives every thread four consecutive slots");
     extern __shared__ __attribute__((aligned(16))) unsigned char fit_lds[];
@@ -202,6 +304,7 @@ __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
         owner[j] = (unsigned short)j;
     }
     int U = M, cur = 0, made = 0;
+    bool nodup0 = false;
     const int sub = tid & 3;
     const v2f kk = {k2, k2};
     __syncthreads();
@@ -212,47 +315,27 @@ __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
         const int n = (U + 7) & ~7;                             // (slots U .. n hold far points of multiplicity 0)
         float move = 0.f;
         int dups = 0;
+        // rounds 0 and 1 of the larger sets were made by mean_shift_spread_round_kernel (round 1: valid when round 0 merged nothing)
+        const float4* ready = M >= kSpreadMin ? (t == 0 ? pre0 : (t == 1 && nodup0 ? pre1 : nullptr)) : nullptr;
+        if (ready) {
+            for (int q = tid; q < U; q += kBT) {
+                const float4 a4 = ready[g * stride + q];
+                const unsigned bits = __float_as_uint(a4.w);
+                nx_[q] = a4.x; ny_[q] = a4.y; nz_[q] = a4.z;
+                pmn[q] = (float)(bits >> 16);
+                rep[q] = (unsigned short)(bits & 0xffffu);
+                dups += (int)(bits & 0xffffu) != q;
+            }
+            move = __uint_as_float(pre_move[t * G + g]);
+        } else
         for (int i0 = 0; i0 < U; i0 += kBT / 4) {
             const int q = i0 + (tid >> 2);
             const int qc = min(q, U - 1);
             const float ccx = cx_[qc], ccy = cy_[qc], ccz = cz_[qc];
             const v2f cx = {ccx, ccx}, cy = {ccy, ccy}, cz = {ccz, ccz};
-            v2f sw = {0.f, 0.f}, sx = {0.f, 0.f}, sy = {0.f, 0.f}, sz = {0.f, 0.f}, mult = {0.f, 0.f};
-            int r0 = kCap, r1 = kCap;
-#pragma unroll 2
-            for (int x = 2 * sub; x < n; x += 8) {
-                const v2f ax = *reinterpret_cast<const v2f*>(&cx_[x]);
-                const v2f ay = *reinterpret_cast<const v2f*>(&cy_[x]);
-                const v2f az = *reinterpret_cast<const v2f*>(&cz_[x]);
-                const v2f am = *reinterpret_cast<const v2f*>(&pm[x]);
-                const v2f dx = ax - cx, dy = ay - cy, dz = az - cz;
-                const v2f d2 = dx * dx + dy * dy + dz * dz;
-                const v2f e = d2 * kk;
-                v2f w;
-                w.x = __builtin_amdgcn_exp2f(e.x);
-                w.y = __builtin_amdgcn_exp2f(e.y);
-                w *= am;
-                sw += w;
-                sx += w * ax;
-                sy += w * ay;
-                sz += w * az;
-                const bool h0 = d2.x == 0.f, h1 = d2.y == 0.f;   // the same position (a far padding point never is)
-                mult.x += h0 ? am.x : 0.f;
-                mult.y += h1 ? am.y : 0.f;
-                r0 = h0 ? min(r0, x) : r0;
-                r1 = h1 ? min(r1, x + 1) : r1;
-            }
-            float aw = sw.x + sw.y, ax = sx.x + sx.y, ay = sy.x + sy.y, az = sz.x + sz.y, am = mult.x + mult.y;
-            int r = min(r0, r1);
-#pragma unroll
-            for (int o = 1; o < 4; o <<= 1) {
-                aw += __shfl_xor(aw, o);
-                ax += __shfl_xor(ax, o);
-                ay += __shfl_xor(ay, o);
-                az += __shfl_xor(az, o);
-                am += __shfl_xor(am, o);
-                r = min(r, __shfl_xor(r, o));
-            }
+            float aw, ax, ay, az, am;
+            int r;
+            fit_pair_sums(cx_, cy_, cz_, pm, n, sub, kk, cx, cy, cz, aw, ax, ay, az, am, r);
             if (q < U && sub == 0) {
                 const float nx = ax / aw, ny = ay / aw, nz = az / aw;
                 nx_[q] = nx; ny_[q] = ny; nz_[q] = nz;
@@ -275,6 +358,7 @@ __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
         int bdups = __float_as_int(red[16]);
         for (int i = 1; i < kBT / 64; ++i) { bmove = fmaxf(bmove, red[i]); bdups += __float_as_int(red[16 + i]); }
         made = t + 1;
+        if (t == 0) nodup0 = bdups == 0;
         if (bdups == 0) {
             cur ^= 1;                                           // (slots U .. n of the other buffer: far points since the start or the last compaction)
         } else {
@@ -672,6 +756,12 @@ static int g_fit_form = 1;
 extern "C" {
 
 void ffb6d_pose_set_fit_form(int form) { g_fit_form = form; }
+// rounds 0 and 1 of the sets of 512 .. 4096 points made chip-wide before the one-workgroup fits: 1 (default) = when the fits alone
+// would leave at least half of the CUs idle (G <= CUs / 2: 40 centre-vote sets of a batch -- 2.21 -> 1.66 ms; with 320 keypoint
+// sets the fits fill the chip and the spread rounds only add work, 3.17 -> 3.57 ms, profiles/r06_pose_spread_kernel_stats.txt),
+// 2 = always, 0 = never
+static int g_fit_spread = 1;
+void ffb6d_pose_set_fit_spread(int on) { g_fit_spread = on; }
 
 
 int ffb6d_vote_sets_f32(const float* pcld, const float* offsets, const void* mask, int mask_bits,
@@ -743,7 +833,9 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
             fit_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&mean_shift_fit_kernel<1024, kCap>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, fit_lds_bytes(kCap)) == hipSuccess &&
                      hipFuncSetAttribute(reinterpret_cast<const void*>(&mean_shift_fit_kernel<512, kCapLight>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, fit_lds_bytes(kCapLight)) == hipSuccess;
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, fit_lds_bytes(kCapLight)) == hipSuccess &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(&mean_shift_spread_round_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * sizeof(float) * kCap) == hipSuccess;
             if (fit_ok) ffb6d::cache_set(attr_set, slot, 1);
             else (void)hipGetLastError();
         }
@@ -751,19 +843,47 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
     const int min_cnt = fit_ok ? kCap : -1;                    // sets above it are fitted round by round
     if (fit_ok) {
         const float4* s4 = reinterpret_cast<const float4*>(sets);
+        // the first two rounds of the sets of kSpreadMin .. kCap points, 128 points per workgroup
+        const float4 *pre0 = nullptr, *pre1 = nullptr;
+        bool spread = g_fit_spread == 2;
+        if (g_fit_spread == 1) {
+            static int cu_count[ffb6d::kMaxDevices + 1];
+            const int slot = ffb6d::device_slot();
+            int cus = ffb6d::cache_get(cu_count, slot);
+            if (cus == 0) {
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+                    cus = 256;
+                ffb6d::cache_set(cu_count, slot, cus);
+            }
+            spread = 2 * G <= cus;
+        }
+        if (spread && set_stride >= kSpreadMin) {
+            const int cap = static_cast<int>(std::min<int64_t>((set_stride + 7) & ~int64_t(7), kCap));
+            const dim3 sgrid(static_cast<unsigned>(ceil_div(cap, kSpreadBT / 4)), static_cast<unsigned>(G));
+            const size_t slds = 4 * sizeof(float) * static_cast<size_t>(cap);
+            mean_shift_spread_round_kernel<<<sgrid, kSpreadBT, slds, st>>>(s4, counts, sets_per_count, set_stride, cap, k2, buf0, shift);
+            FFB6D_LAUNCH_CHECK();
+            mean_shift_spread_round_kernel<<<sgrid, kSpreadBT, slds, st>>>(buf0, counts, sets_per_count, set_stride, cap, k2, buf1, shift + G);
+            FFB6D_LAUNCH_CHECK();
+            pre0 = buf0;
+            pre1 = buf1;
+        }
         if (g_fit_form == 1) {
             mean_shift_fit_kernel<512, kCapLight><<<static_cast<unsigned>(G), 512, fit_lds_bytes(kCapLight), st>>>(
-                s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large, 0, 0);
+                s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large, 0, 0,
+                pre0, pre1, shift, G);
             FFB6D_LAUNCH_CHECK();
             if (set_stride > kCapLight) {
                 mean_shift_fit_kernel<1024, kCap><<<static_cast<unsigned>(G), 1024, fit_lds_bytes(kCap), st>>>(
                     s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large,
-                    kCapLight, 1);
+                    kCapLight, 1, pre0, pre1, shift, G);
                 FFB6D_LAUNCH_CHECK();
             }
         } else {
             mean_shift_fit_kernel<1024, kCap><<<static_cast<unsigned>(G), 1024, fit_lds_bytes(kCap), st>>>(
-                s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large, 0, 1);
+                s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large, 0, 1,
+                pre0, pre1, shift, G);
             FFB6D_LAUNCH_CHECK();
         }
     }
@@ -777,6 +897,7 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
 
     // ---- sets of more than kCap points: one launch per round for all of them (round-1 path) ----
     FFB6D_HIP_TRY(hipMemsetAsync(best, 0, sizeof(unsigned long long) * G, st));
+    FFB6D_HIP_TRY(hipMemsetAsync(shift, 0, 3 * sizeof(unsigned) * G, st));     // (the spread rounds of the fits used two of the slots)
     FFB6D_HIP_TRY(hipMemcpyAsync(buf0, sets, static_cast<size_t>(G) * set_stride * sizeof(float4),
                                  hipMemcpyDeviceToDevice, st));
     // blocks beyond a set's count exit at once: the largest count sizes the grid

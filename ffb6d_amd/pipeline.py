@@ -81,6 +81,16 @@ class SensorToPose:
                 out = self.forward(inp)
                 results.append(pack(self.solve(inp, out), inp, out))
             return results
+        # the solver runs UNDER the next forward here: its one-workgroup fits on 40 CUs cost the forward less than chip-wide first rounds
+        # (overlapped period 25.3 ms without them, 25.8 ms with; serial 30.3 / 29.2 ms -- profiles/r06_e2e_spread_ab.txt)
+        spread = _pose.set_fit_spread(0) if _pose.FIT_SPREAD == 1 else None
+        try:
+            return self._run_overlapped(batches, results, pack)
+        finally:
+            if spread is not None:
+                _pose.set_fit_spread(spread)
+
+    def _run_overlapped(self, batches, results, pack):
         main = torch.cuda.current_stream(self.dev)
         s_in, s_pose = self._side()
 

@@ -22,6 +22,17 @@ RADIUS = 0.04          # bandwidth used by both flows (pvn3d_eval_utils_kpls.py:
 CHECK_EVERY = 8        # rounds between convergence polls
 
 
+FIT_SPREAD = 1         # csrc/pose.hip ffb6d_pose_set_fit_spread: 1 = the fits' first two rounds chip-wide when the call has few sets
+
+
+def set_fit_spread(mode):
+    """0 never / 1 when G <= CUs / 2 (default) / 2 always; returns the previous setting.  Results do not depend on it."""
+    global FIT_SPREAD
+    prev, FIT_SPREAD = FIT_SPREAD, int(mode)
+    _lib.load().ffb6d_pose_set_fit_spread(FIT_SPREAD)
+    return prev
+
+
 def _i32(values, device):
     return torch.tensor(list(values), dtype=torch.int32, device=device)
 

@@ -51,6 +51,10 @@ size_t ffb6d_mean_shift_workspace_bytes(int G, int64_t set_stride);
 /* A/B of the one-workgroup fit: 1 (default) = sets of up to 2048 points on the light form (512 threads, 78 KB of LDS: fits beside
  * other workgroups on a CU), larger ones up to 4096 on the round-5 form; 0 = the round-5 form for all of them.  Identical results. */
 void ffb6d_pose_set_fit_form(int form);
+/* The first two rounds of the sets of 512 .. 4096 points made chip-wide (128 points per workgroup, results in the workspace), the
+ * one-workgroup fits starting from them: 1 (default) = when G <= CUs / 2 (the fits alone would leave half of the chip idle),
+ * 2 = always, 0 = never (every round inside the fit).  Identical results (same pair arithmetic). */
+void ffb6d_pose_set_fit_spread(int on);
 int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_count, int G,
                          int64_t set_stride, int64_t max_count, float bandwidth, int max_iter,
                          int check_every, float* centers, unsigned char* labels, int* n_inside,

@@ -20,10 +20,12 @@ ap.add_argument("--n-points", type=int, default=12288)
 ap.add_argument("--objects", type=int, default=5)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--fit-form", type=int, default=1, help="0: the round-5 one-workgroup fit for every set; 1: light form for sets <= 2048 points")
+ap.add_argument("--fit-spread", type=int, default=1, help="rounds 0 and 1 of the sets of >= 512 points made chip-wide before the fits: 1 when G <= CUs / 2, 2 always, 0 never")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
 _lib.load().ffb6d_pose_set_fit_form(args.fit_form)
+_lib.load().ffb6d_pose_set_fit_spread(args.fit_spread)
 cases = [synth.make_pose_case(900 + b, n_pts=args.n_points, n_obj=args.objects, mesh_seed=9) for b in range(args.batch)]
 stack = lambda key: torch.from_numpy(np.stack([c[key] for c in cases])).to(dev)
 pcld, mask, ctr_of, kp_of = stack("pcld"), stack("mask"), stack("ctr_of"), stack("kp_of")
@@ -43,7 +45,7 @@ stats = {}
 pose.solve_poses(pcld, mask, ctr_of, kp_of, mk, mc, r_lst=rl, stats=stats)
 wall = (time.perf_counter() - t0) / args.steps
 err = max(np.abs(T - cases[b]["RT"][c]).max() for b, (ids, poses, _) in enumerate(res) for c, T in zip(ids, poses))
-out = {"fit_form": args.fit_form, "batch": args.batch, "n_points": args.n_points, "objects_per_frame": args.objects,
+out = {"fit_form": args.fit_form, "fit_spread": args.fit_spread, "batch": args.batch, "n_points": args.n_points, "objects_per_frame": args.objects,
        "wall_ms_per_batch": 1e3 * wall, "frames_per_s": args.batch / wall, "max_pose_err_vs_truth": float(err),
        "kernels_ms_per_batch": {k: v["total_ms"] / args.steps for k, v in tracer.summary().items()}}
 for k in ("refine", "ctr", "kps"):

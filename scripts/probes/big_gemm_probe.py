@@ -13,6 +13,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--reps", type=int, default=8)
 ap.add_argument("--hints", default="7,9")
 ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--xpad", type=int, default=0, help="allocate X rows this many elements longer than K (row stride != K: do the rows' segments rotate over the L2 channels?)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 PEAK = 2500.0
@@ -27,7 +28,7 @@ torch.manual_seed(0)
 BF = torch.bfloat16
 tot = {}
 for K1, K2, C, P, py, role in SHAPES:
-    x1 = torch.randn(B, P, K1, device=dev).to(BF)
+    x1 = torch.randn(B, P, K1 + a.xpad, device=dev).to(BF)[..., :K1]
     x2 = torch.randn(B, P, K2, device=dev).to(BF) if K2 else None
     w = (torch.randn(C, K1 + K2, device=dev) / (K1 + K2) ** 0.5).to(BF)
     b = torch.randn(C, device=dev)

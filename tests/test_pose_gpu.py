@@ -84,6 +84,41 @@ def test_mean_shift_sets_beyond_the_one_workgroup_limit(device):
         assert flips <= max(1, int(LABEL_FLIP * sizes[g])), (sizes[g], flips)
 
 
+def test_mean_shift_forms_give_the_same_bits(device):
+    """Round 6: the first two rounds of the sets of 512 .. 4096 points are made chip-wide (mean_shift_spread_round_kernel) and the
+    one-workgroup fits start from them; sets of up to 2048 points run on the light fit.  Same pair arithmetic in every form: the
+    centres, labels, ball sizes and round counts must be equal bit for bit -- sizes either side of every threshold, sets whose
+    first round already merges duplicates (round 1's spread results are then not used), ragged counts behind one stride."""
+    from ffb6d_amd import _lib
+    lib = _lib.load()
+    sizes = (511, 512, 513, 1700, 2048, 2049, 3000, 4096, 40, 0, 900, 640)
+    stride = 4096
+    sets = torch.zeros((len(sizes), stride, 4), device=device)
+    for g, n in enumerate(sizes):
+        if n:
+            v = torch.from_numpy(gen.ms_votes(700 + g, n)).to(device)
+            if g in (10, 11):                                  # every vote of these sets twice: round 0 finds duplicates
+                v[n // 2:] = v[:n - n // 2]
+            sets[g, :n, :3] = v
+    counts = torch.tensor(sizes, dtype=torch.int32, device=device)
+    got = {}
+    try:
+        for form, spread in ((1, 2), (1, 1), (1, 0), (0, 2), (0, 0)):
+            lib.ffb6d_pose_set_fit_form(form)
+            lib.ffb6d_pose_set_fit_spread(spread)
+            got[form, spread] = [t.clone() for t in pose.mean_shift(sets, counts, 0.04)]
+            for limit in (0, 1, 2):                            # round limits inside the spread rounds
+                got[form, spread] += [t.clone() for t in pose.mean_shift(sets, counts, 0.04, limit)]
+    finally:
+        lib.ffb6d_pose_set_fit_form(1)
+        lib.ffb6d_pose_set_fit_spread(1)
+    base = got[0, 0]
+    assert int(base[3][3]) > 3 and int(base[3][10]) > 3        # real fits, not early exits
+    for key, res in got.items():
+        for a, b in zip(base, res):
+            assert torch.equal(a, b), key
+
+
 def test_mean_shift_round_limit_and_polling(device):
     """max_iter bounds the rounds (it > max_iter after max_iter+1 rounds, meanshift_pytorch.py:47);
     polling the stop flag every k rounds must not change the result."""
