@@ -77,6 +77,7 @@ SIGNATURES = {
     "ffb6d_upconv_set_form": (None, [_i32]),
     "ffb6d_pose_set_fit_form": (None, [_i32]),
     "ffb6d_pose_set_fit_spread": (None, [_i32]),
+    "ffb6d_pose_set_big_form": (None, [_i32]),
     "ffb6d_psp_pool_pm_workspace_bytes": (_sz, [_i64, _i64, _i64, _vp, _i32]),
     "ffb6d_psp_pool_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp]),
     "ffb6d_psp_prior_sum_pm": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp]),

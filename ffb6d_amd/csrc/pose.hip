@@ -54,13 +54,14 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // instruction); the tile is kept as three planes in LDS so a lane fetches two neighbours per b64 read.
 __global__ __launch_bounds__(kBlock) void mean_shift_round_kernel(
     float4* __restrict__ buf0, float4* __restrict__ buf1, const int* __restrict__ counts, int sets_per_count,
-    int64_t stride, float k2, float thresh, unsigned* __restrict__ shift, int* __restrict__ rounds, int t, int G, int min_cnt) {
+    int64_t stride, float k2, float thresh, unsigned* __restrict__ shift, int* __restrict__ rounds, int t, int G, int min_cnt,
+    const int* __restrict__ handed) {
 #pragma clang fp contract(fast)
     __shared__ __attribute__((aligned(16))) float tx[kTile], ty[kTile], tz[kTile];
     __shared__ float wmax[kBlock / 64];
     const int g = blockIdx.y;
     const int cnt = counts[g / sets_per_count];
-    if (cnt <= min_cnt) return;                 // fitted by mean_shift_fit_kernel
+    if (cnt <= min_cnt || (handed && handed[g] <= min_cnt)) return;     // fitted by mean_shift_fit_kernel (directly / after the chip-wide rounds)
     bool done = false;
     if (t > 0) done = __uint_as_float(shift[((t + 2) % 3) * G + g]) < thresh;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -261,9 +262,14 @@ __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
     const float4* __restrict__ sets, const int* __restrict__ counts, int sets_per_count, int64_t stride, float k2, float thresh,
     float bandwidth, int max_iter, float* __restrict__ centers, unsigned char* __restrict__ labels, int* __restrict__ n_inside,
     int* __restrict__ iters, int* __restrict__ rounds_ws, int* __restrict__ n_large, int m_lo, int count_large,
-    const float4* __restrict__ pre0, const float4* __restrict__ pre1, const unsigned* __restrict__ pre_move, int G) {
+    const float4* __restrict__ pre0, const float4* __restrict__ pre1, const unsigned* __restrict__ pre_move, int G,
+    const float4* __restrict__ sets_odd, const int* __restrict__ start_of) {
 #pragma clang fp contract(fast)
     static_assert(kCap == 4 * kBT, "the compaction gives every thread four consecutive slots");
+    // start_of != nullptr: the launch CONTINUES fits begun chip-wide (big_round_kernel / big_compact_kernel below): set g = the distinct
+    // positions left after start_of[g] & 0xffff rounds, multiplicity in .w, in `sets` (even round count) or `sets_odd`; bit 30 = converged
+    // already (no further round); counts = distinct positions per set, 0 = not one of these sets (nothing is written)
+    const bool resumed = start_of != nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char fit_lds[];
     float* px = reinterpret_cast<float*>(fit_lds);              // [2][kCap] each: positions of the distinct points, ping-pong
     float* py = px + 2 * kCap;
@@ -284,6 +290,7 @@ __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
         return;
     }
     if (M <= m_lo && m_lo > 0) return;                          // fitted by the smaller form (empty sets included)
+    if (M <= 0 && resumed) return;
     if (M <= 0) {
         if (tid == 0) {
             centers[3 * g] = centers[3 * g + 1] = centers[3 * g + 2] = 0.f;
@@ -295,28 +302,30 @@ __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
             for (int64_t j = tid; j < stride; j += kBT) labels[g * stride + j] = 0;
         return;
     }
-    const float4* src = sets + g * stride;
+    const int start = resumed ? start_of[g] : 0;
+    const int t_first = start & 0xffff;
+    const float4* src = ((resumed && (t_first & 1)) ? sets_odd : sets) + g * stride;
     for (int j = tid; j < kCap; j += kBT) {
         const float4 p = j < M ? src[j] : make_float4(kFar, kFar, kFar, 0.f);
         px[j] = p.x; py[j] = p.y; pz[j] = p.z;
         px[kCap + j] = kFar; py[kCap + j] = kFar; pz[kCap + j] = kFar;      // the other buffer: far points wherever a round does not write
-        pm[j] = j < M ? 1.f : 0.f;
+        pm[j] = j < M ? (resumed ? p.w : 1.f) : 0.f;
         owner[j] = (unsigned short)j;
     }
-    int U = M, cur = 0, made = 0;
+    int U = M, cur = 0, made = t_first;
     bool nodup0 = false;
     const int sub = tid & 3;
     const v2f kk = {k2, k2};
     __syncthreads();
 
-    for (int t = 0; t <= max_iter; ++t) {                       // `it > max_iter` stops after max_iter + 1 rounds (:47)
+    for (int t = (start >> 30) ? max_iter + 1 : t_first; t <= max_iter; ++t) {      // `it > max_iter` stops after max_iter + 1 rounds (:47)
         const float *cx_ = px + cur * kCap, *cy_ = py + cur * kCap, *cz_ = pz + cur * kCap;
         float *nx_ = px + (cur ^ 1) * kCap, *ny_ = py + (cur ^ 1) * kCap, *nz_ = pz + (cur ^ 1) * kCap;
         const int n = (U + 7) & ~7;                             // (slots U .. n hold far points of multiplicity 0)
         float move = 0.f;
         int dups = 0;
         // rounds 0 and 1 of the larger sets were made by mean_shift_spread_round_kernel (round 1: valid when round 0 merged nothing)
-        const float4* ready = M >= kSpreadMin ? (t == 0 ? pre0 : (t == 1 && nodup0 ? pre1 : nullptr)) : nullptr;
+        const float4* ready = (M >= kSpreadMin && !resumed) ? (t == 0 ? pre0 : (t == 1 && nodup0 ? pre1 : nullptr)) : nullptr;
         if (ready) {
             for (int q = tid; q < U; q += kBT) {
                 const float4 a4 = ready[g * stride + q];
@@ -464,13 +473,13 @@ __global__ __launch_bounds__(kBT) void mean_shift_fit_kernel(
 __global__ __launch_bounds__(kBlock) void ball_count_kernel(
     const float4* __restrict__ buf0, const float4* __restrict__ buf1, const int* __restrict__ counts,
     int sets_per_count, int64_t stride, float bandwidth, const int* __restrict__ rounds,
-    unsigned long long* __restrict__ best, int min_cnt) {
+    unsigned long long* __restrict__ best, int min_cnt, const int* __restrict__ handed) {
     __shared__ float4 tile[kTile];
     __shared__ unsigned long long wbest[kBlock / 64];
     const int g = blockIdx.y;
     const int cnt = counts[g / sets_per_count];
     const int q0 = blockIdx.x * kPointsPerBlock;
-    if (q0 >= cnt || cnt <= min_cnt) return;
+    if (q0 >= cnt || cnt <= min_cnt || (handed && handed[g] <= min_cnt)) return;
     const float4* src = ((rounds[g] & 1) ? buf1 : buf0) + g * stride;
     const int sub = threadIdx.x & (kLanesPerPoint - 1);
     const int q = q0 + (threadIdx.x >> 2);
@@ -510,10 +519,10 @@ __global__ __launch_bounds__(kBlock) void ball_labels_kernel(
     const float4* __restrict__ buf0, const float4* __restrict__ buf1, const int* __restrict__ counts,
     int sets_per_count, int64_t stride, float bandwidth, const int* __restrict__ rounds,
     const unsigned long long* __restrict__ best, float* __restrict__ centers, unsigned char* __restrict__ labels,
-    int* __restrict__ n_inside, int* __restrict__ iters, int min_cnt) {
+    int* __restrict__ n_inside, int* __restrict__ iters, int min_cnt, const int* __restrict__ handed) {
     const int g = blockIdx.y;
     const int cnt = counts[g / sets_per_count];
-    if (cnt <= min_cnt) return;                 // results written by mean_shift_fit_kernel
+    if (cnt <= min_cnt || (handed && handed[g] <= min_cnt)) return;     // results written by mean_shift_fit_kernel
     const int j = blockIdx.x * kBlock + threadIdx.x;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && iters) iters[g] = rounds[g];
@@ -544,6 +553,170 @@ __global__ __launch_bounds__(kBlock) void ball_labels_kernel(
         }
         labels[g * stride + j] = lab;
     }
+}
+
+// ---- sets of more than kCap points: chip-wide rounds WITH duplicate merging, then the one-workgroup fit (round 6) -------------
+// The round-by-round path above makes max_iter + 1 rounds of M^2 pairs: 200 ms for eight 12288-point sets.  But such a set collapses like
+// the small ones -- 12288 scene points are 6246 distinct positions after 8 rounds, 3385 after 9, 63 after 22 -- so the work is in the first
+// rounds only, IF equal positions are merged.  Here the rounds of the large sets run chip-wide on (position, multiplicity) lists:
+//   big_round_kernel    64 points per workgroup against the whole list in 512-point tiles (the fit's pair function: weights times
+//                       multiplicity, multiplicity and lowest index at the point's own position), new positions + representative
+//   big_compact_kernel  one workgroup per set: representatives to the front in index order, original point -> distinct position map,
+//                       the list length, the stopping rule (largest move < thresh after the round, :47)
+// until every large set has at most kCap distinct positions (the host reads the lengths back after each round from the third on).
+// mean_shift_fit_kernel then CONTINUES the fits from those lists (multiplicities as weights, the round counter where it stands) and
+// big_labels_kernel carries its labels back to the original points.  A set that still has more than kCap positions after kBigRounds
+// rounds, or converged with more, or has merged next to nothing after kBigGiveUp rounds (scattered points that never meet), is left
+// to the round-by-round path from the start.
+// Merging is exact (equal bits only): the same iteration as the reference's, terms of equal points collected (as in the fit).
+constexpr int kBigRounds = 32;
+constexpr int kBigGiveUp = 7;
+constexpr int kCompactBT = 1024;
+
+__global__ __launch_bounds__(kBlock) void big_init_kernel(
+    const float4* __restrict__ sets, const int* __restrict__ counts, int sets_per_count, int64_t stride, const int* __restrict__ big_ids,
+    float4* __restrict__ buf0, unsigned* __restrict__ owner, int* __restrict__ len_of) {
+    const int g = big_ids[blockIdx.y];
+    const int cnt = counts[g / sets_per_count];
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j == 0) len_of[g] = cnt;
+    if (j < cnt) {
+        float4 p = sets[g * stride + j];
+        p.w = 1.f;
+        buf0[g * stride + j] = p;
+        owner[g * stride + j] = (unsigned)j;
+    }
+}
+
+// state_of[g]: rounds made | converged << 30
+__global__ __launch_bounds__(kBlock) void big_round_kernel(
+    float4* __restrict__ buf0, float4* __restrict__ buf1, int64_t stride, const int* __restrict__ big_ids, float k2, int t,
+    const int* __restrict__ len_of, const int* __restrict__ state_of, unsigned* __restrict__ rep, unsigned* __restrict__ move_of,
+    int* __restrict__ dups_of) {
+#pragma clang fp contract(fast)
+    __shared__ __attribute__((aligned(16))) float tx[kTile], ty[kTile], tz[kTile], tm[kTile];
+    const int g = big_ids[blockIdx.y];
+    const int U = len_of[g];
+    const int q0 = blockIdx.x * kPointsPerBlock;
+    if ((state_of[g] >> 29) || q0 >= U) return;
+    const float4* src = ((t & 1) ? buf1 : buf0) + g * stride;
+    float4* dst = ((t & 1) ? buf0 : buf1) + g * stride;
+    const int sub = threadIdx.x & 3;
+    const int q = q0 + (threadIdx.x >> 2);
+    const float4 c = src[min(q, U - 1)];
+    const v2f cx = {c.x, c.x}, cy = {c.y, c.y}, cz = {c.z, c.z}, kk = {k2, k2};
+    float aw = 0.f, ax = 0.f, ay = 0.f, az = 0.f, am = 0.f;
+    int r = 1 << 30;
+    for (int j0 = 0; j0 < U; j0 += kTile) {
+        __syncthreads();
+        for (int x = threadIdx.x; x < kTile; x += kBlock) {
+            const int j = j0 + x;
+            const float4 p = j < U ? src[j] : make_float4(kFar, kFar, kFar, 0.f);
+            tx[x] = p.x; ty[x] = p.y; tz[x] = p.z; tm[x] = p.w;
+        }
+        __syncthreads();
+        const int n = min(kTile, (U - j0 + 7) & ~7);
+        float w_, x_, y_, z_, m_;
+        int r_;
+        fit_pair_sums(tx, ty, tz, tm, n, sub, kk, cx, cy, cz, w_, x_, y_, z_, m_, r_);
+        aw += w_; ax += x_; ay += y_; az += z_; am += m_;
+        r = min(r, j0 + r_);
+    }
+    float move = 0.f;
+    int dup = 0;
+    if (q < U && sub == 0) {
+        const float nx = ax / aw, ny = ay / aw, nz = az / aw;
+        dst[q] = make_float4(nx, ny, nz, am);                   // (.w of a representative: the merged multiplicity)
+        rep[g * stride + q] = (unsigned)r;
+        dup = r != q;
+        const float ex = nx - c.x, ey = ny - c.y, ez = nz - c.z;
+        move = sqrtf(ex * ex + ey * ey + ez * ez);
+        if (!(move == move)) move = __uint_as_float(0x7f800000u);   // NaN never counts as converged
+    }
+    move = wave_max(move);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dup += __shfl_xor(dup, o);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&move_of[g], __float_as_uint(move));
+        if (dup) atomicAdd(&dups_of[g], dup);
+    }
+}
+
+__global__ __launch_bounds__(kCompactBT) void big_compact_kernel(
+    float4* __restrict__ buf0, float4* __restrict__ buf1, int64_t stride, const int* __restrict__ big_ids, const int* __restrict__ counts,
+    int sets_per_count, float thresh, int t, int* __restrict__ len_of, int* __restrict__ state_of, unsigned* __restrict__ move_of,
+    int* __restrict__ dups_of, const unsigned* __restrict__ rep, unsigned* __restrict__ owner) {
+    __shared__ int wsum[kCompactBT / 64];
+    const int g = big_ids[blockIdx.x];
+    if (state_of[g] >> 29) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int U = len_of[g], dups = dups_of[g];
+    const float move = __uint_as_float(move_of[g]);
+    float4* cur = ((t & 1) ? buf0 : buf1) + g * stride;         // what round t wrote
+    float4* old = ((t & 1) ? buf1 : buf0) + g * stride;         // what it read: dead, its .w takes the new index of every representative
+    const unsigned* rp = rep + g * stride;
+    if (dups > 0) {
+        int base = 0;
+        for (int i0 = 0; i0 < U; i0 += 4 * kCompactBT) {
+            int f[4], loc = 0;
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 4 * tid + u;
+                f[u] = i < U && rp[i] == (unsigned)i;
+                if (f[u]) v[u] = cur[i];
+                loc += f[u];
+            }
+            int incl = loc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            __syncthreads();                                    // (wsum of the previous chunk has been read; every cur[i] of this chunk is in registers)
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int pre = 0, total = 0;
+            for (int i = 0; i < kCompactBT / 64; ++i) {
+                const int w = wsum[i];
+                pre += i < wave ? w : 0;
+                total += w;
+            }
+            int k = base + pre + incl - loc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (f[u]) {
+                    cur[k] = v[u];                              // k <= i: a slot of this chunk (already in registers) or of an earlier one
+                    old[i0 + 4 * tid + u].w = __int_as_float(k);
+                    ++k;
+                }
+            base += total;
+        }
+        __syncthreads();
+        unsigned* own = owner + g * stride;
+        const int M = counts[g / sets_per_count];
+        for (int j = tid; j < M; j += kCompactBT) own[j] = (unsigned)__float_as_int(old[rp[own[j]]].w);
+        if (tid == 0) len_of[g] = base;
+    }
+    if (tid == 0) {
+        // given up (bit 29): after kBigGiveUp rounds nearly every position is still distinct -- scattered votes that will not meet
+        // (a random-init network's); the set goes to the round-by-round path without spending the other chip-wide rounds
+        const int len = len_of[g];
+        const bool lost = t + 1 >= kBigGiveUp && len > kCap && len > counts[g / sets_per_count] - counts[g / sets_per_count] / 16;
+        state_of[g] = (t + 1) | (move < thresh ? 1 << 30 : 0) | (lost ? 1 << 29 : 0);
+        move_of[g] = 0u;
+        dups_of[g] = 0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void big_labels_kernel(
+    const int* __restrict__ big_ids, const int* __restrict__ counts, int sets_per_count, int64_t stride, const int* __restrict__ len_of,
+    int cap, const unsigned char* __restrict__ fit_labels, const unsigned* __restrict__ owner, unsigned char* __restrict__ labels) {
+    const int g = big_ids[blockIdx.y];
+    if (len_of[g] > cap) return;                                // (left to the round-by-round path)
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= stride) return;
+    labels[g * stride + j] = j < counts[g / sets_per_count] ? fit_labels[g * stride + owner[g * stride + j]] : (unsigned char)0;
 }
 
 template <typename MaskT>
@@ -762,6 +935,9 @@ void ffb6d_pose_set_fit_form(int form) { g_fit_form = form; }
 // 2 = always, 0 = never
 static int g_fit_spread = 1;
 void ffb6d_pose_set_fit_spread(int on) { g_fit_spread = on; }
+// sets of more than 4096 points: 1 (default) = chip-wide rounds with duplicate merging, then the one-workgroup fit; 0 = the round-by-round path
+static int g_big_form = 1;
+void ffb6d_pose_set_big_form(int form) { g_big_form = form; }
 
 
 int ffb6d_vote_sets_f32(const float* pcld, const float* offsets, const void* mask, int mask_bits,
@@ -787,8 +963,11 @@ int ffb6d_vote_sets_f32(const float* pcld, const float* offsets, const void* mas
 
 size_t ffb6d_mean_shift_workspace_bytes(int G, int64_t set_stride) {
     if (G <= 0 || set_stride <= 0) return 0;
+    // two position buffers, the tail of the round-by-round path (shift, rounds, best), and for the chip-wide rounds of the sets beyond
+    // the one-workgroup fit: representative and owner maps (u32 per point each) + five ints per set
     return 2 * align256(static_cast<size_t>(G) * set_stride * sizeof(float4)) + align256(3 * sizeof(unsigned) * G) +
-           align256(sizeof(int) * G) + align256(sizeof(unsigned long long) * G);
+           align256(sizeof(int) * G) + align256(sizeof(unsigned long long) * G) +
+           2 * align256(static_cast<size_t>(G) * set_stride * sizeof(unsigned)) + align256(5 * sizeof(int) * G);
 }
 
 int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_count, int G, int64_t set_stride,
@@ -815,7 +994,14 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
     int* rounds = reinterpret_cast<int*>(tail + align256(3 * sizeof(unsigned) * G));
     unsigned long long* best =
         reinterpret_cast<unsigned long long*>(tail + align256(3 * sizeof(unsigned) * G) + align256(sizeof(int) * G));
-    FFB6D_HIP_TRY(hipMemsetAsync(tail, 0, need - 2 * buf_bytes, st));
+    const size_t tail_bytes = align256(3 * sizeof(unsigned) * G) + align256(sizeof(int) * G) + align256(sizeof(unsigned long long) * G);
+    const size_t map_bytes = align256(static_cast<size_t>(G) * set_stride * sizeof(unsigned));
+    unsigned* rep = reinterpret_cast<unsigned*>(tail + tail_bytes);
+    unsigned* owner = reinterpret_cast<unsigned*>(tail + tail_bytes + map_bytes);
+    int* big_ids = reinterpret_cast<int*>(tail + tail_bytes + 2 * map_bytes);
+    int *len_of = big_ids + G, *state_of = big_ids + 2 * G, *dups_of = big_ids + 4 * G;
+    unsigned* move_of = reinterpret_cast<unsigned*>(big_ids + 3 * G);
+    FFB6D_HIP_TRY(hipMemsetAsync(tail, 0, tail_bytes, st));
 
     const double inv_bw2 = 1.0 / (static_cast<double>(bandwidth) * static_cast<double>(bandwidth));
     const float k2 = static_cast<float>(-0.5 * 1.4426950408889634 * inv_bw2);
@@ -872,18 +1058,18 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
         if (g_fit_form == 1) {
             mean_shift_fit_kernel<512, kCapLight><<<static_cast<unsigned>(G), 512, fit_lds_bytes(kCapLight), st>>>(
                 s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large, 0, 0,
-                pre0, pre1, shift, G);
+                pre0, pre1, shift, G, nullptr, nullptr);
             FFB6D_LAUNCH_CHECK();
             if (set_stride > kCapLight) {
                 mean_shift_fit_kernel<1024, kCap><<<static_cast<unsigned>(G), 1024, fit_lds_bytes(kCap), st>>>(
                     s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large,
-                    kCapLight, 1, pre0, pre1, shift, G);
+                    kCapLight, 1, pre0, pre1, shift, G, nullptr, nullptr);
                 FFB6D_LAUNCH_CHECK();
             }
         } else {
             mean_shift_fit_kernel<1024, kCap><<<static_cast<unsigned>(G), 1024, fit_lds_bytes(kCap), st>>>(
                 s4, counts, sets_per_count, set_stride, k2, thresh, bandwidth, max_iter, centers, labels, n_inside, iters, rounds, n_large, 0, 1,
-                pre0, pre1, shift, G);
+                pre0, pre1, shift, G, nullptr, nullptr);
             FFB6D_LAUNCH_CHECK();
         }
     }
@@ -895,39 +1081,113 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
         if (large == 0) return 0;
     }
 
-    // ---- sets of more than kCap points: one launch per round for all of them (round-1 path) ----
+    // blocks beyond a set's count exit at once: the largest count sizes the grids
+    std::vector<int> host_counts(static_cast<size_t>(ceil_div(G, sets_per_count)));       // (the kernels index counts[g / sets_per_count], g < G)
+    FFB6D_HIP_TRY(hipMemcpyAsync(host_counts.data(), counts, sizeof(int) * host_counts.size(), hipMemcpyDeviceToHost, st));
+    FFB6D_HIP_TRY(hipStreamSynchronize(st));
+
+    // ---- sets of more than kCap points: chip-wide rounds with duplicate merging, then the one-workgroup fit (round 6) ----
+    const int* handed = nullptr;
+    if (fit_ok && g_big_form) {
+        std::vector<int> ids;
+        int64_t span = 1;
+        for (int g = 0; g < G; ++g) {
+            const int c = host_counts[g / sets_per_count];
+            if (c > kCap) { ids.push_back(g); span = std::max<int64_t>(span, std::min<int64_t>(c, set_stride)); }
+        }
+        const unsigned n_big = static_cast<unsigned>(ids.size());
+        FFB6D_HIP_TRY(hipMemsetAsync(big_ids, 0, 5 * sizeof(int) * G, st));
+        FFB6D_HIP_TRY(hipMemcpyAsync(big_ids, ids.data(), sizeof(int) * n_big, hipMemcpyHostToDevice, st));
+        big_init_kernel<<<dim3(static_cast<unsigned>(ceil_div(span, kBlock)), n_big), kBlock, 0, st>>>(reinterpret_cast<const float4*>(sets), counts, sets_per_count, set_stride,
+                                                                                                     big_ids, buf0, owner, len_of);
+        FFB6D_LAUNCH_CHECK();
+        std::vector<int> host_state(2 * static_cast<size_t>(G));           // len_of | state_of
+        bool polled = false;
+        for (int t = 0; t <= max_iter && t < kBigRounds; ++t) {
+            big_round_kernel<<<dim3(static_cast<unsigned>(ceil_div(span, kPointsPerBlock)), n_big), kBlock, 0, st>>>(
+                buf0, buf1, set_stride, big_ids, k2, t, len_of, state_of, rep, move_of, dups_of);
+            FFB6D_LAUNCH_CHECK();
+            big_compact_kernel<<<n_big, kCompactBT, 0, st>>>(buf0, buf1, set_stride, big_ids, counts, sets_per_count, thresh, t, len_of, state_of,
+                                                            move_of, dups_of, rep, owner);
+            FFB6D_LAUNCH_CHECK();
+            polled = false;
+            if (t >= 2) {                                      // (nothing merges in the first rounds)
+                FFB6D_HIP_TRY(hipMemcpyAsync(host_state.data(), len_of, 2 * sizeof(int) * G, hipMemcpyDeviceToHost, st));
+                FFB6D_HIP_TRY(hipStreamSynchronize(st));
+                polled = true;
+                bool ready = true;
+                span = 1;
+                for (int g : ids) {
+                    const bool conv = host_state[G + g] >> 29;          // converged or given up
+                    ready = ready && (conv || host_state[g] <= kCap);
+                    if (!conv) span = std::max<int64_t>(span, host_state[g]);
+                }
+                if (ready) break;
+            }
+        }
+        if (!polled) {
+            FFB6D_HIP_TRY(hipMemcpyAsync(host_state.data(), len_of, 2 * sizeof(int) * G, hipMemcpyDeviceToHost, st));
+            FFB6D_HIP_TRY(hipStreamSynchronize(st));
+        }
+        // the fits continue from the lists (sets whose list is still longer: untouched, counted below)
+        unsigned char* fit_labels = labels ? reinterpret_cast<unsigned char*>(rep) : nullptr;       // (the representatives are dead)
+        if (g_fit_form == 1) {
+            mean_shift_fit_kernel<512, kCapLight><<<static_cast<unsigned>(G), 512, fit_lds_bytes(kCapLight), st>>>(
+                buf0, len_of, 1, set_stride, k2, thresh, bandwidth, max_iter, centers, fit_labels, n_inside, iters, rounds, n_large, 0, 0,
+                nullptr, nullptr, nullptr, G, buf1, state_of);
+            FFB6D_LAUNCH_CHECK();
+        }
+        mean_shift_fit_kernel<1024, kCap><<<static_cast<unsigned>(G), 1024, fit_lds_bytes(kCap), st>>>(
+            buf0, len_of, 1, set_stride, k2, thresh, bandwidth, max_iter, centers, fit_labels, n_inside, iters, rounds, n_large,
+            g_fit_form == 1 ? kCapLight : 0, 0, nullptr, nullptr, nullptr, G, buf1, state_of);
+        FFB6D_LAUNCH_CHECK();
+        if (labels) {
+            big_labels_kernel<<<dim3(static_cast<unsigned>(ceil_div(set_stride, kBlock)), n_big), kBlock, 0, st>>>(
+                big_ids, counts, sets_per_count, set_stride, len_of, kCap, fit_labels, owner, labels);
+            FFB6D_LAUNCH_CHECK();
+        }
+        bool left = false;
+        for (int g : ids) left = left || host_state[g] > kCap;
+        if (!left) return 0;
+        handed = len_of;                                       // the round-by-round kernels skip the sets with lists of <= kCap positions
+    }
+
+    // ---- what is left: one launch per round for all of those sets (round-1 path) ----
     FFB6D_HIP_TRY(hipMemsetAsync(best, 0, sizeof(unsigned long long) * G, st));
     FFB6D_HIP_TRY(hipMemsetAsync(shift, 0, 3 * sizeof(unsigned) * G, st));     // (the spread rounds of the fits used two of the slots)
     FFB6D_HIP_TRY(hipMemcpyAsync(buf0, sets, static_cast<size_t>(G) * set_stride * sizeof(float4),
                                  hipMemcpyDeviceToDevice, st));
-    // blocks beyond a set's count exit at once: the largest count sizes the grid
-    std::vector<int> host_counts(static_cast<size_t>(ceil_div(G, sets_per_count)));       // (the kernels index counts[g / sets_per_count], g < G)
-    FFB6D_HIP_TRY(hipMemcpyAsync(host_counts.data(), counts, sizeof(int) * host_counts.size(), hipMemcpyDeviceToHost, st));
-    FFB6D_HIP_TRY(hipStreamSynchronize(st));
     int64_t span = 1;
     for (int c : host_counts) span = std::max<int64_t>(span, std::min<int64_t>(c, set_stride));
     (void)max_count;
     const dim3 grid(static_cast<unsigned>(ceil_div(span, kPointsPerBlock)), static_cast<unsigned>(G));
     std::vector<float> host_shift;
+    std::vector<int> host_handed;
     if (check_every > 0) host_shift.resize(G);
+    if (handed) {
+        host_handed.resize(G);
+        FFB6D_HIP_TRY(hipMemcpyAsync(host_handed.data(), handed, sizeof(int) * G, hipMemcpyDeviceToHost, st));
+        FFB6D_HIP_TRY(hipStreamSynchronize(st));
+    }
     for (int t = 0; t <= max_iter; ++t) {       // `it > max_iter` stops after max_iter+1 rounds (:47)
         mean_shift_round_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, k2, thresh,
-                                                         shift, rounds, t, G, min_cnt);
+                                                         shift, rounds, t, G, min_cnt, handed);
         FFB6D_LAUNCH_CHECK();
         if (check_every > 0 && (t + 1) % check_every == 0 && t < max_iter) {
             FFB6D_HIP_TRY(hipMemcpyAsync(host_shift.data(), shift + (t % 3) * G, sizeof(float) * G,
                                          hipMemcpyDeviceToHost, st));
             FFB6D_HIP_TRY(hipStreamSynchronize(st));
             bool all_done = true;
-            for (int g = 0; g < G && all_done; ++g) all_done = host_counts[g / sets_per_count] <= min_cnt || host_shift[g] < thresh;
+            for (int g = 0; g < G && all_done; ++g)
+                all_done = host_counts[g / sets_per_count] <= min_cnt || (handed && host_handed[g] <= min_cnt) || host_shift[g] < thresh;
             if (all_done) break;
         }
     }
-    ball_count_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best, min_cnt);
+    ball_count_kernel<<<grid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best, min_cnt, handed);
     FFB6D_LAUNCH_CHECK();
     const dim3 lgrid(static_cast<unsigned>(labels ? ceil_div(set_stride, kBlock) : 1), static_cast<unsigned>(G));
     ball_labels_kernel<<<lgrid, kBlock, 0, st>>>(buf0, buf1, counts, sets_per_count, set_stride, bandwidth, rounds, best,
-                                                 centers, labels, n_inside, iters, min_cnt);
+                                                 centers, labels, n_inside, iters, min_cnt, handed);
     FFB6D_LAUNCH_CHECK();
     return 0;
 }

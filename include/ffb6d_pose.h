@@ -55,6 +55,11 @@ void ffb6d_pose_set_fit_form(int form);
  * one-workgroup fits starting from them: 1 (default) = when G <= CUs / 2 (the fits alone would leave half of the chip idle),
  * 2 = always, 0 = never (every round inside the fit).  Identical results (same pair arithmetic). */
 void ffb6d_pose_set_fit_spread(int on);
+/* Sets of more than 4096 points: 1 (default) = their rounds run chip-wide on (position, multiplicity) lists with exact-duplicate merging
+ * until at most 4096 distinct positions are left (typically 8-10 rounds), then the one-workgroup fit continues; 0 = the round-by-round
+ * path (max_iter + 1 rounds of count^2 pairs).  Results agree to rounding (equal terms are collected, like in the one-workgroup fit).
+ * The call synchronises the stream while such sets are in flight (it reads the list lengths back), whatever check_every says. */
+void ffb6d_pose_set_big_form(int form);
 int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_count, int G,
                          int64_t set_stride, int64_t max_count, float bandwidth, int max_iter,
                          int check_every, float* centers, unsigned char* labels, int* n_inside,

@@ -119,6 +119,59 @@ def test_mean_shift_forms_give_the_same_bits(device):
             assert torch.equal(a, b), key
 
 
+def test_mean_shift_large_sets_chip_wide_rounds_then_one_workgroup(device):
+    """Round 6: sets of more than 4096 points run their rounds chip-wide on (position, multiplicity) lists with exact-duplicate merging
+    and continue in the one-workgroup fit once at most 4096 distinct positions are left (csrc/pose.hip big_round_kernel /
+    big_compact_kernel); before, they made max_iter + 1 rounds of count^2 pairs.  Both forms in one process, on clustered votes
+    (collapse within ~10 rounds), a scene-like cloud (collapses later), votes that come in pairs of equal points, and a lattice whose
+    points never meet (stays with the round-by-round kernels: equal bits); mixed with small sets in the same call; round limits that
+    end inside the chip-wide phase.  The 4200-point case is also held against the oracle in the test above."""
+    from ffb6d_amd import _lib
+    lib = _lib.load()
+    kBigPhase = 8                                               # rounds before anything of a scene-like cloud has merged
+    rng = np.random.RandomState(12)
+    sizes = (9000, 300, 12288, 4097, 6000, 5832, 2500, 7000)
+    clouds = [gen.ms_votes(800 + k, n) for k, n in enumerate(sizes)]
+    clouds[2] = (rng.rand(12288, 3).astype(np.float32) - 0.5) * np.float32([1.2, 1.0, 0.5])          # scene-like: many modes
+    clouds[4][3000:] = clouds[4][:3000]                                                              # every vote twice
+    g = np.arange(18, dtype=np.float32) * 0.2
+    clouds[5] = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)                     # 18^3 points 5 bandwidths apart
+    stride = 12288
+    sets = torch.zeros((len(sizes), stride, 4), device=device)
+    for k, c in enumerate(clouds):
+        sets[k, :len(c), :3] = torch.from_numpy(c).to(device)
+    counts = torch.tensor(sizes, dtype=torch.int32, device=device)
+    res = {}
+    try:
+        for form in (0, 1):
+            lib.ffb6d_pose_set_big_form(form)
+            for limit in (300, 0, 1, 3, 7):
+                res[form, limit] = [t.clone() for t in pose.mean_shift(sets, counts, 0.04, limit)]
+    finally:
+        lib.ffb6d_pose_set_big_form(1)
+    for limit in (300, 0, 1, 3, 7):
+        (c0, l0, n0, r0), (c1, l1, n1, r1) = res[0, limit], res[1, limit]
+        assert (r0 - r1).abs().max() <= (1 if limit == 300 else 0), (limit, r0.tolist(), r1.tolist())
+        for k, n in enumerate(sizes):
+            if n <= 4096 or k == 5:                             # the same kernels in both forms
+                assert torch.equal(c0[k], c1[k]) and torch.equal(l0[k], l1[k]) and int(n0[k]) == int(n1[k]), (limit, k)
+                continue
+            if limit == 300 and k == 2:
+                # many modes of nearly equal ball size: the arg-max may land in another mode; the winner's ball must be as large
+                assert abs(int(n0[k]) - int(n1[k])) <= max(2, int(0.01 * int(n0[k]))), (int(n0[k]), int(n1[k]))
+                continue
+            assert abs(int(n0[k]) - int(n1[k])) <= max(1, int(LABEL_FLIP * n)), (limit, k)
+            if limit != 300:
+                # stopped before the collapse: the arg-max picks among thousands of points whose ball sizes differ by a handful --
+                # rounding may pick a neighbour (inside the same ball)
+                assert (c0[k] - c1[k]).abs().max() <= 0.04, (limit, k, c0[k].tolist(), c1[k].tolist())
+                continue
+            assert (c0[k] - c1[k]).abs().max() <= CTR_TOL, (limit, k, c0[k].tolist(), c1[k].tolist())
+            flips = int((l0[k] != l1[k]).sum())
+            assert flips <= max(1, int(LABEL_FLIP * n)), (limit, k, flips)
+    assert int(res[1, 300][3][2]) > kBigPhase, res[1, 300][3].tolist()        # the scene-like set went on in the one-workgroup fit
+
+
 def test_mean_shift_round_limit_and_polling(device):
     """max_iter bounds the rounds (it > max_iter after max_iter+1 rounds, meanshift_pytorch.py:47);
     polling the stop flag every k rounds must not change the result."""
