@@ -98,6 +98,16 @@ __device__ __forceinline__ void lds_dma_wait()
 #endif
 }
 
+// an integer the compiler cannot see through: what is computed from the result is computed HERE (not hoisted out of the enclosing loop,
+// where it would hold registers across the whole loop)
+__device__ __forceinline__ int opaque(int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
 // make the compiler treat `v` as used HERE: the wait for the load that produces it is placed at this point of the instruction stream
 // (and not after vector-memory operations issued later, whose completion that wait would then include)
 __device__ __forceinline__ void use_here(unsigned v)

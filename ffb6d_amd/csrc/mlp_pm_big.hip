@@ -46,7 +46,10 @@ static_assert(BIG_LDS <= 160 * 1024, "LDS layout");
 // tile is requested while the last step of the current one is multiplied (its LDS stage is free by then), so a tile's epilogue -- its stores
 // drain behind the wave, nothing waits for them -- is followed by MFMAs at once instead of by the workgroup's exit, the launch of the
 // next one and a cold first request (~10 us of 36 per K = 1024 tile, profiles/r06_big_gemm_probe_v4.txt).
-// VAR (probes; 0 = the product form): bit 1 = no epilogue (the stores depend on a condition that never holds)
+// VAR (0 = the product form, one tile per workgroup): bit 1 = no epilogue (probe: the stores depend on a condition that never holds);
+// bit 2 = the tiles store directly from registers (32-byte pieces; the form of the tile sequences, whose images stay in use);
+// 8 = a step's operand requests spread between its MFMA groups instead of one burst in front (rejected); 10 / 14 = timing probes without
+// epilogue (wrong results): half of the fragment reads dropped / no operand requests after step 0
 template <int VAR>
 __global__ void __launch_bounds__(BIG_BLK)
 mlp_pm_big_kernel(const PmParams p)
@@ -115,6 +118,9 @@ mlp_pm_big_kernel(const PmParams p)
         }
     };
     auto request = [&](int s, int stage) {            // step s of the tile w_off points at -> LDS stage: 8 LDS-DMA instructions per thread
+        if constexpr (VAR == 14) {                    // (probe: MFMAs and fragment reads alone)
+            if (s > 0) return;
+        }
         const int seg = s * CB;
         const bool first = seg < kb1;
         const __amdgpu_buffer_rsrc_t rx = first ? rs_x1 : rs_x2;
@@ -126,13 +132,25 @@ mlp_pm_big_kernel(const PmParams p)
             lds_dma16(rx, wi + IMG + i * (64 * CB), first ? x1_off[i] : x2_off[i], xseg);
         }
     };
+    auto request_part = [&](int s, int stage, int i) { // quarter i of request(s, stage): rows 64 i .. 64 i + 63 of both images
+        if constexpr (VAR == 14) return;
+        const int seg = s * CB;
+        const bool first = seg < kb1;
+        const __amdgpu_buffer_rsrc_t rx = first ? rs_x1 : rs_x2;
+        unsigned char* wi = lds + stage * 2 * IMG + wave * (8 * CB) + i * (64 * CB);
+        lds_dma16(rs_w, wi, w_off[i], seg);
+        lds_dma16(rx, wi + IMG, first ? x1_off[i] : x2_off[i], first ? seg : seg - kb1);
+    };
 
     // fragment reads: lane l31 of a 32-row MFMA tile reads chunk 2 ks + kh of its row = LDS chunk (2 ks + kh) ^ ((l31 >> 1) & 7)
     // (tile rows start at multiples of 32); the chunk byte offset of sub-step ks is the one of sub-step 0 XOR 32 ks
     const int fo0 = (kh ^ ((l31 >> 1) & 7)) * 16;
     const int a_row = (wm * 128 + l31) * CB, b_row = IMG + (wn * 64 + l31) * CB;
     f32x16 acc[4][2];
-    auto multiply = [&](int stage) {                  // one step: 32 MFMAs per wave out of the images of `stage`
+    // one step: 32 MFMAs per wave out of the images of `stage`.  req_s >= 0 (VAR 8, a rejected form): step req_s is requested into the
+    // other stage ON THE WAY, a quarter in front of each group of 8 MFMAs, instead of as one burst in front of the step -- measured 3 %
+    // slower over the config-5 shapes (profiles/r06_big_gemm_probe_v10.txt): the burst does not hold the MFMAs up, the late quarter does
+    auto multiply = [&](int stage, int req_s) {
         const unsigned char* im = lds + stage * 2 * IMG;
         u32x4 wa[2][4], xb[2][2];
         auto frags = [&](int ks, u32x4 (&a)[4], u32x4 (&b)[2]) {
@@ -143,9 +161,11 @@ mlp_pm_big_kernel(const PmParams p)
             for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(im + a_row + i * (32 * CB) + fo);
         };
         frags(0, wa[0], xb[0]);
+        if constexpr (VAR == 10) frags(1, wa[1], xb[1]);      // (probe: MFMAs and requests without the fragment reads of sub-steps 2, 3)
 #pragma unroll
         for (int ks = 0; ks < CB / 32; ++ks) {
-            if (ks + 1 < CB / 32) frags(ks + 1, wa[(ks + 1) & 1], xb[(ks + 1) & 1]);
+            if ((VAR != 10) && ks + 1 < CB / 32) frags(ks + 1, wa[(ks + 1) & 1], xb[(ks + 1) & 1]);
+            if (req_s >= 0) request_part(req_s, stage ^ 1, ks);
             __builtin_amdgcn_sched_barrier(0);
             mfma_step<T, 4, 2>(acc, wa[ks & 1], xb[ks & 1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -192,9 +212,11 @@ mlp_pm_big_kernel(const PmParams p)
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int s = 0; s + 1 < nstage; ++s) {        // the last step is multiplied below, outside the loop
             const bool carried = s == 0 && ti > 0;    // step 1 was requested before the previous tile's stores (below)
-            if (!carried) request(s + 1, (g + 1) & 1);
+            if constexpr (VAR != 8) {
+                if (!carried) request(s + 1, (g + 1) & 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            multiply(g & 1);
+            multiply(g & 1, (VAR == 8 && !carried) ? s + 1 : -1);
             __builtin_amdgcn_sched_barrier(0);
             if (carried) {
                 // the previous tile's 16 stores are younger than the requests of step 1: wait for the requests only.  A plain
@@ -211,7 +233,7 @@ mlp_pm_big_kernel(const PmParams p)
             request(0, (g + 1) & 1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        multiply(g & 1);
+        multiply(g & 1, -1);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                              // (the next tile's first step has landed, every wave is done with this tile's images)
         ++g;
@@ -270,21 +292,60 @@ mlp_pm_big_kernel(const PmParams p)
                                   (__bf16)activate(v[3], slope)};
                 return __builtin_bit_cast(u32x2, b);
             };
+            // The tile of a one-tile workgroup (the automatic plan) goes out through LDS: the operand images are dead by now and
+            // nothing is in flight into them, so every wave lays its 64 points x 128 channels (16 KB, its own eighth of the images)
+            // down as rows of 256 bytes -- 16-byte chunk c of point row r at chunk slot c ^ (r & 15): the 32 rows one write instruction
+            // touches spread over all banks -- and reads it back row-wise: a store instruction then writes 4 whole rows of 256 bytes
+            // (eight full 128-byte lines) where the direct form below writes 32-byte pieces of 32 rows (32 partial lines; measured
+            // ~10 bytes per clock and CU, a quarter of the launch).  Same bits to the same addresses.
+            // (compile-time choice: with both forms in one kernel hipcc spills 67 registers; VAR 0 is launched with one tile per workgroup)
+            constexpr bool through_lds = (VAR & 4) == 0;
+            unsigned char* own = lds + wave * 16384;
+            auto piece = [&](int i, int j, int gp) -> u32x4 {   // the lane's 16 bytes of MFMA tile (i, j), channel pair group gp
+                const u32x2 lo = group(i, j, 2 * gp), hi = group(i, j, 2 * gp + 1);
+                const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], hi[0], false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
+                // lower lane: [own group 2gp | upper's group 2gp]; upper lane: [lower's group 2gp+1 | own group 2gp+1]
+                return u32x4{sx[0], sy[0], sx[1], sy[1]};
+            };
+            if constexpr (!through_lds) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            const int ch16 = c0 + (wm * 4 + i) * 32 + 16 * gp + 8 * kh;
+                            __builtin_amdgcn_raw_buffer_store_b128(piece(i, j, gp), rs_o,
+                                                                   (ch16 < p.cout && o_off[j] != OOB) ? o_off[j] + ch16 * SZ : OOB, 0, 0);
+                            if constexpr (HASY) __builtin_amdgcn_sched_barrier(0);     // (left free, the scheduler computes many groups ahead and spills them)
+                        }
+                return;
+            }
+            const int lw = opaque(lane);                  // (the write slots: computed here, not carried through the tile loop)
+            const int wbase = (lw & 31) * 256, wkey = lw & 15, wkh = lw >> 5;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int gp = 0; gp < 2; ++gp) {
-                        const u32x2 lo = group(i, j, 2 * gp), hi = group(i, j, 2 * gp + 1);
-                        const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], hi[0], false, false);
-                        const auto sy = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
-                        // lower lane: [own group 2gp | upper's group 2gp]; upper lane: [lower's group 2gp+1 | own group 2gp+1]
-                        const int ch16 = c0 + (wm * 4 + i) * 32 + 16 * gp + 8 * kh;
-                        const u32x4 ou = {sx[0], sy[0], sx[1], sy[1]};
-                        __builtin_amdgcn_raw_buffer_store_b128(ou, rs_o, (ch16 < p.cout && o_off[j] != OOB) ? o_off[j] + ch16 * SZ : OOB, 0, 0);
-                        if constexpr (HASY) __builtin_amdgcn_sched_barrier(0);     // (left free, the scheduler computes many groups ahead and spills them)
+                        // row j * 32 + l31 (row & 15 = l31 & 15), chunk 4 i + 2 gp + kh
+                        *reinterpret_cast<u32x4*>(own + j * 8192 + wbase + (((4 * i + 2 * gp + wkh) ^ wkey) * 16)) = piece(i, j, gp);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+            // (LDS instructions of one wave execute in order: the reads below see every lane's writes)
+            const int ln = opaque(lane);                  // (row offsets of the 16 stores: computed here, not carried through the tile loop)
+            const int rr = ln >> 4, pos = ln & 15;
+            const int rbase = rr * 256 + pos * 16;
+            const int r_first = r0 + wn * 64 + rr;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(own + k * 1024 + rbase);
+                const int r = r_first + 4 * k, ch8 = c0 + wm * 128 + ((pos ^ ((4 * k + rr) & 15)) * 8);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_o, (r < p.rows && ch8 < p.cout) ? (r * p.ldo + ch8) * SZ : OOB, 0, 0);
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
         };
         if (hasy) epilogue(std::true_type{});
         else epilogue(std::false_type{});
@@ -339,8 +400,12 @@ bool launch_pm_big_bf16(PmParams& p, hipStream_t st, int plan)
     int tpg = plan & 15;
     if (tpg == 0) tpg = big_form_plan(p.rows, p.cout);
     switch ((plan >> 4) & 15) {
-        case 0: return launch_big_var<0>(p, tpg, st);
+        case 0: return tpg == 1 ? launch_big_var<0>(p, tpg, st) : launch_big_var<4>(p, tpg, st);   // (tile sequences keep their images: direct stores)
         case 2: return launch_big_var<2>(p, tpg, st);
+        case 4: return launch_big_var<4>(p, tpg, st);
+        case 8: return launch_big_var<8>(p, tpg, st);
+        case 10: return launch_big_var<10>(p, tpg, st);
+        case 14: return launch_big_var<14>(p, tpg, st);
         default: return false;
     }
 }
