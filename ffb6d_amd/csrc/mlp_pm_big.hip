@@ -118,7 +118,7 @@ mlp_pm_big_kernel(const PmParams p)
         }
     };
     auto request = [&](int s, int stage) {            // step s of the tile w_off points at -> LDS stage: 8 LDS-DMA instructions per thread
-        if constexpr (VAR == 14) {                    // (probe: MFMAs and fragment reads alone)
+        if constexpr ((VAR & 15) == 14) {             // (probe: MFMAs and fragment reads alone)
             if (s > 0) return;
         }
         const int seg = s * CB;
@@ -133,7 +133,7 @@ mlp_pm_big_kernel(const PmParams p)
         }
     };
     auto request_part = [&](int s, int stage, int i) { // quarter i of request(s, stage): rows 64 i .. 64 i + 63 of both images
-        if constexpr (VAR == 14) return;
+        if constexpr ((VAR & 15) == 14) return;
         const int seg = s * CB;
         const bool first = seg < kb1;
         const __amdgpu_buffer_rsrc_t rx = first ? rs_x1 : rs_x2;
@@ -210,6 +210,44 @@ mlp_pm_big_kernel(const PmParams p)
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if constexpr (VAR & 16) {
+            // The one-tile workgroup's loop with the step boundary moved IN FRONT of a step's last 8 MFMAs: at that point the step's
+            // last fragments are in registers (every wave is done with the stage: the request for the step after next may overwrite
+            // it) and the next step's images have landed, so the barrier sits there, the next request and the next step's first
+            // fragment reads are issued behind it, and the 8 MFMAs run while those fragments travel -- in the plain loop every wave
+            // stands behind the barrier with nothing to multiply until 12 fragment reads per wave of all 8 waves have come back.
+            u32x4 wa[2][4], xb[2][2];
+            auto frags = [&](int stage, int ks, u32x4 (&a)[4], u32x4 (&b)[2]) {
+                const unsigned char* im = lds + stage * 2 * IMG;
+                const int fo = fo0 ^ (ks * 32);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const u32x4*>(im + b_row + j * (32 * CB) + fo);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(im + a_row + i * (32 * CB) + fo);
+            };
+            request(1, 1);                            // (at least two steps: big_form_ok)
+            frags(0, 0, wa[0], xb[0]);
+            for (int s = 0; s < nstage; ++s) {
+                const int st = s & 1;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    frags(st, ks + 1, wa[(ks + 1) & 1], xb[(ks + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step<T, 4, 2>(acc, wa[ks & 1], xb[ks & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (s + 1 < nstage) {
+                    __syncthreads();                  // (lgkmcnt(0): the last fragments of stage st; vmcnt(0): step s + 1 has landed)
+                    if (s + 2 < nstage) request(s + 2, st);
+                    frags(st ^ 1, 0, wa[0], xb[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step<T, 4, 2>(acc, wa[1], xb[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                          // (every wave is done with the images: the epilogue lays the tile over them)
+            g = nstage;
+        } else {
         for (int s = 0; s + 1 < nstage; ++s) {        // the last step is multiplied below, outside the loop
             const bool carried = s == 0 && ti > 0;    // step 1 was requested before the previous tile's stores (below)
             if constexpr (VAR != 8) {
@@ -237,6 +275,7 @@ mlp_pm_big_kernel(const PmParams p)
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                              // (the next tile's first step has landed, every wave is done with this tile's images)
         ++g;
+        }
         if constexpr (VAR & 2) {
             if (p.act != 77) continue;
         }
@@ -394,18 +433,21 @@ bool launch_big_var(PmParams& p, int tpg, hipStream_t st)
 // launch wherever the stores are issued.  Sequences stay available (tile_hint 9 + 256 * T; tests), the automatic plan is one tile.
 int big_form_plan(int64_t, int64_t) { return 1; }
 
-// plan: bits 0-3 = tiles per workgroup (0: big_form_plan), bits 4-7 = probe variant
+// plan: bits 0-3 = tiles per workgroup (0: big_form_plan), bits 4-8 = variant
 bool launch_pm_big_bf16(PmParams& p, hipStream_t st, int plan)
 {
     int tpg = plan & 15;
     if (tpg == 0) tpg = big_form_plan(p.rows, p.cout);
-    switch ((plan >> 4) & 15) {
+    switch ((plan >> 4) & 31) {
         case 0: return tpg == 1 ? launch_big_var<0>(p, tpg, st) : launch_big_var<4>(p, tpg, st);   // (tile sequences keep their images: direct stores)
         case 2: return launch_big_var<2>(p, tpg, st);
         case 4: return launch_big_var<4>(p, tpg, st);
         case 8: return launch_big_var<8>(p, tpg, st);
         case 10: return launch_big_var<10>(p, tpg, st);
         case 14: return launch_big_var<14>(p, tpg, st);
+        case 16: return launch_big_var<16>(p, 1, st);
+        case 18: return launch_big_var<18>(p, 1, st);
+        case 30: return launch_big_var<30>(p, 1, st);
         default: return false;
     }
 }

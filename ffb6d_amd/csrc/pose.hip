@@ -1096,12 +1096,13 @@ int ffb6d_mean_shift_f32(const float* sets, const int* counts, int sets_per_coun
             if (c > kCap) { ids.push_back(g); span = std::max<int64_t>(span, std::min<int64_t>(c, set_stride)); }
         }
         const unsigned n_big = static_cast<unsigned>(ids.size());
+        if (n_big == 0) return 0;                              // (every set was fitted above)
         FFB6D_HIP_TRY(hipMemsetAsync(big_ids, 0, 5 * sizeof(int) * G, st));
         FFB6D_HIP_TRY(hipMemcpyAsync(big_ids, ids.data(), sizeof(int) * n_big, hipMemcpyHostToDevice, st));
         big_init_kernel<<<dim3(static_cast<unsigned>(ceil_div(span, kBlock)), n_big), kBlock, 0, st>>>(reinterpret_cast<const float4*>(sets), counts, sets_per_count, set_stride,
                                                                                                      big_ids, buf0, owner, len_of);
         FFB6D_LAUNCH_CHECK();
-        std::vector<int> host_state(2 * static_cast<size_t>(G));           // len_of | state_of
+        std::vector<int> host_state(2 * static_cast<size_t>(G));           // len_of | state_of: adjacent in the workspace, one copy
         bool polled = false;
         for (int t = 0; t <= max_iter && t < kBigRounds; ++t) {
             big_round_kernel<<<dim3(static_cast<unsigned>(ceil_div(span, kPointsPerBlock)), n_big), kBlock, 0, st>>>(

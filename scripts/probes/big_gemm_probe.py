@@ -42,11 +42,12 @@ for K1, K2, C, P, py, role in SHAPES:
     auto = ops_pm._lib.load().ffb6d_mlp_pm_choice(B * P, C, K1, K2, 1, 1, 0) & 255
     variants = []
     for v in hints:
+        out.zero_()
         try:
             got = ops_pm.mlp(x1, w, b, 1, x2=x2, out=out, tile_hint=v, **kw)
         except Exception as e:           # a form that does not take this shape
             continue
-        if not (v >> 8) & 2:             # (probe variants without an epilogue write nothing)
+        if not (v >> 12) & 2:            # (probe variants without an epilogue write nothing; variant = bits 12.. of the hint)
             assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (role, v)
         variants.append(v)
     times = {v: [] for v in variants}
