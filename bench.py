@@ -299,6 +299,10 @@ def run_e2e(args, dev, net, frames):
                                f"overlapped = input assembly of batch i+1 and pose solver of batch i on side streams under the forward of "
                                f"batch i+1 (ffb6d_amd/pipeline.py)"},
         "e2e": out,
+        "e2e_note": "synthetic_votes is the measured workload (5 objects per frame, ~1700 clustered votes per set).  network_votes feeds the "
+                    "random-init network's own outputs to the solver: one class for all 12288 points and offsets of ~80 m, i.e. one "
+                    "scattered 12288-vote set per frame whose points never meet -- max_iter + 1 rounds of 12288^2 pairs "
+                    "(profiles/r06_pose_netvotes_probe.txt); kept as the solver's worst case, not a pose workload",
         "reference_published": "57 ms forward + 18 ms pose = 75 ms per FRAME on the reference's GPU (README.md:305-330); other hardware, "
                                "not a baseline for vs_baseline",
         "roofline": None,
