@@ -114,6 +114,24 @@ def test_workspace_query_is_pure_host_logic(native_lib):
     assert native_lib.ffb6d_knn_workspace_bytes(0, 10, 10, 16) == 0
 
 
+def test_pose_solver_workspace_and_form_switches_are_host_logic(native_lib):
+    """Round 6: the mean-shift workspace also holds the representative / owner maps (u32 per point each) and five ints per set of the
+    chip-wide rounds of large vote sets; the form switches are plain setters (pose.set_fit_spread keeps a Python-side mirror that
+    pipeline.SensorToPose.run uses to switch the chip-wide first rounds off under the overlapped schedule and restore them)."""
+    from ffb6d_amd import pose
+    a256 = lambda n: (n + 255) // 256 * 256                                      # noqa: E731
+    G, stride = 40, 12288
+    want = 2 * a256(G * stride * 16) + a256(3 * 4 * G) + a256(4 * G) + a256(8 * G) + 2 * a256(G * stride * 4) + a256(5 * 4 * G)
+    assert native_lib.ffb6d_mean_shift_workspace_bytes(G, stride) == want
+    assert native_lib.ffb6d_mean_shift_workspace_bytes(0, stride) == 0
+    assert pose.FIT_SPREAD == 1
+    assert pose.set_fit_spread(0) == 1 and pose.FIT_SPREAD == 0
+    assert pose.set_fit_spread(1) == 0 and pose.FIT_SPREAD == 1
+    for setter in ("ffb6d_pose_set_fit_form", "ffb6d_pose_set_big_form"):
+        getattr(native_lib, setter)(0)
+        getattr(native_lib, setter)(1)
+
+
 def test_argument_errors_are_reported_without_a_gpu(native_lib):
     from ffb6d_amd import _lib
     rc = native_lib.ffb6d_knn_batch_device(None, None, 1, 100, 10, 64, None, None, None, None, 0, None)
